@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu`)")
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The C-ABI library + a CUDA(HIP) device; skips only when no GPU is present."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU in this container")
+    from ampligraph_amd import _ffi
+
+    return _ffi.lib()

