@@ -1,0 +1,105 @@
+"""ctypes binding of libamdkge.so (C ABI declared in include/amdkge.h).
+
+The library is the product: there is no CPU fallback.  `lib()` raises `AmdKgeLibraryError` when the
+shared object is missing or does not export the ABI version this package was written for.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libamdkge.so")
+ABI_VERSION = 1
+
+# enums of include/amdkge.h
+SCORING_TYPES = {"TransE": 0, "DistMult": 1, "ComplEx": 2, "HolE": 3, "RotatE": 4}
+LOSSES = {"pairwise": 0, "nll": 1, "absolute_margin": 2, "self_adversarial": 3, "multiclass_nll": 4}
+OPTIMIZERS = {"sgd": 0, "adagrad": 1, "adam": 2}
+SIDE_S, SIDE_O = 1, 2
+RANK_STRATEGY = {"worst": 0, "best": 1, "middle": 2}
+
+
+class AmdKgeLibraryError(RuntimeError):
+    pass
+
+
+class AmdKgeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libamdkge error {code}: {msg}")
+        self.code = code
+
+
+class Model(C.Structure):
+    _fields_ = [("scoring_type", C.c_int32), ("k", C.c_int32), ("n_ents", C.c_int64), ("n_rels", C.c_int64),
+                ("max_rel_size", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Loss(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reduction_mean", C.c_int32), ("margin", C.c_float), ("alpha", C.c_float)]
+
+
+class Opt(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reg_p", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("epsilon", C.c_float), ("reg_lambda", C.c_float), ("iteration", C.c_int64)]
+
+
+P = C.c_void_p
+I64 = C.c_int64
+I32 = C.c_int32
+U64 = C.c_uint64
+
+# name -> (restype, argtypes): every symbol include/amdkge.h declares
+SIGNATURES = {
+    "amdkge_abi_version": (C.c_int, []),
+    "amdkge_last_error": (C.c_char_p, []),
+    "amdkge_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "amdkge_set_device": (C.c_int, [C.c_int]),
+    "amdkge_dev_alloc": (C.c_int, [C.POINTER(P), U64]),
+    "amdkge_dev_free": (C.c_int, [P]),
+    "amdkge_h2d": (C.c_int, [P, P, U64, P]),
+    "amdkge_d2h": (C.c_int, [P, P, U64, P]),
+    "amdkge_dev_memset": (C.c_int, [P, C.c_int, U64, P]),
+    "amdkge_stream_sync": (C.c_int, [P]),
+    "amdkge_internal_k": (C.c_int, [C.c_int, C.c_int]),
+    "amdkge_score": (C.c_int, [C.POINTER(Model), P, P, P, I64, P, P]),
+    "amdkge_sample_corruptions": (C.c_int, [P, I64, I32, I64, I64, U64, U64, I64, I64, P, P]),
+    "amdkge_train_fwdbwd": (C.c_int, [C.POINTER(Model), C.POINTER(Loss), P, P, P, I64, I32, I64, I64, U64, U64,
+                                      I64, I64, P, P, P, P, P, P, P]),
+    "amdkge_opt_step": (C.c_int, [C.POINTER(Opt), P, P, P, P, I64, P, P]),
+    "amdkge_rank_workspace_bytes": (I64, [C.POINTER(Model), I64]),
+    "amdkge_rank_counts": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, I64, I64, P, P, P]),
+    "amdkge_rank_filter": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, P, P, P, I64, I64, P, P, P]),
+    "amdkge_rank_compose": (C.c_int, [P, P, I64, I32, P, I64, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raise loudly if it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmdKgeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ampligraph_amd/csrc`). ampligraph_amd has no CPU fallback.")
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise AmdKgeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise AmdKgeLibraryError(f"{LIB_PATH} does not export {name}; stale build?") from e
+        fn.restype = res
+        fn.argtypes = args
+    if handle.amdkge_abi_version() != ABI_VERSION:
+        raise AmdKgeLibraryError("libamdkge ABI version mismatch; rebuild the library")
+    _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AmdKgeError(rc, lib().amdkge_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,44 @@
+// Host-side helpers shared by the translation units of libamdkge: error reporting that never
+// throws across the C ABI, argument validation, per-model constants.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/amdkge.h"
+#include "kge_device.h"
+
+namespace kge {
+
+int set_error(int code, const char* msg);            // stores a thread-local message, returns code
+int set_error_hip(hipError_t e, const char* where);  // AMDKGE_EHIP with hipGetErrorString
+int check_launch(const char* kernel_name);           // hipGetLastError() after a launch
+
+inline int validate_model(const amdkge_model* m) {
+    if (!m) return set_error(AMDKGE_EINVAL, "model descriptor is NULL");
+    if (m->scoring_type < AMDKGE_TRANSE || m->scoring_type > AMDKGE_ROTATE)
+        return set_error(AMDKGE_EINVAL, "unknown scoring_type (expected TransE/DistMult/ComplEx/HolE/RotatE)");
+    if (m->k <= 0) return set_error(AMDKGE_EINVAL, "k must be positive");
+    if (m->n_ents <= 0 || m->n_rels <= 0)
+        return set_error(AMDKGE_EINVAL, "entity / relation table sizes must be positive (model not built?)");
+    if (m->n_ents > 0x7FFFFFFFll || m->n_rels > 0x7FFFFFFFll)
+        return set_error(AMDKGE_EINVAL, "row ids are int32: tables are limited to 2^31-1 rows");
+    return AMDKGE_OK;
+}
+
+inline ModelConst model_const(const amdkge_model* m) {
+    ModelConst mc;
+    mc.score_scale = 1.f;
+    mc.score_sign = 1.f;
+    mc.phase_div = 1.f;
+    if (m->scoring_type == AMDKGE_TRANSE || m->scoring_type == AMDKGE_ROTATE) mc.score_sign = -1.f;
+    if (m->scoring_type == AMDKGE_HOLE) mc.score_scale = (float)(2.0 / (double)m->k);  // HolE.py:45
+    if (m->scoring_type == AMDKGE_ROTATE) {
+        const double R = m->max_rel_size > 0 ? (double)m->max_rel_size : 1.0;           // RotatE.py:87-94
+        const double embedding_range = sqrt(6.0 / (2.0 * (double)m->k * R));            // RotatE.py:95
+        mc.phase_div = (float)(embedding_range / 3.14159265358979323846);               // :96 (pi from math)
+    }
+    return mc;
+}
+
+}  // namespace kge

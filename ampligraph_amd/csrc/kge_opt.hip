@@ -1,0 +1,125 @@
+// Dense optimizer sweep fused with the whole-table LP regulariser and the gradient-buffer reset.
+// Replaces OptimizerWrapper.minimize -> Keras *legacy* apply_gradients
+// (/root/reference/ampligraph/latent_features/optimizers.py:136-168; update rules live in the
+// third-party tensorflow==2.15 wheel, keras/optimizers/legacy/{adam,adagrad,gradient_descent}.py)
+// and LP_regularizer (regularizers.py:35-37).  Non-lazy like the reference: every row's slots
+// decay and every row moves each step.  HBM-bound: reads x,m,v,g and writes x,m,v,g(=0), 16 B/lane.
+#include "kge_host.h"
+
+namespace kge {
+
+struct OptArgs {
+    float* x;
+    float* g;
+    float* s0;
+    float* s1;
+    int64_t n;
+    double* reg_loss;
+    float lr, lr_t, beta1, beta2, omb1, omb2, eps, lam;
+    int kind, reg_p;
+};
+
+__device__ __forceinline__ float ipowf(float a, int p) {
+    float r = 1.f;
+    for (int i = 0; i < p; ++i) r *= a;
+    return r;
+}
+
+template <int KIND>
+__device__ __forceinline__ void opt_elem(const OptArgs& a, float& x, float g, float& s0, float& s1, float& reg_acc) {
+    if (a.lam != 0.f) {
+        const float ax = fabsf(x);
+        // lambda * sum |x|^p ; d/dx = lambda * p * |x|^(p-1) * sign(x)
+        reg_acc += ipowf(ax, a.reg_p);
+        const float sg = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+        g += a.lam * (float)a.reg_p * ipowf(ax, a.reg_p - 1) * sg;
+    }
+    if constexpr (KIND == AMDKGE_OPT_ADAM) {
+        s0 = s0 * a.beta1 + g * a.omb1;
+        s1 = s1 * a.beta2 + (g * g) * a.omb2;
+        x -= (a.lr_t * s0) / (sqrtf(s1) + a.eps);
+    } else if constexpr (KIND == AMDKGE_OPT_ADAGRAD) {
+        s0 += g * g;
+        x -= a.lr * g / (sqrtf(s0) + a.eps);
+    } else {
+        x -= a.lr * g;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_kernel(OptArgs a) {
+    const int64_t n4 = a.n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float reg_acc = 0.f;
+    float4* x4 = reinterpret_cast<float4*>(a.x);
+    float4* g4 = reinterpret_cast<float4*>(a.g);
+    float4* m4 = reinterpret_cast<float4*>(a.s0);
+    float4* v4 = reinterpret_cast<float4*>(a.s1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 x = x4[i], g = g4[i];
+        float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
+        if constexpr (KIND != AMDKGE_OPT_SGD) m = m4[i];
+        if constexpr (KIND == AMDKGE_OPT_ADAM) v = v4[i];
+        opt_elem<KIND>(a, x.x, g.x, m.x, v.x, reg_acc);
+        opt_elem<KIND>(a, x.y, g.y, m.y, v.y, reg_acc);
+        opt_elem<KIND>(a, x.z, g.z, m.z, v.z, reg_acc);
+        opt_elem<KIND>(a, x.w, g.w, m.w, v.w, reg_acc);
+        x4[i] = x;
+        g4[i] = make_float4(0, 0, 0, 0);
+        if constexpr (KIND != AMDKGE_OPT_SGD) m4[i] = m;
+        if constexpr (KIND == AMDKGE_OPT_ADAM) v4[i] = v;
+    }
+    // scalar tail (n % 4)
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        float x = a.x[i], g = a.g[i], m = 0.f, v = 0.f;
+        if constexpr (KIND != AMDKGE_OPT_SGD) m = a.s0[i];
+        if constexpr (KIND == AMDKGE_OPT_ADAM) v = a.s1[i];
+        opt_elem<KIND>(a, x, g, m, v, reg_acc);
+        a.x[i] = x;
+        a.g[i] = 0.f;
+        if constexpr (KIND != AMDKGE_OPT_SGD) a.s0[i] = m;
+        if constexpr (KIND == AMDKGE_OPT_ADAM) a.s1[i] = v;
+    }
+    if (a.reg_loss && a.lam != 0.f) {
+        __shared__ float red[4];
+        const float w = wave_sum(reg_acc);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(a.reg_loss, (double)a.lam * ((double)red[0] + red[1] + red[2] + red[3]));
+    }
+}
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_slot0, float* d_slot1,
+                               int64_t n_elems, double* d_reg_loss, void* stream) {
+    if (!opt) return set_error(AMDKGE_EINVAL, "opt_step: NULL optimizer descriptor");
+    if (opt->kind < AMDKGE_OPT_SGD || opt->kind > AMDKGE_OPT_ADAM) return set_error(AMDKGE_EINVAL, "opt_step: unknown optimizer kind");
+    if (n_elems < 0) return set_error(AMDKGE_EINVAL, "opt_step: n_elems must be >= 0");
+    if (n_elems == 0) return AMDKGE_OK;
+    if (!d_x || !d_grad) return set_error(AMDKGE_EINVAL, "opt_step: NULL table / gradient pointer");
+    if (opt->kind != AMDKGE_OPT_SGD && !d_slot0) return set_error(AMDKGE_EINVAL, "opt_step: optimizer slot 0 is NULL");
+    if (opt->kind == AMDKGE_OPT_ADAM && !d_slot1) return set_error(AMDKGE_EINVAL, "opt_step: Adam slot 1 (v) is NULL");
+    if (opt->iteration < 1) return set_error(AMDKGE_EINVAL, "opt_step: iteration is 1-based");
+    if (opt->reg_lambda != 0.f && opt->reg_p < 1) return set_error(AMDKGE_EINVAL, "opt_step: regulariser p must be >= 1");
+    if ((((uintptr_t)d_x | (uintptr_t)d_grad | (uintptr_t)d_slot0 | (uintptr_t)d_slot1) & 15) != 0)
+        return set_error(AMDKGE_EINVAL, "opt_step: buffers must be 16-byte aligned");
+    OptArgs a{};
+    a.x = d_x; a.g = d_grad; a.s0 = d_slot0; a.s1 = d_slot1; a.n = n_elems; a.reg_loss = d_reg_loss;
+    a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->epsilon;
+    a.omb1 = (float)(1.0 - (double)opt->beta1);   // python: 1 - beta_1, cast to fp32 like the TF constant
+    a.omb2 = (float)(1.0 - (double)opt->beta2);
+    a.lam = opt->reg_lambda; a.kind = opt->kind; a.reg_p = opt->reg_p;
+    const double t = (double)opt->iteration;
+    a.lr_t = (float)((double)opt->lr * sqrt(1.0 - pow((double)opt->beta2, t)) / (1.0 - pow((double)opt->beta1, t)));
+    const int64_t n4 = (n_elems + 3) / 4;
+    unsigned grid = (unsigned)((n4 + 255) / 256);
+    if (grid > 2048) grid = 2048;   // 256 CUs x 8 blocks, grid-stride beyond
+    hipStream_t st = (hipStream_t)stream;
+    if (opt->kind == AMDKGE_OPT_ADAM) hipLaunchKernelGGL(opt_kernel<AMDKGE_OPT_ADAM>, dim3(grid), dim3(256), 0, st, a);
+    else if (opt->kind == AMDKGE_OPT_ADAGRAD) hipLaunchKernelGGL(opt_kernel<AMDKGE_OPT_ADAGRAD>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(opt_kernel<AMDKGE_OPT_SGD>, dim3(grid), dim3(256), 0, st, a);
+    return check_launch("opt_step");
+}

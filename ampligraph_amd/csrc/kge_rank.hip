@@ -1,0 +1,483 @@
+// evaluate(): 1-vs-all ranking for gfx950.  Replaces AbstractScoringLayer.get_ranks
+// (/root/reference/ampligraph/latent_features/layers/scoring/AbstractScoringLayer.py:156-422) and the
+// five `_get_{subject,object}_corruption_scores` (TransE.py:56-114, DistMult.py:51-99,
+// ComplEx.py:65-151, HolE.py:47-89, RotatE.py:107-217) without ever materialising the reference's
+// (n, m, K) broadcast temporaries or the (n, m) score matrix:
+//
+//   rank_prep   : per test triple, the quantised positive score q(pos) and the side's "query vector"
+//                 (everything of the corruption score that does not depend on the corrupting entity,
+//                 rounded exactly where the reference rounds it, e.g. DistMult fl(p*o)).
+//   rank_counts : LDS-tiled (64 queries x 64 entities x 16 units) score tile with a
+//                 quantise -> compare -> count epilogue; only two int32 counters per triple leave the CU.
+//   rank_filter : per triple, recomputes the few true-positive corruptions with the SAME k-ordered
+//                 accumulation chain (bitwise the scores the tile kernel produced) and counts those that
+//                 outrank the positive (always "<=", AbstractScoringLayer.py:292-303).
+//   rank_compose: tie strategy + filter subtraction + 1 (ScoringBasedEmbeddingModel.py:1684).
+#include "kge_host.h"
+
+namespace kge {
+
+enum { MODE_DOT = 0, MODE_L1 = 1, MODE_ROT_O = 2, MODE_ROT_S = 3 };
+
+template <int MODE> struct ModeTraits;
+template <> struct ModeTraits<MODE_DOT>   { static constexpr int NQF = 1, NEF = 1; };
+template <> struct ModeTraits<MODE_L1>    { static constexpr int NQF = 1, NEF = 1; };
+template <> struct ModeTraits<MODE_ROT_O> { static constexpr int NQF = 2, NEF = 2; };
+template <> struct ModeTraits<MODE_ROT_S> { static constexpr int NQF = 4, NEF = 2; };
+
+// One unit of the corruption score, accumulated in unit order.  Shared by the tile kernel and the
+// filter kernel so that both produce bitwise identical scores (compiled with -ffp-contract=off).
+template <int MODE>
+__device__ __forceinline__ float rank_op(float acc, const float (&q)[ModeTraits<MODE>::NQF],
+                                         const float (&e)[ModeTraits<MODE>::NEF], float sgn) {
+    if constexpr (MODE == MODE_DOT) {
+        return fmaf(q[0], e[0], acc);
+    } else if constexpr (MODE == MODE_L1) {
+        return acc + fabsf(q[0] + sgn * e[0]);   // subj: e + (p - o) ; obj: (s + p) - e
+    } else if constexpr (MODE == MODE_ROT_O) {
+        const float re = q[0] - e[0], im = q[1] - e[1];   // RotatE.py:209-214
+        return acc + sqrtf(re * re + im * im);
+    } else {
+        // q = (cos, sin, o_re, o_im) ; RotatE.py:151-160
+        const float re = e[0] * q[0] - e[1] * q[1] - q[2];
+        const float im = e[0] * q[1] + e[1] * q[0] - q[3];
+        return acc + sqrtf(re * re + im * im);
+    }
+}
+
+struct RankGeom {
+    int U;        // units accumulated per (query, entity)
+    int eplane;   // float offset between entity planes (re/im halves), 0 if NEF == 1
+    int qplane;   // float offset between query planes
+    int QW;       // floats per query row in the workspace
+    int K;        // floats per table row
+    float sgn;    // MODE_L1: +1 subject side, -1 object side
+};
+
+__host__ __device__ inline int mode_of(int model, int side) {
+    if (model == AMDKGE_TRANSE) return MODE_L1;
+    if (model == AMDKGE_ROTATE) return side == AMDKGE_SIDE_S ? MODE_ROT_S : MODE_ROT_O;
+    return MODE_DOT;
+}
+
+inline RankGeom geom_of(const amdkge_model* m, int side) {
+    RankGeom g{};
+    g.K = internal_k_of(m->scoring_type, m->k);
+    const int mode = mode_of(m->scoring_type, side);
+    if (mode == MODE_DOT || mode == MODE_L1) { g.U = g.K; g.eplane = 0; g.qplane = 0; g.QW = g.K; }
+    else { g.U = m->k; g.eplane = m->k; g.qplane = m->k; g.QW = (mode == MODE_ROT_S ? 4 : 2) * m->k; }
+    g.sgn = (side == AMDKGE_SIDE_S) ? 1.f : -1.f;
+    return g;
+}
+
+__device__ __forceinline__ int quantise(float score) {
+    return (int)(score * 1000.0f);   // AbstractScoringLayer.py:201 tf.cast(score * 1e3, int32): truncation
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: one wave per test triple
+// ------------------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(256) void rank_prep_kernel(const float* __restrict__ ent, const float* __restrict__ rel,
+                                                        const int32_t* __restrict__ triples, int64_t n, int k, int K,
+                                                        int side, int QW, ModelConst mc, float* __restrict__ Q,
+                                                        int* __restrict__ qpos) {
+    constexpr int NC = ModelTraits<MODEL>::NC;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* rs = ent + (int64_t)triples[3 * i + 0] * K;
+    const float* rp = rel + (int64_t)triples[3 * i + 1] * K;
+    const float* ro = ent + (int64_t)triples[3 * i + 2] * K;
+    float* q = Q + i * (int64_t)QW;
+    float part = 0.f;
+    for (int c = lane; c < k; c += KGE_WAVE) {
+        float s[NC], p[NC], o[NC];
+#pragma unroll
+        for (int h = 0; h < NC; ++h) { s[h] = rs[c + h * k]; p[h] = rp[c + h * k]; o[h] = ro[c + h * k]; }
+        prep_rel<MODEL>(mc, p);
+        part += score_unit<MODEL>(s, p, o);
+        if constexpr (MODEL == AMDKGE_TRANSE) {
+            q[c] = (side == AMDKGE_SIDE_S) ? (p[0] - o[0]) : (s[0] + p[0]);           // TransE.py:77-83,107-113
+        } else if constexpr (MODEL == AMDKGE_DISTMULT) {
+            q[c] = (side == AMDKGE_SIDE_S) ? (p[0] * o[0]) : (s[0] * p[0]);           // DistMult.py:71-73,96-98
+        } else if constexpr (MODEL == AMDKGE_COMPLEX) {
+            if (side == AMDKGE_SIDE_S) {   // ComplEx.py:93-107
+                q[c] = p[0] * o[0] + p[1] * o[1];
+                q[c + k] = p[0] * o[1] - p[1] * o[0];
+            } else {                        // ComplEx.py:138-150
+                q[c] = s[0] * p[0] - s[1] * p[1];
+                q[c + k] = s[1] * p[0] + s[0] * p[1];
+            }
+        } else {
+            if (side == AMDKGE_SIDE_S) {   // RotatE.py:151-160: needs cos, sin, o_re, o_im per unit
+                q[c] = p[0]; q[c + k] = p[1]; q[c + 2 * k] = o[0]; q[c + 3 * k] = o[1];
+            } else {                        // RotatE.py:209-212
+                q[c] = s[0] * p[0] - s[1] * p[1];
+                q[c + k] = s[0] * p[1] + s[1] * p[0];
+            }
+        }
+    }
+    const float tot = wave_sum(part);
+    if (lane == 0) qpos[i] = quantise(mc.score_sign * mc.score_scale * tot);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int QT = 64, ET = 64, KT = 16, LDP = 68;   // LDP: padded LDS row (floats), keeps float4 reads aligned
+
+struct CountArgs {
+    const float* ent;
+    const float* Q;
+    const int* qpos;
+    const int32_t* ent_ids;
+    int32_t* counts;
+    int64_t n;
+    int64_t ent_lo, ent_hi;
+    int ent_per_block;
+    RankGeom g;
+    float sgn_scale;
+};
+
+template <int MODE, bool V4>
+__global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
+    constexpr int NQF = ModeTraits<MODE>::NQF, NEF = ModeTraits<MODE>::NEF;
+    __shared__ __attribute__((aligned(16))) float Qs[NQF][KT][LDP];
+    __shared__ __attribute__((aligned(16))) float Es[NEF][KT][LDP];
+
+    const int tid = threadIdx.x;
+    const int tq = tid >> 4, te = tid & 15;
+    const int64_t q0 = (int64_t)blockIdx.x * QT;
+    const int64_t e_begin = a.ent_lo + (int64_t)blockIdx.y * a.ent_per_block;
+    const int64_t e_end = min(a.ent_hi, e_begin + a.ent_per_block);
+
+    int qp[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int64_t qi = q0 + tq * 4 + x;
+        qp[x] = a.qpos[qi < a.n ? qi : a.n - 1];
+    }
+    int cgt[4] = {0, 0, 0, 0}, ceq[4] = {0, 0, 0, 0};
+
+    // loader mapping: row = tid / 4 (0..63), 4-unit group = tid % 4
+    const int lrow = tid >> 2, lgrp = tid & 3;
+    const int64_t lq = q0 + lrow;
+    const float* qrow = a.Q + (lq < a.n ? lq : a.n - 1) * (int64_t)a.g.QW;
+
+    for (int64_t et = e_begin; et < e_end; et += ET) {
+        const int64_t le = et + lrow;
+        const int64_t le_c = le < e_end ? le : e_end - 1;
+        const int64_t erow_id = a.ent_ids ? (int64_t)a.ent_ids[le_c] : le_c;
+        const float* erow = a.ent + erow_id * a.g.K;
+        float acc[4][4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) acc[x][y] = 0.f;
+
+        for (int k0 = 0; k0 < a.g.U; k0 += KT) {
+            const int ku = k0 + lgrp * 4;
+            // ---- global -> LDS (transposed: [plane][unit][row]) ----
+#pragma unroll
+            for (int f = 0; f < NQF; ++f) {
+                float v[4];
+                if (V4 && ku + 3 < a.g.U) {
+                    const float4 t = *reinterpret_cast<const float4*>(qrow + f * a.g.qplane + ku);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = (ku + u < a.g.U) ? qrow[f * a.g.qplane + ku + u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Qs[f][lgrp * 4 + u][lrow] = v[u];
+            }
+#pragma unroll
+            for (int f = 0; f < NEF; ++f) {
+                float v[4];
+                if (V4 && ku + 3 < a.g.U) {
+                    const float4 t = *reinterpret_cast<const float4*>(erow + f * a.g.eplane + ku);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = (ku + u < a.g.U) ? erow[f * a.g.eplane + ku + u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Es[f][lgrp * 4 + u][lrow] = v[u];
+            }
+            __syncthreads();
+            // ---- 4x4 micro tile over the KT units, strictly in unit order ----
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) {
+                float qv[NQF][4], ev[NEF][4];
+#pragma unroll
+                for (int f = 0; f < NQF; ++f) {
+                    const float4 t = *reinterpret_cast<const float4*>(&Qs[f][kk][tq * 4]);
+                    qv[f][0] = t.x; qv[f][1] = t.y; qv[f][2] = t.z; qv[f][3] = t.w;
+                }
+#pragma unroll
+                for (int f = 0; f < NEF; ++f) {
+                    const float4 t = *reinterpret_cast<const float4*>(&Es[f][kk][te * 4]);
+                    ev[f][0] = t.x; ev[f][1] = t.y; ev[f][2] = t.z; ev[f][3] = t.w;
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) {
+                        float qq[NQF], ee[NEF];
+#pragma unroll
+                        for (int f = 0; f < NQF; ++f) qq[f] = qv[f][x];
+#pragma unroll
+                        for (int f = 0; f < NEF; ++f) ee[f] = ev[f][y];
+                        acc[x][y] = rank_op<MODE>(acc[x][y], qq, ee, a.g.sgn);
+                    }
+            }
+            __syncthreads();
+        }
+        // ---- epilogue: quantise, compare, count ----
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const bool valid = (et + te * 4 + y) < e_end;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int q = quantise(a.sgn_scale * acc[x][y]);
+                cgt[x] += (valid && qp[x] < q) ? 1 : 0;
+                ceq[x] += (valid && qp[x] == q) ? 1 : 0;
+            }
+        }
+    }
+    // reduce over the 16 lanes (te) that share the same queries, one atomic pair per query per block
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        int g = cgt[x], e = ceq[x];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); e += __shfl_xor(e, o, 64); }
+        const int64_t qi = q0 + tq * 4 + x;
+        if (te == 0 && qi < a.n) {
+            if (g) atomicAdd(&a.counts[2 * qi + 0], g);
+            if (e) atomicAdd(&a.counts[2 * qi + 1], e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// filter kernel: one wave per test triple, one lane per true-positive id
+// ------------------------------------------------------------------------------------------------
+struct FilterArgs {
+    const float* ent;
+    const float* Q;
+    const int* qpos;
+    const int64_t* flt_lo;
+    const int64_t* flt_hi;
+    const int32_t* flt_ids;
+    const int32_t* subset_pos;
+    int32_t* sub;
+    int64_t n;
+    int64_t ent_lo, ent_hi;
+    RankGeom g;
+    float sgn_scale;
+};
+
+template <int MODE, bool V4>
+__global__ __launch_bounds__(256) void rank_filter_kernel(FilterArgs a) {
+    constexpr int NQF = ModeTraits<MODE>::NQF, NEF = ModeTraits<MODE>::NEF;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n) return;
+    const int64_t lo = a.flt_lo[i], hi = a.flt_hi[i];
+    const float* qrow = a.Q + i * (int64_t)a.g.QW;
+    const int qp = a.qpos[i];
+    int cnt = 0;
+    for (int64_t f0 = lo; f0 < hi; f0 += KGE_WAVE) {
+        const int64_t f = f0 + lane;
+        bool ok = f < hi;
+        int64_t id = ok ? (int64_t)a.flt_ids[f] : 0;
+        if (ok && a.subset_pos) {   // mapping_dict.lookup + drop -1 (AbstractScoringLayer.py:266-275)
+            const int pos = a.subset_pos[id];
+            ok = pos >= 0;
+            // the corruption row of position `pos` is the table row `id` itself
+            if (ok) ok = (pos >= a.ent_lo) && (pos < a.ent_hi);
+        } else if (ok) {
+            ok = (id >= a.ent_lo) && (id < a.ent_hi);   // partition rule :280-288
+        }
+        const float* erow = a.ent + (ok ? id : 0) * a.g.K;
+        float acc = 0.f;
+        if (V4) {
+            for (int u0 = 0; u0 < a.g.U; u0 += 4) {
+                float qv[NQF][4], ev[NEF][4];
+#pragma unroll
+                for (int p = 0; p < NQF; ++p) {
+                    const float4 t = *reinterpret_cast<const float4*>(qrow + p * a.g.qplane + u0);
+                    qv[p][0] = t.x; qv[p][1] = t.y; qv[p][2] = t.z; qv[p][3] = t.w;
+                }
+#pragma unroll
+                for (int p = 0; p < NEF; ++p) {
+                    const float4 t = *reinterpret_cast<const float4*>(erow + p * a.g.eplane + u0);
+                    ev[p][0] = t.x; ev[p][1] = t.y; ev[p][2] = t.z; ev[p][3] = t.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float qq[NQF], ee[NEF];
+#pragma unroll
+                    for (int p = 0; p < NQF; ++p) qq[p] = qv[p][u];
+#pragma unroll
+                    for (int p = 0; p < NEF; ++p) ee[p] = ev[p][u];
+                    acc = rank_op<MODE>(acc, qq, ee, a.g.sgn);
+                }
+            }
+        } else {
+            for (int u = 0; u < a.g.U; ++u) {
+                float qq[NQF], ee[NEF];
+#pragma unroll
+                for (int p = 0; p < NQF; ++p) qq[p] = qrow[p * a.g.qplane + u];
+#pragma unroll
+                for (int p = 0; p < NEF; ++p) ee[p] = erow[p * a.g.eplane + u];
+                acc = rank_op<MODE>(acc, qq, ee, a.g.sgn);
+            }
+        }
+        const int q = quantise(a.sgn_scale * acc);
+        cnt += (ok && qp <= q) ? 1 : 0;
+    }
+    cnt = wave_sum_i(cnt);
+    if (lane == 0 && cnt) atomicAdd(&a.sub[i], cnt);
+}
+
+__global__ void rank_compose_kernel(const int32_t* counts, const int32_t* sub, int64_t n, int strategy,
+                                    int32_t* ranks, int64_t stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int gt = counts[2 * i], eq = counts[2 * i + 1];
+    int r;
+    if (strategy == AMDKGE_RANK_BEST) r = gt;                       // AbstractScoringLayer.py:221-227
+    else if (strategy == AMDKGE_RANK_MIDDLE) r = gt + (eq + 1) / 2; // :232-244 ceil(#equal / 2)
+    else r = gt + eq;                                               // :252-258
+    if (sub) r -= sub[i];
+    ranks[i * stride] = r + 1;                                      // ScoringBasedEmbeddingModel.py:1684
+}
+
+static inline char* align_up(char* p, size_t a) { return (char*)(((uintptr_t)p + a - 1) & ~(uintptr_t)(a - 1)); }
+
+struct Workspace {
+    float* Q;
+    int* qpos;
+};
+
+static Workspace carve(void* d_work, const amdkge_model* m, int64_t n) {
+    Workspace w;
+    char* p = align_up((char*)d_work, 256);
+    w.qpos = (int*)p;
+    p = align_up(p + n * sizeof(int), 256);
+    w.Q = (float*)p;
+    return w;
+}
+
+static int run_prep(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples, int64_t n,
+                    int side, const RankGeom& g, const Workspace& w, hipStream_t st) {
+    const ModelConst mc = model_const(m);
+    const unsigned grid = (unsigned)((n + 3) / 4);
+#define KGE_PREP(M) hipLaunchKernelGGL((rank_prep_kernel<M>), dim3(grid), dim3(256), 0, st, d_ent, d_rel, d_triples, n, m->k, g.K, side, g.QW, mc, w.Q, w.qpos)
+    switch (m->scoring_type) {
+        case AMDKGE_TRANSE: KGE_PREP(AMDKGE_TRANSE); break;
+        case AMDKGE_DISTMULT: KGE_PREP(AMDKGE_DISTMULT); break;
+        case AMDKGE_COMPLEX:
+        case AMDKGE_HOLE: KGE_PREP(AMDKGE_COMPLEX); break;
+        default: KGE_PREP(AMDKGE_ROTATE); break;
+    }
+#undef KGE_PREP
+    return check_launch("rank_prep");
+}
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" int64_t amdkge_rank_workspace_bytes(const amdkge_model* m, int64_t n) {
+    if (validate_model(m) != AMDKGE_OK || n < 0) return -1;
+    const int64_t qw = (m->scoring_type == AMDKGE_ROTATE) ? 4ll * m->k : internal_k_of(m->scoring_type, m->k);
+    return 1024 + ((n * 4 + 255) / 256) * 256 + n * qw * 4;
+}
+
+extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
+                                  int64_t n, int32_t side, const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
+                                  int32_t* d_counts, void* d_work, void* stream) {
+    if (int rc = validate_model(m)) return rc;
+    if (side != AMDKGE_SIDE_S && side != AMDKGE_SIDE_O) return set_error(AMDKGE_EINVAL, "rank_counts: side must be AMDKGE_SIDE_S or AMDKGE_SIDE_O");
+    if (n < 0 || ent_lo < 0 || ent_hi < ent_lo) return set_error(AMDKGE_EINVAL, "rank_counts: bad sizes");
+    if (!d_ent_ids && ent_hi > m->n_ents) return set_error(AMDKGE_EINVAL, "rank_counts: entity range outside the table");
+    if (n == 0 || ent_hi == ent_lo) return AMDKGE_OK;
+    if (!d_ent || !d_rel || !d_triples || !d_counts || !d_work) return set_error(AMDKGE_EINVAL, "rank_counts: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const RankGeom g = geom_of(m, side);
+    const Workspace w = carve(d_work, m, n);
+    if (int rc = run_prep(m, d_ent, d_rel, d_triples, n, side, g, w, st)) return rc;
+
+    const ModelConst mc = model_const(m);
+    CountArgs a{};
+    a.ent = d_ent; a.Q = w.Q; a.qpos = w.qpos; a.ent_ids = d_ent_ids; a.counts = d_counts; a.n = n;
+    a.ent_lo = ent_lo; a.ent_hi = ent_hi; a.g = g; a.sgn_scale = mc.score_sign * mc.score_scale;
+    const int64_t qtiles = (n + QT - 1) / QT;
+    const int64_t etiles = (ent_hi - ent_lo + ET - 1) / ET;
+    int64_t splits = (2048 + qtiles - 1) / qtiles;   // aim for >= 2048 blocks (256 CUs x 8)
+    if (splits > etiles) splits = etiles;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const int64_t tiles_per = (etiles + splits - 1) / splits;
+    a.ent_per_block = (int)(tiles_per * ET);
+    splits = (etiles + tiles_per - 1) / tiles_per;
+    const dim3 grid((unsigned)qtiles, (unsigned)splits);
+    const bool v4 = (g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
+    const int mode = mode_of(m->scoring_type, side);
+#define KGE_CNT(MODE) do { if (v4) hipLaunchKernelGGL((rank_count_kernel<MODE, true>), grid, dim3(256), 0, st, a); \
+                           else hipLaunchKernelGGL((rank_count_kernel<MODE, false>), grid, dim3(256), 0, st, a); } while (0)
+    switch (mode) {
+        case MODE_DOT: KGE_CNT(MODE_DOT); break;
+        case MODE_L1: KGE_CNT(MODE_L1); break;
+        case MODE_ROT_O: KGE_CNT(MODE_ROT_O); break;
+        default: KGE_CNT(MODE_ROT_S); break;
+    }
+#undef KGE_CNT
+    return check_launch("rank_counts");
+}
+
+extern "C" int amdkge_rank_filter(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
+                                  int64_t n, int32_t side, const int64_t* d_flt_lo, const int64_t* d_flt_hi,
+                                  const int32_t* d_flt_ids, const int32_t* d_subset_pos, int64_t ent_lo, int64_t ent_hi,
+                                  int32_t* d_sub, void* d_work, void* stream) {
+    if (int rc = validate_model(m)) return rc;
+    if (side != AMDKGE_SIDE_S && side != AMDKGE_SIDE_O) return set_error(AMDKGE_EINVAL, "rank_filter: side must be AMDKGE_SIDE_S or AMDKGE_SIDE_O");
+    if (n < 0 || ent_lo < 0 || ent_hi < ent_lo) return set_error(AMDKGE_EINVAL, "rank_filter: bad sizes");
+    if (n == 0) return AMDKGE_OK;
+    if (!d_ent || !d_rel || !d_triples || !d_flt_lo || !d_flt_hi || !d_sub || !d_work) return set_error(AMDKGE_EINVAL, "rank_filter: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const RankGeom g = geom_of(m, side);
+    const Workspace w = carve(d_work, m, n);
+    if (int rc = run_prep(m, d_ent, d_rel, d_triples, n, side, g, w, st)) return rc;
+    const ModelConst mc = model_const(m);
+    FilterArgs a{};
+    a.ent = d_ent; a.Q = w.Q; a.qpos = w.qpos; a.flt_lo = d_flt_lo; a.flt_hi = d_flt_hi; a.flt_ids = d_flt_ids;
+    a.subset_pos = d_subset_pos; a.sub = d_sub; a.n = n; a.ent_lo = ent_lo; a.ent_hi = ent_hi; a.g = g;
+    a.sgn_scale = mc.score_sign * mc.score_scale;
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    const bool v4 = (g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
+    const int mode = mode_of(m->scoring_type, side);
+#define KGE_FLT(MODE) do { if (v4) hipLaunchKernelGGL((rank_filter_kernel<MODE, true>), dim3(grid), dim3(256), 0, st, a); \
+                           else hipLaunchKernelGGL((rank_filter_kernel<MODE, false>), dim3(grid), dim3(256), 0, st, a); } while (0)
+    switch (mode) {
+        case MODE_DOT: KGE_FLT(MODE_DOT); break;
+        case MODE_L1: KGE_FLT(MODE_L1); break;
+        case MODE_ROT_O: KGE_FLT(MODE_ROT_O); break;
+        default: KGE_FLT(MODE_ROT_S); break;
+    }
+#undef KGE_FLT
+    return check_launch("rank_filter");
+}
+
+extern "C" int amdkge_rank_compose(const int32_t* d_counts, const int32_t* d_sub, int64_t n, int32_t strategy,
+                                   int32_t* d_ranks, int64_t rank_stride, void* stream) {
+    if (n < 0 || rank_stride < 1) return set_error(AMDKGE_EINVAL, "rank_compose: bad sizes");
+    if (strategy < AMDKGE_RANK_WORST || strategy > AMDKGE_RANK_MIDDLE) return set_error(AMDKGE_EINVAL, "rank_compose: unknown ranking strategy");
+    if (n == 0) return AMDKGE_OK;
+    if (!d_counts || !d_ranks) return set_error(AMDKGE_EINVAL, "rank_compose: NULL pointer");
+    hipLaunchKernelGGL(rank_compose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_counts, d_sub, n, strategy, d_ranks, rank_stride);
+    return check_launch("rank_compose");
+}

@@ -1,0 +1,154 @@
+"""Thin Python layer over the C ABI: torch tensors supply device memory and the HIP stream
+(plumbing only); every computation is a libamdkge entry point.
+
+`KgeEngine` owns the HBM-resident state of one model replica on one GPU: the two embedding tables,
+their dense gradient buffers and optimizer slots, and the scratch used by evaluation.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import check
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class KgeEngine:
+    def __init__(self, scoring_type, k, n_ents, n_rels, max_rel_size=None, device=None):
+        if scoring_type not in _ffi.SCORING_TYPES:
+            raise ValueError(f"unknown scoring_type {scoring_type!r}")
+        self.lib = _ffi.lib()  # raises when the HIP library is absent: no fallback path exists
+        if not torch.cuda.is_available():
+            raise RuntimeError("ampligraph_amd needs a ROCm GPU (torch.cuda.is_available() is False)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.scoring_type = scoring_type
+        self.k = int(k)
+        self.n_ents = int(n_ents)
+        self.n_rels = int(n_rels)
+        self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], self.k))
+        self.model = _ffi.Model(_ffi.SCORING_TYPES[scoring_type], self.k, self.n_ents, self.n_rels,
+                                int(max_rel_size) if max_rel_size else 0, 0)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.ent = torch.zeros(self.n_ents, self.K, **f32)
+        self.rel = torch.zeros(self.n_rels, self.K, **f32)
+        self.g_ent = None
+        self.g_rel = None
+        self.slots = {}
+        self.opt_kind = None
+        self.loss_acc = torch.zeros(2, dtype=torch.float64, device=self.device)  # [data loss, reg loss]
+        self._work = None
+
+    # ------------------------------------------------------------------ tables
+    def set_tables(self, ent, rel):
+        ent = torch.as_tensor(np.ascontiguousarray(ent, dtype=np.float32))
+        rel = torch.as_tensor(np.ascontiguousarray(rel, dtype=np.float32))
+        if tuple(ent.shape) != (self.n_ents, self.K) or tuple(rel.shape) != (self.n_rels, self.K):
+            raise ValueError(f"table shapes must be {(self.n_ents, self.K)} and {(self.n_rels, self.K)}")
+        self.ent.copy_(ent)
+        self.rel.copy_(rel)
+
+    def get_tables(self):
+        return self.ent.cpu().numpy(), self.rel.cpu().numpy()
+
+    # ------------------------------------------------------------------ training
+    def prepare_training(self, optimizer="adam"):
+        if optimizer not in _ffi.OPTIMIZERS:
+            raise ValueError(f"unknown optimizer {optimizer!r}")
+        self.opt_kind = optimizer
+        self.g_ent = torch.zeros_like(self.ent)
+        self.g_rel = torch.zeros_like(self.rel)
+        self.slots = {}
+        if optimizer == "adam":
+            for n in ("m_e", "v_e"):
+                self.slots[n] = torch.zeros_like(self.ent)
+            for n in ("m_r", "v_r"):
+                self.slots[n] = torch.zeros_like(self.rel)
+        elif optimizer == "adagrad":  # Keras legacy Adagrad initial_accumulator_value = 0.1
+            self.slots["a_e"] = torch.full_like(self.ent, 0.1)
+            self.slots["a_r"] = torch.full_like(self.rel, 0.1)
+
+    def train_fwdbwd(self, triples, eta, loss, seed, step, sample_base=0, sample_range=None,
+                     row_offset=0, b_global=0, neg_override=None, pos_scores=None, neg_scores=None):
+        """triples: int32 cuda tensor (B,3).  Accumulates into g_ent/g_rel and loss_acc[0]."""
+        B = int(triples.shape[0])
+        if sample_range is None:
+            sample_range = self.n_ents
+        check(self.lib.amdkge_train_fwdbwd(
+            C.byref(self.model), C.byref(loss), _ptr(self.ent), _ptr(self.rel), _ptr(triples), B, int(eta),
+            int(sample_base), int(sample_range), int(seed), int(step), int(row_offset), int(b_global),
+            _ptr(neg_override), _ptr(self.g_ent), _ptr(self.g_rel), C.c_void_p(self.loss_acc.data_ptr()),
+            _ptr(pos_scores), _ptr(neg_scores), _stream()))
+
+    def opt_step(self, opt_desc, reg_e=0.0, reg_r=0.0):
+        """Dense sweep over both tables (optimizer + regulariser + gradient reset)."""
+        reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8)
+        for x, g, names, lam in ((self.ent, self.g_ent, ("m_e", "v_e", "a_e"), reg_e),
+                                 (self.rel, self.g_rel, ("m_r", "v_r", "a_r"), reg_r)):
+            opt_desc.reg_lambda = float(lam)
+            if self.opt_kind == "adam":
+                s0, s1 = self.slots[names[0]], self.slots[names[1]]
+            elif self.opt_kind == "adagrad":
+                s0, s1 = self.slots[names[2]], None
+            else:
+                s0 = s1 = None
+            check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(x), _ptr(g), _ptr(s0), _ptr(s1),
+                                           x.numel(), reg_ptr, _stream()))
+
+    def sample_corruptions(self, triples, eta, seed, step, sample_base=0, sample_range=None,
+                           row_offset=0, b_global=0):
+        B = int(triples.shape[0])
+        out = torch.empty(B * eta, 3, dtype=torch.int32, device=self.device)
+        check(self.lib.amdkge_sample_corruptions(
+            _ptr(triples), B, int(eta), int(sample_base), int(sample_range or self.n_ents), int(seed),
+            int(step), int(row_offset), int(b_global), _ptr(out), _stream()))
+        return out
+
+    # ------------------------------------------------------------------ predict
+    def score(self, triples):
+        n = int(triples.shape[0])
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        check(self.lib.amdkge_score(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples), n,
+                                    _ptr(out), _stream()))
+        return out
+
+    # ------------------------------------------------------------------ evaluate
+    def _workspace(self, n):
+        need = int(self.lib.amdkge_rank_workspace_bytes(C.byref(self.model), n))
+        if self._work is None or self._work.numel() < need:
+            self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._work
+
+    def rank_side(self, triples, side, strategy="worst", flt=None, ent_ids=None, subset_pos=None,
+                  ent_lo=0, ent_hi=None, out=None, out_stride=1):
+        """Ranks (1-based, reference semantics) of `triples` for one corruption side.
+
+        flt: None or (lo int64[n], hi int64[n], ids int32[*]) cuda tensors."""
+        n = int(triples.shape[0])
+        if ent_hi is None:
+            ent_hi = self.n_ents if ent_ids is None else int(ent_ids.shape[0])
+        work = self._workspace(n)
+        counts = torch.zeros(n, 2, dtype=torch.int32, device=self.device)
+        check(self.lib.amdkge_rank_counts(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples), n,
+                                          side, _ptr(ent_ids), int(ent_lo), int(ent_hi), _ptr(counts),
+                                          _ptr(work), _stream()))
+        sub = None
+        if flt is not None:
+            lo, hi, ids = flt
+            sub = torch.zeros(n, dtype=torch.int32, device=self.device)
+            check(self.lib.amdkge_rank_filter(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples),
+                                              n, side, _ptr(lo), _ptr(hi), _ptr(ids), _ptr(subset_pos),
+                                              int(ent_lo), int(ent_hi), _ptr(sub), _ptr(work), _stream()))
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
+            out_stride = 1
+        check(self.lib.amdkge_rank_compose(_ptr(counts), _ptr(sub), n, _ffi.RANK_STRATEGY[strategy], _ptr(out),
+                                           int(out_stride), _stream()))
+        return out, counts, sub

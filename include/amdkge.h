@@ -1,0 +1,164 @@
+/*
+ * amdkge.h -- C ABI of libamdkge.so, the MI355X (gfx950) engine behind AmpliGraph's
+ * ScoringBasedEmbeddingModel.fit()/predict()/evaluate() hot path.
+ *
+ * The reference (Accenture/AmpliGraph, 100 % Python on TensorFlow) has no FFI: its "operator
+ * interface" for this path is the set of Keras layers / objects listed next to each entry point
+ * below (paths relative to /root/reference/).  Every entry point replaces one of them; the Python
+ * host in ampligraph_amd/ binds these symbols with ctypes (see INTEGRATION.md for the binding a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain C types only; every pointer named d_* is a DEVICE pointer (HBM), every other pointer
+ *     is a host pointer.  Tables are fp32 row-major [rows, K]; K = k for TransE/DistMult and 2k
+ *     ([re || im] halves) for ComplEx/HolE/RotatE.  Triples are int32 [n,3] row-major (s,p,o).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All compute entry
+ *     points are asynchronous on that stream; the caller owns synchronisation.
+ *   - return value: 0 = ok, negative = error class below; amdkge_last_error() gives a message
+ *     (thread local).  Nothing throws across the ABI.
+ */
+#ifndef AMDKGE_H
+#define AMDKGE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMDKGE_ABI_VERSION 1
+
+/* error classes */
+#define AMDKGE_OK 0
+#define AMDKGE_EINVAL (-1)       /* invalid argument */
+#define AMDKGE_EHIP (-2)         /* HIP runtime error */
+#define AMDKGE_ENOMEM (-4)       /* device allocation failed */
+#define AMDKGE_EUNSUPPORTED (-5) /* shape outside the compiled kernels' range */
+
+/* scoring_type -- SCORING_LAYER_REGISTRY, latent_features/layers/scoring/AbstractScoringLayer.py:15-18 */
+enum { AMDKGE_TRANSE = 0, AMDKGE_DISTMULT = 1, AMDKGE_COMPLEX = 2, AMDKGE_HOLE = 3, AMDKGE_ROTATE = 4 };
+/* loss -- LOSS_REGISTRY, latent_features/loss_functions.py:17,229,312,386,468,578 */
+enum { AMDKGE_LOSS_PAIRWISE = 0, AMDKGE_LOSS_NLL = 1, AMDKGE_LOSS_ABSOLUTE_MARGIN = 2,
+       AMDKGE_LOSS_SELF_ADVERSARIAL = 3, AMDKGE_LOSS_MULTICLASS_NLL = 4 };
+/* optimizer -- latent_features/optimizers.py:255-291 (Keras *legacy* update rules) */
+enum { AMDKGE_OPT_SGD = 0, AMDKGE_OPT_ADAGRAD = 1, AMDKGE_OPT_ADAM = 2 };
+/* corrupt side bit mask -- ScoringBasedEmbeddingModel.evaluate(corrupt_side=...) :1516 */
+enum { AMDKGE_SIDE_S = 1, AMDKGE_SIDE_O = 2 };
+/* ranking_strategy -- AbstractScoringLayer.get_ranks(comparison_type=...) :165 */
+enum { AMDKGE_RANK_WORST = 0, AMDKGE_RANK_BEST = 1, AMDKGE_RANK_MIDDLE = 2 };
+
+/* Model geometry: ScoringBasedEmbeddingModel.__init__(eta,k,scoring_type,max_ent_size,max_rel_size)
+ * ScoringBasedEmbeddingModel.py:100-108 */
+typedef struct amdkge_model {
+    int32_t scoring_type;   /* AMDKGE_TRANSE .. AMDKGE_ROTATE */
+    int32_t k;              /* user-facing embedding size (rows hold internal_k floats) */
+    int64_t n_ents;         /* rows of the entity table */
+    int64_t n_rels;         /* rows of the relation table */
+    int32_t max_rel_size;   /* RotatE phase normaliser (RotatE.py:95); <=0 means "None" -> 1 */
+    int32_t reserved;
+} amdkge_model;
+
+/* Loss hyper-parameters: loss_functions.py:76-117 (`hyperparam_dict`), defaults :23-35 */
+typedef struct amdkge_loss {
+    int32_t kind;           /* AMDKGE_LOSS_* */
+    int32_t reduction_mean; /* 0 = "sum" (default), 1 = "mean" over the corruptions */
+    float margin;           /* pairwise / absolute_margin / self_adversarial */
+    float alpha;            /* self_adversarial sampling temperature */
+} amdkge_loss;
+
+/* Optimizer + regulariser for one table sweep: optimizers.py:136-168, regularizers.py:14-37 */
+typedef struct amdkge_opt {
+    int32_t kind;           /* AMDKGE_OPT_* */
+    int32_t reg_p;          /* LP regulariser power p (>=1); ignored when reg_lambda == 0 */
+    float lr;
+    float beta1, beta2;     /* Adam */
+    float epsilon;          /* Adam / Adagrad (Keras legacy default 1e-7) */
+    float reg_lambda;       /* 0 = no regulariser */
+    int64_t iteration;      /* t = optimizer.iterations + 1 of this step (1-based) */
+} amdkge_opt;
+
+/* ---- library / device helpers (so that a host without torch can drive the engine) ---- */
+int amdkge_abi_version(void);
+const char* amdkge_last_error(void);
+int amdkge_device_count(int* count);
+int amdkge_set_device(int device);
+int amdkge_dev_alloc(void** d_ptr, uint64_t bytes);
+int amdkge_dev_free(void* d_ptr);
+int amdkge_h2d(void* d_dst, const void* src, uint64_t bytes, void* stream);
+int amdkge_d2h(void* dst, const void* d_src, uint64_t bytes, void* stream);
+int amdkge_dev_memset(void* d_ptr, int value, uint64_t bytes, void* stream);
+int amdkge_stream_sync(void* stream);
+
+/* internal_k of a model (2k for ComplEx/HolE/RotatE) -- ComplEx.py:37, RotatE.py:57 */
+int amdkge_internal_k(int scoring_type, int k);
+
+/* predict(): EmbeddingLookupLayer.call + <Model>._compute_scores
+ * (layers/encoding/EmbeddingLookupLayer.py:307-342; TransE.py:37, DistMult.py:34, ComplEx.py:39,
+ *  HolE.py:31, RotatE.py:62).  d_scores[n] fp32. */
+int amdkge_score(const amdkge_model* m, const float* d_ent, const float* d_rel,
+                 const int32_t* d_triples, int64_t n, float* d_scores, void* stream);
+
+/* CorruptionGenerationLayerTrain.call (layers/corruption_generation/
+ * CorruptionGenerationLayerTrain.py:35-94): d_out[(B*eta),3], row j*B+i = j-th corruption of
+ * positive i.  Draws: Philox4x32-10, counter = global row j*b_global + row_offset + i, step;
+ * key = seed; replacement = sample_base + mulhi32(x1, sample_range). */
+int amdkge_sample_corruptions(const int32_t* d_triples, int64_t B, int32_t eta,
+                              int64_t sample_base, int64_t sample_range, uint64_t seed, uint64_t step,
+                              int64_t row_offset, int64_t b_global, int32_t* d_out, void* stream);
+
+/* One fused forward+backward of train_step (ScoringBasedEmbeddingModel.py:370-429): lookup,
+ * negative sampling, scoring, Loss.__call__ (loss_functions.py:185-225) and the gradient of the
+ * loss w.r.t. both tables, accumulated (+=) into the dense fp32 buffers d_grad_ent / d_grad_rel
+ * (same shape as the tables; the caller zeroes them, amdkge_opt_step re-zeroes them).
+ *   d_neg_override : NULL, or int32 [(B*eta),3] corruptions to use instead of sampling
+ *   d_loss_sum     : double, += sum_i per-sample loss (no regulariser term)
+ *   d_pos_scores   : NULL or fp32 [B];  d_neg_scores : NULL or fp32 [B*eta] (layout j*B+i)
+ */
+int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* loss,
+                        const float* d_ent, const float* d_rel,
+                        const int32_t* d_triples, int64_t B, int32_t eta,
+                        int64_t sample_base, int64_t sample_range, uint64_t seed, uint64_t step,
+                        int64_t row_offset, int64_t b_global, const int32_t* d_neg_override,
+                        float* d_grad_ent, float* d_grad_rel, double* d_loss_sum,
+                        float* d_pos_scores, float* d_neg_scores, void* stream);
+
+/* OptimizerWrapper.minimize -> Keras legacy apply_gradients (optimizers.py:166-168) fused with the
+ * whole-table LP regulariser (regularizers.py:35-37): one dense sweep over `n_elems` floats of a
+ * table.  grad_total = d_grad + lambda*p*|x|^(p-1)*sign(x); updates d_x and the slots in place,
+ * zeroes d_grad, and adds lambda*sum|x|^p (pre-update x) to *d_reg_loss (double, may be NULL).
+ *   Adam:    d_slot0 = m, d_slot1 = v;  Adagrad: d_slot0 = accumulator;  SGD: no slots. */
+int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_slot0, float* d_slot1,
+                    int64_t n_elems, double* d_reg_loss, void* stream);
+
+/* evaluate(): AbstractScoringLayer.get_ranks steps (1)+(2) (AbstractScoringLayer.py:156-258,
+ * 309-366) for ONE side: quantised positive score vs the quantised score of every corruption.
+ *   d_ent_ids : NULL = corruptions are table rows [ent_lo, ent_hi); else int32 [m] row ids
+ *               (entities_subset, ScoringBasedEmbeddingModel.py:1349-1354) and ent_lo/hi index it
+ *   d_counts  : int32 [n,2], += (#corr with q(pos) < q(corr), #corr with q(pos) == q(corr))
+ *   d_work    : scratch of amdkge_rank_workspace_bytes(m, n) bytes */
+int64_t amdkge_rank_workspace_bytes(const amdkge_model* m, int64_t n);
+int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d_rel,
+                       const int32_t* d_triples, int64_t n, int32_t side,
+                       const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
+                       int32_t* d_counts, void* d_work, void* stream);
+
+/* get_ranks step (3): filter correction (AbstractScoringLayer.py:260-307,368-417).  For triple i
+ * the true-positive ids are d_flt_ids[d_flt_lo[i] .. d_flt_hi[i]) (a CSR when lo=off[i],
+ * hi=off[i+1]).  Ids are table row ids; they are kept if ent_lo <= id < ent_hi (partition rule
+ * :280-288) and, when d_subset_pos != NULL (int32 [n_ents], -1 = not in entities_subset,
+ * :266-275), if d_subset_pos[id] >= 0.  d_sub[n] int32 += #{f : q(pos) <= q(corr_f)}. */
+int amdkge_rank_filter(const amdkge_model* m, const float* d_ent, const float* d_rel,
+                       const int32_t* d_triples, int64_t n, int32_t side,
+                       const int64_t* d_flt_lo, const int64_t* d_flt_hi, const int32_t* d_flt_ids,
+                       const int32_t* d_subset_pos, int64_t ent_lo, int64_t ent_hi,
+                       int32_t* d_sub, void* d_work, void* stream);
+
+/* Tie strategy + "+1" (AbstractScoringLayer.py:217-258, ScoringBasedEmbeddingModel.py:1684):
+ * d_ranks[i] = strategy(gt,eq) - sub + 1;  d_sub may be NULL (unfiltered). */
+int amdkge_rank_compose(const int32_t* d_counts, const int32_t* d_sub, int64_t n, int32_t strategy,
+                        int32_t* d_ranks, int64_t rank_stride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMDKGE_H */

@@ -1,0 +1,343 @@
+"""GPU parity tests proper: every HIP entry point of libamdkge (called through the C ABI) against the
+CPU oracle on the same seeded inputs.  Tolerances: fp32 outputs within 1e-5 relative (north_star);
+integer outputs (corruptions, ranks) bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kge_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODELS = list(O.MODELS)
+LOSSES = list(O.LOSS_DEFAULTS)
+
+
+def make_engine(model, k, N, R, seed=0, scale=None):
+    from ampligraph_amd.engine import KgeEngine
+
+    eng = KgeEngine(model, k, N, R, max_rel_size=R)
+    rng = np.random.default_rng(seed)
+    K = eng.K
+    if scale is None:
+        ent = O.glorot_uniform(N, K, rng)
+        rel = O.glorot_uniform(R, K, rng)
+    else:
+        ent = (rng.normal(size=(N, K)) * scale).astype(np.float32)
+        rel = (rng.normal(size=(R, K)) * scale).astype(np.float32)
+    eng.set_tables(ent, rel)
+    return eng, ent, rel
+
+
+def rand_triples(rng, n, N, R):
+    return np.stack([rng.integers(0, N, n), rng.integers(0, R, n), rng.integers(0, N, n)], 1).astype(np.int32)
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def loss_desc(name, reduction="sum", **kw):
+    from ampligraph_amd import _ffi
+
+    prm = dict(O.LOSS_DEFAULTS[name])
+    prm.update(kw)
+    return _ffi.Loss(_ffi.LOSSES[name], 1 if reduction == "mean" else 0, float(prm.get("margin", 0.0)),
+                     float(prm.get("alpha", 0.0)))
+
+
+# -------------------------------------------------------------------------------- wave reduction
+def test_library_loaded(gpu_lib):
+    assert gpu_lib.amdkge_abi_version() == 1
+    c = C.c_int(0)
+    assert gpu_lib.amdkge_device_count(C.byref(c)) == 0 and c.value >= 1
+
+
+# -------------------------------------------------------------------------------- predict (a20)
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("k", [3, 50, 200, 350, 1000])
+def test_score_parity(gpu_lib, model, k):
+    N, R, n = 500, 7, 1001
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.5 if k < 100 else 0.1)
+    rng = np.random.default_rng(1)
+    X = rand_triples(rng, n, N, R)
+    got = eng.score(dev(X)).cpu().numpy()
+    s, p, o = O.lookup(ent, rel, X)
+    ref = O.compute_scores(model, s, p, o, max_rel_size=R)
+    scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max())
+    assert np.max(np.abs(got - ref) / scale) < 1e-5, (model, k)
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_score_reference_kat(gpu_lib, model):
+    """The reference's own score KATs (test_{TransE,DistMult,ComplEx,HolE,RotatE}.py) through the HIP path."""
+    from kat_data import EXPECTED, _cplx_triples, _real_triples
+    from ampligraph_amd.engine import KgeEngine
+
+    cplx = model in ("ComplEx", "HolE", "RotatE")
+    s, p, o = _cplx_triples() if cplx else _real_triples(model)
+    k = 3 if cplx else 7
+    eng = KgeEngine(model, k, 4, 2, max_rel_size=2)
+    eng.set_tables(np.concatenate([s, o]), p)
+    X = np.array([[0, 0, 2], [1, 1, 3]], dtype=np.int32)
+    got = np.around(eng.score(dev(X)).cpu().numpy(), 2)
+    assert (got == EXPECTED[model]).all(), (model, got)
+
+
+# -------------------------------------------------------------------------------- sampling (a3)
+@pytest.mark.parametrize("B,eta,N", [(1, 1, 1), (7, 3, 10), (1000, 20, 14505), (333, 64, 50_000_000)])
+def test_sampler_bit_exact(gpu_lib, B, eta, N):
+    from ampligraph_amd.engine import KgeEngine
+
+    eng = KgeEngine("DistMult", 4, max(N, 2), 3)
+    rng = np.random.default_rng(2)
+    X = rand_triples(rng, B, max(N, 2), 3)
+    got = eng.sample_corruptions(dev(X), eta, seed=12345678901234, step=(1 << 33) + 5, sample_range=N,
+                                 row_offset=17, b_global=B + 40).cpu().numpy()
+    ref = O.generate_corruptions(X, N, eta, 12345678901234, (1 << 33) + 5, row_offset=17, b_global=B + 40)
+    assert (got == ref).all()
+
+
+# -------------------------------------------------------------------------------- train fwd/bwd
+def run_fwdbwd(eng, X, eta, loss_name, reduction, seed, step, negs=None):
+    B = X.shape[0]
+    eng.prepare_training("adam")
+    eng.loss_acc.zero_()
+    ps = torch.empty(B, dtype=torch.float32, device="cuda")
+    ns = torch.empty(B * eta, dtype=torch.float32, device="cuda")
+    eng.train_fwdbwd(dev(X), eta, loss_desc(loss_name, reduction), seed, step,
+                     neg_override=None if negs is None else dev(negs), pos_scores=ps, neg_scores=ns)
+    torch.cuda.synchronize()
+    return (float(eng.loss_acc[0].item()), eng.g_ent.cpu().numpy(), eng.g_rel.cpu().numpy(),
+            ps.cpu().numpy(), ns.cpu().numpy())
+
+
+def assert_grads_close(G, T, tol=2e-5):
+    T = T.astype(np.float64)
+    # row-wise scale: atomics reorder fp32 sums, so compare against the row's magnitude
+    scale = np.maximum(np.abs(T).max(axis=1, keepdims=True), 1e-6 * max(np.abs(T).max(), 1e-30))
+    err = np.abs(G - T) / scale
+    assert err.max() < tol, err.max()
+
+
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("loss", LOSSES)
+def test_train_fwdbwd_parity(gpu_lib, model, loss):
+    N, R, k, B, eta = 300, 5, 32, 257, 6
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.6)
+    rng = np.random.default_rng(3)
+    X = rand_triples(rng, B, N, R)
+    for reduction in ("sum", "mean"):
+        L, Ge, Gr, ps, ns = run_fwdbwd(eng, X, eta, loss, reduction, seed=9, step=4)
+        negs = O.generate_corruptions(X, N, eta, 9, 4)
+        total, Te, Tr, (sp, sn, per) = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, reduction, R)
+        assert np.allclose(ps, sp, rtol=1e-5, atol=1e-5 * np.abs(sp).max())
+        assert np.allclose(ns, sn, rtol=1e-5, atol=1e-5 * np.abs(sn).max())
+        assert abs(L - float(per.astype(np.float64).sum())) <= 1e-5 * max(1.0, abs(L)), (L, float(total))
+        assert_grads_close(Ge, Te)
+        assert_grads_close(Gr, Tr)
+
+
+@pytest.mark.parametrize("model,k", [("TransE", 50), ("TransE", 7), ("DistMult", 400), ("ComplEx", 200),
+                                       ("ComplEx", 350), ("HolE", 100), ("RotatE", 1000), ("RotatE", 33),
+                                       ("ComplEx", 1024), ("DistMult", 2048)])
+def test_train_fwdbwd_geometries(gpu_lib, model, k):
+    """Every slot geometry (W waves x CH quads, VEC 1/2/4) against the oracle, incl. a ragged tail block."""
+    N, R, B, eta = 200, 4, 37, 5
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.3 if k < 100 else 0.08)
+    rng = np.random.default_rng(4)
+    X = rand_triples(rng, B, N, R)
+    L, Ge, Gr, ps, ns = run_fwdbwd(eng, X, eta, "self_adversarial", "sum", seed=1, step=0)
+    negs = O.generate_corruptions(X, N, eta, 1, 0)
+    total, Te, Tr, (sp, sn, per) = O.dense_gradients(model, ent, rel, X, negs, eta, "self_adversarial", None, "sum", R)
+    assert np.allclose(ps, sp, rtol=1e-5, atol=1e-5 * np.abs(sp).max())
+    assert np.allclose(ns, sn, rtol=1e-5, atol=1e-5 * np.abs(sn).max())
+    assert abs(L - float(total)) <= 2e-5 * max(1.0, abs(L))
+    assert_grads_close(Ge, Te)
+    assert_grads_close(Gr, Tr)
+
+
+def test_train_neg_override_and_duplicates(gpu_lib):
+    """Identity corruptions, s == o triples and heavy row duplication (gradient dedup = sum)."""
+    N, R, k, eta = 5, 2, 8, 4
+    eng, ent, rel = make_engine("ComplEx", k, N, R, scale=0.7)
+    X = np.array([[0, 0, 0], [1, 1, 1], [0, 0, 1], [0, 0, 1], [2, 1, 2]], dtype=np.int32)
+    negs = np.tile(X, (eta, 1))
+    negs[::2, 2] = 3          # object replaced
+    negs[1::2, 0] = X[np.arange(1, len(negs), 2) % len(X), 0]  # identity corruption (subject "replaced" by itself)
+    L, Ge, Gr, ps, ns = run_fwdbwd(eng, X, eta, "multiclass_nll", "sum", 0, 0, negs=negs)
+    total, Te, Tr, _ = O.dense_gradients("ComplEx", ent, rel, X, negs, eta, "multiclass_nll", None, "sum", R)
+    assert abs(L - float(total)) <= 1e-5 * max(1.0, abs(L))
+    assert_grads_close(Ge, Te)
+    assert_grads_close(Gr, Tr)
+
+
+# -------------------------------------------------------------------------------- optimizer (a17/a18)
+@pytest.mark.parametrize("opt", ["adam", "adagrad", "sgd"])
+@pytest.mark.parametrize("reg", [None, (2, 1e-3), (3, 1e-2)])
+def test_opt_step_parity(gpu_lib, opt, reg):
+    from ampligraph_amd import _ffi
+
+    N, R, k = 123, 3, 9   # 123*9 is not a multiple of 4: exercises the scalar tail
+    eng, ent, rel = make_engine("DistMult", k, N, R, scale=0.5)
+    eng.prepare_training(opt)
+    st = O.TrainState(ent, rel, opt, 1e-2)
+    rng = np.random.default_rng(5)
+    for t in range(1, 4):
+        Ge = rng.normal(size=ent.shape) * (rng.random(size=ent.shape) < 0.3)
+        Gr = rng.normal(size=rel.shape)
+        eng.g_ent.copy_(dev(Ge.astype(np.float32)))
+        eng.g_rel.copy_(dev(Gr.astype(np.float32)))
+        eng.loss_acc.zero_()
+        d = _ffi.Opt(_ffi.OPTIMIZERS[opt], reg[0] if reg else 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, t)
+        lam = reg[1] if reg else 0.0
+        reg_loss = 0.0
+        Ge32, Gr32 = Ge.astype(np.float32).astype(np.float64), Gr.astype(np.float32).astype(np.float64)
+        if reg:
+            for x, G in ((st.ent, Ge32), (st.rel, Gr32)):
+                xx = x.astype(np.float64)
+                reg_loss += lam * float((np.abs(xx) ** reg[0]).sum())
+                G += lam * reg[0] * np.abs(xx) ** (reg[0] - 1) * np.sign(xx)
+        eng.opt_step(d, lam, lam)
+        O.apply_optimizer(st, Ge32, Gr32)
+        torch.cuda.synchronize()
+        e, r = eng.get_tables()
+        assert np.abs(e - st.ent).max() <= 2e-6 * max(1.0, np.abs(st.ent).max()), (opt, t)
+        assert np.abs(r - st.rel).max() <= 2e-6 * max(1.0, np.abs(st.rel).max())
+        assert float(eng.g_ent.abs().max()) == 0.0 and float(eng.g_rel.abs().max()) == 0.0  # gradient reset
+        if reg:
+            assert abs(float(eng.loss_acc[1]) - reg_loss) <= 1e-5 * reg_loss
+
+
+# -------------------------------------------------------------------------------- ranks (a9-a11)
+def dyadic_tables(rng, N, R, K):
+    """Tables whose products/sums are exact in fp32 in any order -> bit-exact rank parity, many ties."""
+    ent = (rng.integers(-4, 5, size=(N, K)) / 8.0).astype(np.float32)
+    rel = (rng.integers(-4, 5, size=(R, K)) / 8.0).astype(np.float32)
+    return ent, rel
+
+
+def csr_filters(fl, n):
+    lens = np.array([len(x) for x in fl], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ids = np.concatenate([np.asarray(x, dtype=np.int32) for x in fl] + [np.zeros(0, np.int32)]).astype(np.int32)
+    if ids.size == 0:
+        ids = np.zeros(1, np.int32)
+    return dev(off[:-1]), dev(off[1:]), dev(ids)
+
+
+def gpu_ranks(eng, X, corrupt_side, strategy, fs=None, fo=None, subset=None):
+    from ampligraph_amd import _ffi
+
+    n = X.shape[0]
+    Xd = dev(X)
+    ent_ids = subset_pos = None
+    if subset is not None:
+        ent_ids = dev(np.asarray(subset, dtype=np.int32))
+        pos = np.full(eng.n_ents, -1, dtype=np.int32)
+        pos[np.asarray(subset)] = np.arange(len(subset), dtype=np.int32)
+        subset_pos = dev(pos)
+    cols = []
+    if "s" in corrupt_side:
+        flt = csr_filters(fs, n) if fs is not None else None
+        cols.append(eng.rank_side(Xd, _ffi.SIDE_S, strategy, flt, ent_ids, subset_pos)[0])
+    if "o" in corrupt_side:
+        flt = csr_filters(fo, n) if fo is not None else None
+        cols.append(eng.rank_side(Xd, _ffi.SIDE_O, strategy, flt, ent_ids, subset_pos)[0])
+    r = torch.stack(cols, 1).cpu().numpy()
+    if corrupt_side == "s+o":
+        r = r.sum(1, keepdims=True) - 1
+    return r
+
+
+def test_ranks_reference_kat(gpu_lib):
+    """test_AbstractScoringLayer.py:15-53 through the HIP path (values there are 0-based; +1 here)."""
+    from ampligraph_amd.engine import KgeEngine
+
+    eng = KgeEngine("DistMult", 3, 4, 2)
+    eng.set_tables(np.array([[1, 1, 1], [2, 2, 2], [3, 3, 3], [4, 4, 4]], np.float32),
+                   np.array([[10, 10, 10], [100, 100, 100]], np.float32))
+    X = np.array([[0, 0, 2], [1, 1, 3]], dtype=np.int32)
+    assert (gpu_ranks(eng, X, "s,o", "worst") == np.array([[4, 2], [3, 1]]) + 1).all()
+    fs, fo = [[0], [1]], [[2], [3]]
+    assert (gpu_ranks(eng, X, "s,o", "worst", fs, fo) == np.array([[3, 1], [2, 0]]) + 1).all()
+    assert (gpu_ranks(eng, X, "s", "worst", fs, None) == np.array([[3], [2]]) + 1).all()
+    assert (gpu_ranks(eng, X, "o", "worst", None, fo) == np.array([[1], [0]]) + 1).all()
+
+
+@pytest.mark.parametrize("model", ["TransE", "DistMult", "ComplEx", "HolE"])
+@pytest.mark.parametrize("strategy", ["worst", "best", "middle"])
+def test_ranks_bit_exact_dyadic(gpu_lib, model, strategy):
+    from ampligraph_amd.engine import KgeEngine
+
+    rng = np.random.default_rng(6)
+    N, R, k, n = 777, 5, 12, 301
+    K = O.internal_k(model, k)
+    ent, rel = dyadic_tables(rng, N, R, K)
+    eng = KgeEngine(model, k, N, R)
+    eng.set_tables(ent, rel)
+    X = rand_triples(rng, n, N, R)
+    train = rand_triples(rng, 4000, N, R)
+    fs, fo = O.filter_sets(X, [train, X])
+    for side in ("s,o", "s", "o", "s+o"):
+        ref = O.evaluate_ranks(model, ent, rel, X, fs if "s" in side else None, fo if "o" in side else None,
+                               side, strategy)
+        got = gpu_ranks(eng, X, side, strategy, fs if "s" in side else None, fo if "o" in side else None)
+        assert (got == ref).all(), (model, strategy, side, np.abs(got - ref).max())
+    ref = O.evaluate_ranks(model, ent, rel, X, None, None, "s,o", strategy)
+    assert (gpu_ranks(eng, X, "s,o", strategy) == ref).all()
+
+
+@pytest.mark.parametrize("model", ["DistMult", "TransE"])
+def test_ranks_entities_subset(gpu_lib, model):
+    from ampligraph_amd.engine import KgeEngine
+
+    rng = np.random.default_rng(7)
+    N, R, k, n = 300, 3, 8, 100
+    ent, rel = dyadic_tables(rng, N, R, O.internal_k(model, k))
+    eng = KgeEngine(model, k, N, R)
+    eng.set_tables(ent, rel)
+    X = rand_triples(rng, n, N, R)
+    subset = rng.permutation(N)[:97]
+    fs, fo = O.filter_sets(X, [X, rand_triples(rng, 3000, N, R)])
+    ref = O.evaluate_ranks(model, ent, rel, X, fs, fo, "s,o", "worst", entities_subset=subset)
+    got = gpu_ranks(eng, X, "s,o", "worst", fs, fo, subset=subset)
+    assert (got == ref).all()
+
+
+@pytest.mark.parametrize("model,k", [("TransE", 50), ("DistMult", 400), ("ComplEx", 200), ("HolE", 30),
+                                       ("RotatE", 40), ("RotatE", 7)])
+def test_ranks_random_fp32(gpu_lib, model, k):
+    """Non-exact inputs: ranks may differ from the fp64-accumulated oracle only on comparisons that are
+    fragile under fp32 summation-order noise; the bound is checked per triple, MRR within 2e-3."""
+    N, R, n = 1500, 6, 200
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.4)
+    rng = np.random.default_rng(8)
+    X = rand_triples(rng, n, N, R)
+    fs, fo = O.filter_sets(X, [X, rand_triples(rng, 20000, N, R)])
+    ref = O.evaluate_ranks(model, ent, rel, X, fs, fo, "s,o", "worst", max_rel_size=R)
+    got = gpu_ranks(eng, X, "s,o", "worst", fs, fo)
+    for c, side in enumerate(("s", "o")):
+        frag = O.fragile_rank_mask(model, ent, rel, X, side, max_rel_size=R)
+        diff = np.abs(got[:, c] - ref[:, c])
+        assert (diff <= 2 * frag).all(), (model, side, diff.max(), frag[diff > 0])
+    assert (got != ref).mean() < 0.02
+    assert abs(O.mrr_score(got) - O.mrr_score(ref)) < 2e-3
+
+
+def test_rank_filter_consistent_with_tile_kernel(gpu_lib):
+    """Filtering every entity must cancel the worst-case count exactly: the filter kernel reproduces the
+    tile kernel's scores bit for bit (same k-ordered chain), for all four kernel modes."""
+    rng = np.random.default_rng(9)
+    for model, k in (("DistMult", 37), ("ComplEx", 200), ("TransE", 50), ("RotatE", 24)):
+        N, R, n = 130, 3, 50
+        eng, ent, rel = make_engine(model, k, N, R, scale=0.5)
+        X = rand_triples(rng, n, N, R)
+        allids = [np.arange(N, dtype=np.int32)] * n
+        got = gpu_ranks(eng, X, "s,o", "worst", allids, allids)
+        assert (got == 1).all(), (model, got.min(), got.max())
