@@ -6,6 +6,12 @@ shared object is missing or does not export the ABI version this package was wri
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (soname libamdhip64.so.7, same soname as /opt/rocm's).  It must be
+# the first one mapped into the process so that libamdkge and torch share ONE runtime (one set of
+# devices, streams and allocations); loading libamdkge first would pull /opt/rocm's copy and leave
+# the process with mismatched HIP/HSA runtimes.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libamdkge.so")
 ABI_VERSION = 1
