@@ -116,6 +116,10 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
     unsafeAtomicAdd(p, v);
 }
 
+__device__ __forceinline__ void atomic_add_f32_wg(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ----------------------------------------------------------------------------------------------
 // Scoring-model arithmetic on one "unit": one float of each row (TransE, DistMult) or one complex
 // component pair (ComplEx, HolE, RotatE: re at column c, im at column k+c).

@@ -13,6 +13,7 @@
 // replacement row: one atomic row-add) with hardware fp32 atomics into the dense gradient buffers.
 #include "kge_device.h"
 #include "kge_host.h"
+#include <stdlib.h>
 
 namespace kge {
 
@@ -34,6 +35,7 @@ struct TrainArgs {
     SampleCfg sc;
     ModelConst mc;
     amdkge_loss loss;
+    int dbg;     // development ablation flags (env AMDKGE_DEBUG): 1 no neg-row atomics, 2 no s/p/o atomics, 4 no pass 2, 8 workgroup-scope atomics
 };
 
 __device__ __forceinline__ float log_sigmoid(float x) {
@@ -290,12 +292,42 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
             for (int h = 0; h < NC; ++h) { gs[c][u][h] = ds[h]; gp[c][u][h] = dp[h]; go[c][u][h] = dd[h]; }
         }
 
-    for (int j = 0; j < eta; ++j) {
+    // Row-gradient emit.  fp32 atomics retire per 128-byte line (measured ~10.4 G line-ops/s on MI355X,
+    // scripts/atomic_bench.hip), so every atomic wave-instruction must cover 64 CONSECUTIVE floats.
+    // VEC == 1: the lane's units already are consecutive across lanes.  VEC == 4 (16-byte loads): the row
+    // is transposed through a per-wave LDS staging row (ds_write_b128 -> ds_read_b32) first.
+    float* stage = reinterpret_cast<float*>(smem + (size_t)SLOTS * per_slot + SLOTS * sizeof(double)) + (size_t)(tid >> 6) * a.K;
+    auto emit_row = [&](float* grow, const float (&gr)[CH][VEC][NC], int nfloats, float mul) {
+        if constexpr (VEC == 1) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int h = 0; h < NC; ++h)
+                    if (qok[c] && qoff[c] + h * a.k < nfloats) atomic_add_f32(grow + qoff[c] + h * a.k, gr[c][0][h] * mul);
+        } else {
+            static_assert(VEC == 1 || W == 1, "LDS-transposed emit is per wave");
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int h = 0; h < NC; ++h)
+                    if (qok[c])
+                        *reinterpret_cast<float4*>(stage + qoff[c] + h * a.k) =
+                            make_float4(gr[c][0][h] * mul, gr[c][1][h] * mul, gr[c][2][h] * mul, gr[c][3][h] * mul);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int idx = lane; idx < nfloats; idx += KGE_WAVE) atomic_add_f32(grow + idx, stage[idx]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    const bool do_neg_atomics = active && !(a.dbg & 1);
+    for (int j = 0; j < ((a.dbg & 4) ? 0 : eta); ++j) {
         const int keep = sh_keep[j];
         const int64_t er = (int64_t)sh_repl[j];
         const float g = sh_neg[j] * sgn_scale;
         const float* re = a.ent + er * a.K;
-        float* ge = a.g_ent + er * a.K;
+        float gr[CH][VEC][NC];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             float e[VEC][NC];
@@ -311,20 +343,15 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 if (keep) {   // (s, p, e): object replaced
                     grad_unit<MODEL>(s[c][u], p[c][u], e[u], g, ds, dp, dd);
 #pragma unroll
-                    for (int h = 0; h < NC; ++h) {
-                        gs[c][u][h] += ds[h]; gp[c][u][h] += dp[h];
-                        if (active && qok[c]) atomic_add_f32(ge + qoff[c] + u + h * a.k, dd[h]);
-                    }
+                    for (int h = 0; h < NC; ++h) { gs[c][u][h] += ds[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = dd[h]; }
                 } else {      // (e, p, o): subject replaced
                     grad_unit<MODEL>(e[u], p[c][u], o[c][u], g, ds, dp, dd);
 #pragma unroll
-                    for (int h = 0; h < NC; ++h) {
-                        go[c][u][h] += dd[h]; gp[c][u][h] += dp[h];
-                        if (active && qok[c]) atomic_add_f32(ge + qoff[c] + u + h * a.k, ds[h]);
-                    }
+                    for (int h = 0; h < NC; ++h) { go[c][u][h] += dd[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = ds[h]; }
                 }
             }
         }
+        if (do_neg_atomics) emit_row(a.g_ent + er * a.K, gr, a.K, 1.f);
     }
 
     // ---- per-block loss: one fp64 atomic -------------------------------------------------------
@@ -337,27 +364,14 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     }
 
     // ---- one atomic row-add per resident row ---------------------------------------------------
-    if (active) {
-        float* gS = a.g_ent + (int64_t)ps * a.K;
-        float* gP = a.g_rel + (int64_t)pp * a.K;
-        float* gO = a.g_ent + (int64_t)po * a.K;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (!qok[c]) continue;
-#pragma unroll
-            for (int u = 0; u < VEC; ++u) {
-#pragma unroll
-                for (int h = 0; h < NC; ++h) {
-                    atomic_add_f32(gS + qoff[c] + u + h * a.k, gs[c][u][h]);
-                    atomic_add_f32(gO + qoff[c] + u + h * a.k, go[c][u][h]);
-                    if constexpr (MODEL == AMDKGE_ROTATE) {
-                        // d/dtheta = d/dphi / phase_div ; second half of the relation row gets no gradient
-                        if (h == 0) atomic_add_f32(gP + qoff[c] + u, gp[c][u][0] / a.mc.phase_div);
-                    } else {
-                        atomic_add_f32(gP + qoff[c] + u + h * a.k, gp[c][u][h]);
-                    }
-                }
-            }
+    if (active && !(a.dbg & 2)) {
+        emit_row(a.g_ent + (int64_t)ps * a.K, gs, a.K, 1.f);
+        emit_row(a.g_ent + (int64_t)po * a.K, go, a.K, 1.f);
+        if constexpr (MODEL == AMDKGE_ROTATE) {
+            // d/dtheta = d/dphi / phase_div ; the second half of the relation row gets no gradient
+            emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.k, 1.f / a.mc.phase_div);
+        } else {
+            emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.K, 1.f);
         }
     }
 }
@@ -378,33 +392,46 @@ __global__ void sample_kernel(const int32_t* triples, int64_t B, int eta, Sample
     out[3 * r + 2] = keep ? repl : o;
 }
 
-template <int MODEL, int VEC>
-static int launch_train_mv(const TrainArgs& a, hipStream_t st) {
-    // slot geometry: W waves per positive, CH quads per lane
-    int W, CH;
-    if (a.nq <= 64) { W = 1; CH = 1; }
-    else if (a.nq <= 128) { W = 2; CH = 1; }
-    else if (a.nq <= 256) { W = 4; CH = 1; }
-    else if (a.nq <= 512) { W = 4; CH = 2; }
-    else return set_error(AMDKGE_EUNSUPPORTED, "train: embedding row too long for the compiled slot geometries (units/VEC > 512)");
+template <int MODEL, int VEC, int W>
+static int launch_train_w(const TrainArgs& a, int CH, hipStream_t st) {
     const int slots = 4 / W;
-    const size_t shmem = (size_t)slots * slot_lds_bytes(a.eta, W) + slots * sizeof(double);
+    const size_t shmem = (size_t)slots * slot_lds_bytes(a.eta, W) + slots * sizeof(double) + (VEC == 4 ? 4 * (size_t)a.K * 4 : 0);
     if (shmem > 64 * 1024) return set_error(AMDKGE_EUNSUPPORTED, "train: eta too large for the LDS score buffer");
     const unsigned grid = (unsigned)((a.B + slots - 1) / slots);
-#define KGE_LAUNCH(WW, CC) hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, VEC, WW, CC>), dim3(grid), dim3(256), shmem, st, a)
-    if (W == 1) KGE_LAUNCH(1, 1);
-    else if (W == 2) KGE_LAUNCH(2, 1);
-    else if (CH == 1) KGE_LAUNCH(4, 1);
-    else KGE_LAUNCH(4, 2);
+#define KGE_LAUNCH(CC) hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, VEC, W, CC>), dim3(grid), dim3(256), shmem, st, a)
+    switch (CH) {
+        case 1: KGE_LAUNCH(1); break;
+        case 2: KGE_LAUNCH(2); break;
+        case 4: KGE_LAUNCH(4); break;
+        default: KGE_LAUNCH(8); break;
+    }
 #undef KGE_LAUNCH
     return check_launch("train_fwdbwd");
+}
+
+// Slot geometry.  A lane owns CH "quads" of VEC consecutive units at quad index ts + c*64*W, so with
+// VEC == 1 every wave-instruction (load or atomic) covers 64 consecutive floats = two full 128-byte
+// lines.  Measured on MI355X (scripts/atomic_bench.hip): fp32 atomics retire ~10.4 G cache-line
+// operations/s whatever the number of dwords per line, so the 16-byte-per-lane layout (8 active
+// dwords per line) makes the gradient scatter 4.4x slower than the lane-contiguous one.
+template <int MODEL, int VEC>
+static int launch_train_mv(const TrainArgs& a, hipStream_t st) {
+    int W = 1;
+    while (W < 4 && (a.nq + 64 * W - 1) / (64 * W) > 8) W *= 2;
+    int ch = (a.nq + 64 * W - 1) / (64 * W);
+    if (ch > 8) return set_error(AMDKGE_EUNSUPPORTED, "train: embedding row too long for the compiled slot geometries (k > 2048)");
+    int CH = 1;
+    while (CH < ch) CH *= 2;
+    if (W == 1) return launch_train_w<MODEL, VEC, 1>(a, CH, st);
+    if (W == 2) return launch_train_w<MODEL, VEC, 2>(a, CH, st);
+    return launch_train_w<MODEL, VEC, 4>(a, CH, st);
 }
 
 template <int MODEL>
 static int launch_train_m(TrainArgs& a, hipStream_t st) {
     const int units = a.k;  // units per row: k floats (real models) or k complex pairs
-    if (units % 4 == 0) { a.nq = units / 4; return launch_train_mv<MODEL, 4>(a, st); }
-    if (units % 2 == 0) { a.nq = units / 2; return launch_train_mv<MODEL, 2>(a, st); }
+    // 16-byte loads + LDS-transposed scatter when one wave covers the row with <= 2 quads per lane
+    if (units % 4 == 0 && units <= 512 && !(a.dbg & 16)) { a.nq = units / 4; return launch_train_w<MODEL, 4, 1>(a, a.nq <= 64 ? 1 : 2, st); }
     a.nq = units;
     return launch_train_mv<MODEL, 1>(a, st);
 }
@@ -450,6 +477,7 @@ extern "C" int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* los
                      (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
     a.mc = model_const(m);
     a.loss = *loss;
+    { const char* e = getenv("AMDKGE_DEBUG"); a.dbg = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
     switch (m->scoring_type) {
         case AMDKGE_TRANSE: return launch_train_m<AMDKGE_TRANSE>(a, st);

@@ -1,0 +1,54 @@
+"""True-positive filter sets for evaluate(use_filter=...), as sort-based CSR instead of the
+reference's pandas groupby + Python `sum(lists, [])` per batch
+(/root/reference/ampligraph/datasets/graph_data_loader.py:287-350,382-439).
+
+Semantics kept: for a test triple (s,p,o) the subject-side filter is the SET {s' : (s',p,o) in any
+filter dataset} and the object-side filter the SET {o' : (s,p,o') in any filter dataset}; all ids are
+the training id map's.  The index is built once per evaluate() call; a test triple's filter is a
+[lo, hi) range into one shared id array, so no per-batch host work remains."""
+import numpy as np
+
+
+class FilterIndex:
+    def __init__(self, datasets, n_ents, n_rels):
+        X = np.concatenate([np.asarray(d)[:, :3].astype(np.int64) for d in datasets], 0) if len(datasets) else \
+            np.zeros((0, 3), dtype=np.int64)
+        self.n_ents, self.n_rels = int(n_ents), int(n_rels)
+        N, R = self.n_ents, self.n_rels
+        s, p, o = X[:, 0], X[:, 1], X[:, 2]
+        # subject side: group by (p,o), values s (unique)
+        k_s = np.unique((p * N + o) * N + s)
+        self.po_keys, self.po_start = np.unique(k_s // N, return_index=True)
+        self.po_start = np.append(self.po_start, k_s.size).astype(np.int64)
+        self.s_ids = (k_s % N).astype(np.int32)
+        # object side: group by (s,p), values o (unique)
+        k_o = np.unique((s * R + p) * N + o)
+        self.sp_keys, self.sp_start = np.unique(k_o // N, return_index=True)
+        self.sp_start = np.append(self.sp_start, k_o.size).astype(np.int64)
+        self.o_ids = (k_o % N).astype(np.int32)
+
+    @staticmethod
+    def _ranges(keys, start, q):
+        if keys.size == 0:
+            z = np.zeros(q.shape[0], dtype=np.int64)
+            return z, z.copy()
+        pos = np.searchsorted(keys, q)
+        pos_c = np.minimum(pos, keys.size - 1)
+        hit = keys[pos_c] == q
+        lo = np.where(hit, start[pos_c], 0).astype(np.int64)
+        hi = np.where(hit, start[pos_c + 1], 0).astype(np.int64)
+        return lo, hi
+
+    def subject_ranges(self, triples):
+        t = np.asarray(triples)[:, :3].astype(np.int64)
+        return self._ranges(self.po_keys, self.po_start, t[:, 1] * self.n_ents + t[:, 2])
+
+    def object_ranges(self, triples):
+        t = np.asarray(triples)[:, :3].astype(np.int64)
+        return self._ranges(self.sp_keys, self.sp_start, t[:, 0] * self.n_rels + t[:, 1])
+
+    def as_lists(self, triples):
+        """Materialise per-triple id arrays (what the reference yields as a RaggedTensor); tests only."""
+        slo, shi = self.subject_ranges(triples)
+        olo, ohi = self.object_ranges(triples)
+        return ([self.s_ids[a:b] for a, b in zip(slo, shi)], [self.o_ids[a:b] for a, b in zip(olo, ohi)])

@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): training triples/s INCLUDING negatives, ComplEx k=200, eta=20,
+self-adversarial NLL, Adam, on an FB15K-237-shaped synthetic graph (configs[1]); batch 10 000
+positives per GPU per step (the reference docstring's batch, ScoringBasedEmbeddingModel.py:66).
+One "step" = one pass of the hot path over one batch: fused lookup/sampling/score/loss/backward
+kernel + (N>1: gradient all-reduce over RCCL) + dense optimizer sweep of both tables.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run
+(one rank per GPU).  Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel =
+train_fwdbwd, HBM-bound, algorithmic bytes 2*(3+eta)*4K per positive), `cpu_baseline`
+(oracle/ref_cpu.py, the op-for-op torch-CPU port, on a bounded sample) and `eval` (filtered
+ranks/s of evaluate() on the 20 438 synthetic test triples, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=280)
+    ap.add_argument("--warmup", type=int, default=28)
+    ap.add_argument("--batch", type=int, default=10000, help="positives per GPU per step")
+    ap.add_argument("--model", default="ComplEx")
+    ap.add_argument("--k", type=int, default=200)
+    ap.add_argument("--eta", type=int, default=20)
+    ap.add_argument("--loss", default="self_adversarial")
+    ap.add_argument("--dataset", default="synth-fb15k237")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, data, ent0, rel0):
+    """The reference-equivalent CPU path (oracle/ref_cpu.py) timed on this box's host cores: a bounded
+    sample of the SAME workload (first `cpu_steps`+1 batches, first one untimed)."""
+    from oracle import ref_cpu
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tr = ref_cpu.RefCpuTrainer(args.model, ent0, rel0, args.eta, args.loss, 1e-3, data["n_rels"])
+    X = torch.as_tensor(data["train"].astype(np.int64))
+    B = args.batch
+    tr.step(X[:B])  # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    for s in range(1, args.cpu_steps + 1):
+        tr.step(X[s * B:(s + 1) * B])
+    dt = time.perf_counter() - t0
+    return {"value": args.cpu_steps * B * (1 + args.eta) / dt, "unit": "triples/s", "cores": cores,
+            "kind": "port", "threads": torch.get_num_threads(),
+            "sample": f"{args.cpu_steps} train steps of B={B} (after 1 warm-up step), same tables and triples; "
+                      "oracle/ref_cpu.py = op-for-op torch-CPU restatement of the reference TF graph "
+                      "(TensorFlow itself is not installable here)"}
+
+
+def eval_bench(eng, data, rank):
+    """Filtered evaluate() of the synthetic test split, both sides: ranks/s (BASELINE.json metric, part 2)."""
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.datasets.filters import FilterIndex
+
+    test = data["test"]
+    n = test.shape[0]
+    t0 = time.perf_counter()
+    fi = FilterIndex([data["train"], data["valid"], test], data["n_ents"], data["n_rels"])
+    slo, shi = fi.subject_ranges(test)
+    olo, ohi = fi.object_ranges(test)
+    host_prep = time.perf_counter() - t0
+    dev = eng.device
+    Xd = torch.as_tensor(test).to(dev)
+    fs = (torch.as_tensor(slo).to(dev), torch.as_tensor(shi).to(dev), torch.as_tensor(fi.s_ids).to(dev))
+    fo = (torch.as_tensor(olo).to(dev), torch.as_tensor(ohi).to(dev), torch.as_tensor(fi.o_ids).to(dev))
+    ranks = torch.empty(n, 2, dtype=torch.int32, device=dev)
+
+    def run():
+        eng.rank_side(Xd, _ffi.SIDE_S, "worst", fs, out=ranks[:, 0], out_stride=2)
+        eng.rank_side(Xd, _ffi.SIDE_O, "worst", fo, out=ranks[:, 1], out_stride=2)
+
+    run()
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    r = ranks.cpu().numpy()
+    flops = 2.0 * data["n_ents"] * eng.K * n * 2
+    return {"ranks_per_s": 2 * n / dt, "ms": dt * 1e3, "n_test": int(n), "sides": 2, "filtered": True,
+            "host_filter_index_ms": host_prep * 1e3, "achieved_tflops_fp32": flops / dt / 1e12,
+            "mrr_untrained_tables": float(np.mean(1.0 / r)), "note": "tables as left by the timed training steps"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.datasets import make_synthetic_kg
+    from ampligraph_amd.engine import KgeEngine
+
+    data = make_synthetic_kg(args.dataset, seed=0)
+    N, R = data["n_ents"], data["n_rels"]
+    eng = KgeEngine(args.model, args.k, N, R, max_rel_size=R)
+    rng = np.random.Generator(np.random.PCG64(0))
+    lim_e, lim_r = np.sqrt(6.0 / (N + eng.K)), np.sqrt(6.0 / (R + eng.K))
+    ent0 = rng.uniform(-lim_e, lim_e, size=(N, eng.K)).astype(np.float32)  # Glorot uniform, same on every rank
+    rel0 = rng.uniform(-lim_r, lim_r, size=(R, eng.K)).astype(np.float32)
+    eng.set_tables(ent0, rel0)
+    eng.prepare_training("adam")
+    loss = _ffi.Loss(_ffi.LOSSES[args.loss], 0, 3.0 if args.loss == "self_adversarial" else 1.0, 0.5)
+
+    # the training set lives in HBM; a global batch is a contiguous slice (reference order: sequential,
+    # un-shuffled, graph_data_loader.py:472-523), each rank takes its B-row share of it
+    B = args.batch
+    Bg = B * world
+    train = torch.as_tensor(data["train"]).cuda()
+    n_train = train.shape[0]
+    steps_per_epoch = max(1, n_train // Bg)
+
+    def batch_of(step):
+        b0 = (step % steps_per_epoch) * Bg + rank * B
+        return train[b0:b0 + B]
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def one_step(step, timed_idx=None):
+        xb = batch_of(step)
+        if timed_idx is not None:
+            ev[timed_idx][0].record()
+        eng.train_fwdbwd(xb, args.eta, loss, seed=0, step=step, row_offset=rank * B, b_global=Bg)
+        if timed_idx is not None:
+            ev[timed_idx][1].record()
+        if world > 1:
+            dist.all_reduce(eng.g_ent)
+            dist.all_reduce(eng.g_rel)
+        eng.opt_step(_ffi.Opt(_ffi.OPTIMIZERS["adam"], 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, step + 1))
+
+    for s in range(args.warmup):
+        one_step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(args.warmup + s, s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    loss_mean = float(eng.loss_acc[0].item()) / max(1, args.warmup + args.steps)
+    if world > 1:
+        t = torch.tensor([loss_mean], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        loss_mean = float(t.item())
+
+    if rank == 0:
+        triples = float(world) * B * (1 + args.eta) * args.steps
+        bytes_per_pos = 2.0 * (3 + args.eta) * 4.0 * eng.K   # each distinct row read once + its gradient written once
+        achieved = bytes_per_pos * B / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("train_fwdbwd_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "training triples/sec (incl. negatives), ComplEx k=200 eta=20 FB15K-237-shaped",
+            "value": triples / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.dataset} (uniform, seed 0) {args.model} k={args.k} eta={args.eta} "
+                                   f"{args.loss} adam lr=1e-3, {B} positives/GPU/step, tables resident in HBM, "
+                                   f"dense Keras-legacy Adam sweep every step",
+                       "global_batch": Bg, "n_ents": N, "n_rels": R, "row_floats": eng.K,
+                       "parallelism": f"dp{world} (replicated tables, gradient all-reduce)" if world > 1 else "single GPU"},
+            "mean_batch_loss": loss_mean,
+            "roofline": {"bound": "hbm", "kernel": "train_fwdbwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_pos * B},
+        }
+        if world == 1 and not args.no_eval:
+            out["eval"] = eval_bench(eng, data, rank)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, data, ent0, rel0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
