@@ -1,0 +1,106 @@
+"""String/any-label -> int32 id maps with the reference's in-memory rule
+(/root/reference/ampligraph/datasets/data_indexer.py:373-399): scan the rows in order, the subject
+then the object of a row get the next free entity id when first seen; relations are numbered
+separately in order of first appearance.  Unknown keys at lookup time make the whole row drop out
+(data_indexer.py:485-549).  Vectorised with numpy (sort + first-occurrence) instead of Python dict
+loops; results are identical."""
+import numpy as np
+
+
+def _as_labels(a):
+    a = np.asarray(a)
+    if a.dtype == object:
+        a = a.astype(str)
+    return a
+
+
+def _first_seen(flat):
+    uniq, first = np.unique(flat, return_index=True)
+    order = np.argsort(first, kind="stable")
+    ids = np.empty(uniq.shape[0], dtype=np.int32)
+    ids[order] = np.arange(uniq.shape[0], dtype=np.int32)
+    return uniq, ids  # uniq sorted; ids[i] = id of uniq[i]
+
+
+class DataIndexer:
+    def __init__(self, X):
+        X = _as_labels(X)
+        if X.ndim != 2 or X.shape[1] < 3:
+            raise ValueError("training data must have shape (n, 3) or (n, >3)")
+        ents = np.stack([X[:, 0], X[:, 2]], 1).reshape(-1)   # s0,o0,s1,o1,... = the reference's scan order
+        self._ent_sorted, self._ent_ids = _first_seen(ents)
+        self._rel_sorted, self._rel_ids = _first_seen(X[:, 1])
+        # ind -> raw
+        self._ent_raw = np.empty_like(self._ent_sorted)
+        self._ent_raw[self._ent_ids] = self._ent_sorted
+        self._rel_raw = np.empty_like(self._rel_sorted)
+        self._rel_raw[self._rel_ids] = self._rel_sorted
+
+    # counts -------------------------------------------------------------------------------------
+    def get_entities_count(self):
+        return int(self._ent_sorted.shape[0])
+
+    def get_relations_count(self):
+        return int(self._rel_sorted.shape[0])
+
+    # lookups ------------------------------------------------------------------------------------
+    @staticmethod
+    def _lookup(sorted_keys, ids, q):
+        q = _as_labels(q)
+        if sorted_keys.dtype.kind in "US" and q.dtype.kind not in "US":
+            q = q.astype(str)
+        elif sorted_keys.dtype.kind not in "US" and q.dtype.kind in "US":
+            sorted_keys = sorted_keys.astype(str)  # mixed use: compare as text
+            order = np.argsort(sorted_keys)
+            sorted_keys, ids = sorted_keys[order], ids[order]
+        pos = np.searchsorted(sorted_keys, q)
+        pos_c = np.minimum(pos, sorted_keys.shape[0] - 1)
+        ok = sorted_keys[pos_c] == q
+        return np.where(ok, ids[pos_c], -1).astype(np.int32), ok
+
+    def get_indexes(self, X, type_of="t", order="raw2ind"):
+        if order not in ("raw2ind", "ind2raw"):
+            raise Exception(f"No such order available options: ind2raw, raw2ind, instead got {order}.")
+        X = np.asarray(X)
+        if type_of == "t":
+            if order == "raw2ind":
+                s, oks = self._lookup(self._ent_sorted, self._ent_ids, X[:, 0])
+                p, okp = self._lookup(self._rel_sorted, self._rel_ids, X[:, 1])
+                o, oko = self._lookup(self._ent_sorted, self._ent_ids, X[:, 2])
+                ok = oks & okp & oko
+                bad = int((~ok).sum())
+                if bad:
+                    print(f"\n{bad} triples containing invalid keys skipped!\n")
+                return np.stack([s[ok], p[ok], o[ok]], 1).astype(np.int32)
+            X = X.astype(np.int64)
+            return np.stack([self._ent_raw[X[:, 0]], self._rel_raw[X[:, 1]], self._ent_raw[X[:, 2]]], 1)
+        keys, ids, raw = ((self._ent_sorted, self._ent_ids, self._ent_raw) if type_of == "e"
+                          else (self._rel_sorted, self._rel_ids, self._rel_raw))
+        if type_of not in ("e", "r"):
+            raise ValueError("type_of must be 't', 'e' or 'r'")
+        if order == "raw2ind":
+            out, ok = self._lookup(keys, ids, X.reshape(-1))
+            return out[ok]
+        return raw[X.reshape(-1).astype(np.int64)]
+
+    def valid_row_mask(self, X):
+        """Rows of raw triples whose three keys are all known (the rows get_indexes keeps)."""
+        X = np.asarray(X)
+        _, a = self._lookup(self._ent_sorted, self._ent_ids, X[:, 0])
+        _, b = self._lookup(self._rel_sorted, self._rel_ids, X[:, 1])
+        _, c = self._lookup(self._ent_sorted, self._ent_ids, X[:, 2])
+        return a & b & c
+
+    # persistence --------------------------------------------------------------------------------
+    def state(self):
+        return {"ent_raw": self._ent_raw, "rel_raw": self._rel_raw}
+
+    @classmethod
+    def from_state(cls, st):
+        self = cls.__new__(cls)
+        self._ent_raw, self._rel_raw = np.asarray(st["ent_raw"]), np.asarray(st["rel_raw"])
+        for raw, pre in ((self._ent_raw, "_ent"), (self._rel_raw, "_rel")):
+            order = np.argsort(raw, kind="stable")
+            setattr(self, pre + "_sorted", raw[order])
+            setattr(self, pre + "_ids", order.astype(np.int32))
+        return self

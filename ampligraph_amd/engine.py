@@ -75,6 +75,9 @@ class KgeEngine:
             self.slots["a_e"] = torch.full_like(self.ent, 0.1)
             self.slots["a_r"] = torch.full_like(self.rel, 0.1)
 
+    def grad_tensors(self):
+        return [self.g_ent, self.g_rel]
+
     def train_fwdbwd(self, triples, eta, loss, seed, step, sample_base=0, sample_range=None,
                      row_offset=0, b_global=0, neg_override=None, pos_scores=None, neg_scores=None):
         """triples: int32 cuda tensor (B,3).  Accumulates into g_ent/g_rel and loss_acc[0]."""

@@ -1,0 +1,339 @@
+"""ScoringBasedEmbeddingModel: the reference's public model class
+(/root/reference/ampligraph/latent_features/models/ScoringBasedEmbeddingModel.py:47) re-hosted on the
+MI355X engine.  Same constructor / compile / fit / predict / evaluate / get_embeddings surface,
+argument meaning and error behaviour; the Keras/TF machinery underneath is replaced by libamdkge
+(HIP kernels, C ABI) driven from plain Python.  No TensorFlow, no CPU fallback.
+
+Intentional, documented differences: negatives come from a counter-based Philox stream
+keyed by (seed, step, row) instead of TF's stateful stream; tables are always HBM-resident, so
+`partitioning_k > 1` is rejected; FocusE / calibration are "next" rows and raise.
+"""
+import json
+import os
+
+import numpy as np
+
+from .. import _ffi
+from ..datasets.filters import FilterIndex
+from ..datasets.indexer import DataIndexer
+from ..evaluation.metrics import hits_at_n_score, mr_score, mrr_score
+from ..trainer import StepLoop
+from . import loss_functions, optimizers, regularizers
+from .initializers import initialise
+
+SCORING_LAYER_REGISTRY = dict(_ffi.SCORING_TYPES)  # AbstractScoringLayer.py:15 (Random is out of scope)
+
+
+class History:
+    """Keras-History look-alike returned by fit(): `.history[name]` lists, `.epoch` list."""
+
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+    def _log(self, epoch, logs):
+        self.epoch.append(epoch)
+        for k, v in logs.items():
+            self.history.setdefault(k, []).append(v)
+
+
+def _load_triples(x):
+    """Accept what the reference's GraphDataLoader accepts for in-memory data
+    (datasets/graph_data_loader.py:129-181): ndarray, list, DataFrame, or a csv/tsv file name."""
+    if isinstance(x, str):
+        import pandas as pd
+
+        x = pd.read_csv(x, sep="\t", header=None, dtype=str).values
+    elif hasattr(x, "values") and not isinstance(x, np.ndarray):
+        x = x.values
+    x = np.asarray(x)
+    if x.ndim != 2 or x.shape[1] < 3:
+        raise ValueError("triples must have shape (n, 3) (or (n, >3) with numeric edge values)")
+    return x
+
+
+class ScoringBasedEmbeddingModel:
+    def __init__(self, eta, k, scoring_type="DistMult", seed=0, max_ent_size=None, max_rel_size=None):
+        if scoring_type not in SCORING_LAYER_REGISTRY:
+            raise KeyError(scoring_type)  # the reference indexes SCORING_LAYER_REGISTRY directly (:146)
+        self.eta = int(eta)
+        self.k = int(k)
+        self.scoring_type = scoring_type
+        self.seed = int(seed)
+        self.max_ent_size = max_ent_size
+        self.max_rel_size = max_rel_size
+        self.internal_k = 2 * self.k if scoring_type in ("ComplEx", "HolE", "RotatE") else self.k
+        self.data_indexer = None
+        self.is_fitted = False
+        self.is_calibrated = False
+        self.is_compiled = False
+        self.use_focusE = False
+        self.history = None
+        self.stop_training = False
+        self._engine = None
+        self._loop = None
+
+    # ------------------------------------------------------------------------------------ compile
+    def compile(self, optimizer="adam", loss=None, entity_relation_initializer="glorot_uniform",
+                entity_relation_regularizer=None, **kwargs):
+        """:1145-1152.  optimizer: name | OptimizerWrapper; loss: name | Loss; initializer: one value or
+        [entity_init, relation_init]; regularizer: None | 'LP'/'l1'/'l2'/'l3' | LPRegularizer | pair."""
+        self.optimizer = optimizers.get(optimizer)
+        if loss is None:
+            raise ValueError("compile(): a loss is required")
+        self.loss = loss_functions.get(loss)
+        ini = entity_relation_initializer
+        self._initializers = list(ini) if isinstance(ini, (list, tuple)) else [ini, ini]
+        if len(self._initializers) != 2:
+            raise ValueError("entity_relation_initializer must be one value or a pair [entity, relation]")
+        if self.scoring_type == "RotatE":  # :1312-1315
+            r = self._initializers[1]
+            assert isinstance(r, str) and r.lower() == "glorot_uniform", \
+                "RotatE requires the relation embeddings to be initialised with GlorotUniform"
+        reg = entity_relation_regularizer
+        regs = list(reg) if isinstance(reg, (list, tuple)) else [reg, reg]
+        self._regularizers = [regularizers.get(r) for r in regs]
+        if (self._regularizers[0] is None) != (self._regularizers[1] is None) or (
+                self._regularizers[0] is not None and self._regularizers[0].p != self._regularizers[1].p):
+            raise NotImplementedError("entity and relation regularisers must share p (different lambdas are fine)")
+        self.is_compiled = True
+
+    def _assert_compile_was_called(self):
+        if not self.is_compiled:
+            raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
+
+    # ------------------------------------------------------------------------------------ engine
+    def _build(self, n_ents, n_rels):
+        from ..engine import KgeEngine  # raises loudly without the HIP library / a GPU
+
+        self.max_ent_size, self.max_rel_size = int(n_ents), int(n_rels)
+        self._engine = KgeEngine(self.scoring_type, self.k, n_ents, n_rels, max_rel_size=n_rels)
+        rng = np.random.Generator(np.random.PCG64(self.seed))
+        ent = initialise(self._initializers[0], (n_ents, self.internal_k), rng)
+        rel = initialise(self._initializers[1], (n_rels, self.internal_k), rng)
+        self._engine.set_tables(ent, rel)
+
+    def _dist(self):
+        import torch.distributed as dist
+
+        return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+    # ------------------------------------------------------------------------------------ fit
+    def fit(self, x=None, batch_size=1000, epochs=100, verbose=True, callbacks=None, validation_split=0.0,
+            validation_data=None, shuffle=True, initial_epoch=0, validation_batch_size=10,
+            validation_corrupt_side="s,o", validation_freq=10, validation_burn_in=0, validation_filter=False,
+            validation_entities_subset=None, partitioning_k=1, focusE=False, focusE_params={}):
+        """:544-883.  Batches are sequential, un-shuffled slices of `x` with a short last batch
+        (graph_data_loader.py:472-523); `shuffle` is accepted and, like in the reference (:553), unused."""
+        import torch
+
+        self._assert_compile_was_called()
+        if partitioning_k != 1:
+            raise NotImplementedError("partitioning_k > 1: tables are HBM-resident on MI355X, graph partitioning "
+                                      "with disk swapping is out of scope (SURVEY.md section 2, rows 15-16)")
+        if focusE:
+            raise NotImplementedError("FocusE numeric-edge weighting is a 'next' row (SURVEY.md 8f)")
+        if validation_split:
+            raise NotImplementedError("validation_split: pass validation_data explicitly")
+        X = _load_triples(x)
+        if self.data_indexer is None or not self.is_fitted:
+            self.data_indexer = DataIndexer(X)
+            Xi = self.data_indexer.get_indexes(X[:, :3])
+            self._build(self.data_indexer.get_entities_count(), self.data_indexer.get_relations_count())
+        else:  # continue training (initial_epoch > 0): same id map, same tables
+            Xi = self.data_indexer.get_indexes(X[:, :3])
+        eng = self._engine
+        if self._loop is None:
+            reg = self._regularizers[0]
+            if reg is not None and self._regularizers[1].lam != reg.lam:
+                raise NotImplementedError("different lambdas for entity / relation tables")
+            self._loop = StepLoop(eng, self.eta, self.loss, self.optimizer, reg, self.seed, self._dist())
+        loop = self._loop
+        train = torch.as_tensor(np.ascontiguousarray(Xi, dtype=np.int32)).to(eng.device)
+        n = int(train.shape[0])
+        batch_size = int(batch_size)
+        steps = (n + batch_size - 1) // batch_size
+        self.history = History()
+        cbs = list(callbacks or [])
+        for cb in cbs:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+            if hasattr(cb, "on_train_begin"):
+                cb.on_train_begin()
+        self.stop_training = False
+        if isinstance(validation_entities_subset, str) and validation_entities_subset == "all":
+            validation_entities_subset = None
+        for epoch in range(int(initial_epoch), int(epochs)):
+            self.current_epoch = epoch
+            loop.reset_loss()
+            for step in range(steps):
+                b0 = step * batch_size
+                loop.step(train[b0:b0 + batch_size], epoch * steps + step)
+            logs = {"loss": loop.mean_batch_loss()}
+            validate = (epoch >= (validation_burn_in - 1) and validation_data is not None
+                        and (epoch + 1) % int(validation_freq) == 0)
+            if validate:
+                self.is_fitted = True
+                ranks = self.evaluate(validation_data, batch_size=validation_batch_size or batch_size,
+                                      use_filter=validation_filter, dataset_type="valid",
+                                      corrupt_side=validation_corrupt_side,
+                                      entities_subset=validation_entities_subset, verbose=False)
+                logs.update({"val_mrr": mrr_score(ranks), "val_mr": mr_score(ranks),
+                             "val_hits@1": hits_at_n_score(ranks, 1), "val_hits@10": hits_at_n_score(ranks, 10),
+                             "val_hits@100": hits_at_n_score(ranks, 100)})  # :1857-1863
+            self.history._log(epoch, logs)
+            if verbose:
+                print(f"Epoch {epoch + 1}/{epochs} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()))
+            for cb in cbs:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in cbs:
+            if hasattr(cb, "on_train_end"):
+                cb.on_train_end()
+        self.is_fitted = True
+        return self.history
+
+    # ------------------------------------------------------------------------------------ predict
+    def _index_test(self, x):
+        assert self.is_fitted, "Model is not fit on the data yet!"
+        X = _load_triples(x)
+        return np.ascontiguousarray(self.data_indexer.get_indexes(X[:, :3]), dtype=np.int32)
+
+    def predict(self, x, batch_size=32, verbose=0, callbacks=None):
+        """:1736-1823: float32 (n,) scores in input order (rows with unknown keys dropped)."""
+        import torch
+
+        Xi = self._index_test(x)
+        if Xi.shape[0] == 0:
+            return np.zeros(0, dtype=np.float32)
+        out = self._engine.score(torch.as_tensor(Xi).to(self._engine.device))
+        return out.cpu().numpy()
+
+    # ------------------------------------------------------------------------------------ evaluate
+    def evaluate(self, x=None, batch_size=32, verbose=True, use_filter=False, corrupt_side="s,o",
+                 entities_subset=None, ranking_strategy="worst", callbacks=None, dataset_type="test"):
+        """:1516-1692: int32 ranks (n, 1|2), 1-based, reference tie/filter semantics.  `batch_size` only
+        chunked the TF graph in the reference; results do not depend on it and it is ignored here."""
+        import torch
+
+        assert corrupt_side in ["s", "o", "s,o", "s+o"], "Invalid value for corrupt_side"
+        assert ranking_strategy in ["best", "middle", "worst"], "Invalid value for ranking_strategy"
+        Xi = self._index_test(x)
+        eng = self._engine
+        n = Xi.shape[0]
+        sides = [sd for sd in ("s", "o") if sd in corrupt_side]
+        if n == 0:
+            return np.zeros((0, 1 if corrupt_side in ("s", "o", "s+o") else 2), dtype=np.int32)
+        # filters (graph_data_loader.py:184-190,652-653): True -> the evaluated data filters itself;
+        # dict -> union of the given datasets, all indexed with the training id map
+        fi = None
+        if isinstance(use_filter, dict):
+            fi = FilterIndex([self.data_indexer.get_indexes(_load_triples(v)[:, :3]) for v in use_filter.values()],
+                             eng.n_ents, eng.n_rels)
+        elif use_filter:
+            fi = FilterIndex([Xi], eng.n_ents, eng.n_rels)
+        dev = eng.device
+        ent_ids = subset_pos = None
+        if entities_subset is not None and len(entities_subset) > 0:
+            sub = np.asarray(self.data_indexer.get_indexes(np.asarray(entities_subset), "e"), dtype=np.int32)
+            pos = np.full(eng.n_ents, -1, dtype=np.int32)
+            pos[sub] = np.arange(sub.shape[0], dtype=np.int32)  # DenseHashTable.insert: last wins (:1639-1643)
+            ent_ids, subset_pos = torch.as_tensor(sub).to(dev), torch.as_tensor(pos).to(dev)
+        Xd = torch.as_tensor(Xi).to(dev)
+        ranks = torch.empty(n, len(sides), dtype=torch.int32, device=dev)
+        flt_ids = {}
+        if fi is not None:
+            flt_ids = {"s": torch.as_tensor(fi.s_ids if fi.s_ids.size else np.zeros(1, np.int32)).to(dev),
+                       "o": torch.as_tensor(fi.o_ids if fi.o_ids.size else np.zeros(1, np.int32)).to(dev)}
+        CH = 1 << 16
+        for c0 in range(0, n, CH):
+            xs = Xd[c0:c0 + CH]
+            for col, sd in enumerate(sides):
+                flt = None
+                if fi is not None:
+                    lo, hi = (fi.subject_ranges if sd == "s" else fi.object_ranges)(Xi[c0:c0 + CH])
+                    flt = (torch.as_tensor(lo).to(dev), torch.as_tensor(hi).to(dev), flt_ids[sd])
+                eng.rank_side(xs, _ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, ranking_strategy, flt, ent_ids,
+                              subset_pos, out=ranks[c0:c0 + CH, col], out_stride=len(sides))
+        r = ranks.cpu().numpy()
+        if corrupt_side == "s+o":  # :1459-1463 sums the two 0-based sides, then +1 (:1684)
+            r = (r.sum(1, keepdims=True) - 1).astype(np.int32)
+        return r
+
+    # ------------------------------------------------------------------------------------ accessors
+    def is_fit(self):
+        return self.is_fitted
+
+    def get_indexes(self, X, type_of="t", order="raw2ind"):
+        return self.data_indexer.get_indexes(X, type_of, order)
+
+    def get_count(self, concept_type="e"):
+        assert self.is_fitted, "Model is not fit on the data yet!"
+        if concept_type == "e":
+            return self.data_indexer.get_entities_count()
+        if concept_type == "r":
+            return self.data_indexer.get_relations_count()
+        raise ValueError("Invalid Concept Type (expected 'e' or 'r')")
+
+    def get_train_embedding_matrix_size(self):
+        assert self.is_fitted, "Model is not fit on the data yet!"
+        return {"e": (self._engine.n_ents, self.internal_k), "r": (self._engine.n_rels, self.internal_k)}
+
+    def get_embeddings(self, entities, embedding_type="e"):
+        """:2214-2277."""
+        if embedding_type not in ("e", "r"):
+            raise ValueError("Invalid entity type: {}".format(embedding_type))
+        assert self.is_fitted, "Model is not fit on the data yet!"
+        idx = np.asarray(self.data_indexer.get_indexes(np.asarray(entities), embedding_type), dtype=np.int64)
+        import torch
+
+        tab = self._engine.ent if embedding_type == "e" else self._engine.rel
+        return tab[torch.as_tensor(idx).to(tab.device)].cpu().numpy()
+
+    # calibration is a "next" row; keep the reference's error for the uncalibrated case
+    def calibrate(self, *a, **kw):
+        raise NotImplementedError("calibrate(): Platt scaling is a 'next' row (SURVEY.md 8f)")
+
+    def predict_proba(self, *a, **kw):
+        if not self.is_calibrated:
+            raise RuntimeError("Model has not been calibrated. Please call `model.calibrate(...)` before predicting probabilities.")
+
+    # ------------------------------------------------------------------------------------ persistence
+    def save_weights(self, filepath):
+        """Own flat format (the reference writes a TF checkpoint, :1046-1071): <filepath>.npz holds tables,
+        optimizer slots and id maps; <filepath>.json the hyper-parameters."""
+        assert self.is_fitted, "Model is not fit on the data yet!"
+        ent, rel = self._engine.get_tables()
+        arrays = {"ent": ent, "rel": rel}
+        for kname, t in self._engine.slots.items():
+            arrays["slot_" + kname] = t.cpu().numpy()
+        st = self.data_indexer.state()
+        arrays["ent_raw"], arrays["rel_raw"] = st["ent_raw"], st["rel_raw"]
+        np.savez(filepath + ".npz", **arrays)
+        meta = {"eta": self.eta, "k": self.k, "scoring_type": self.scoring_type, "seed": self.seed,
+                "optimizer": self.optimizer.get_config() if self.is_compiled else None,
+                "iterations": self.optimizer.iterations if self.is_compiled else 0,
+                "loss": {"name": self.loss.name, "params": self.loss._loss_parameters} if self.is_compiled else None}
+        with open(filepath + ".json", "w") as f:
+            json.dump(meta, f)
+
+    def load_weights(self, filepath):
+        z = np.load(filepath + ".npz", allow_pickle=False)
+        self.data_indexer = DataIndexer.from_state({"ent_raw": z["ent_raw"], "rel_raw": z["rel_raw"]})
+        if not self.is_compiled:
+            self._initializers = ["zeros", "zeros"]
+        self._build(z["ent"].shape[0], z["rel"].shape[0])
+        self._engine.set_tables(z["ent"], z["rel"])
+        slots = {k[5:]: z[k] for k in z.files if k.startswith("slot_")}
+        if slots and self.is_compiled:
+            import torch
+
+            self._loop = StepLoop(self._engine, self.eta, self.loss, self.optimizer, self._regularizers[0],
+                                  self.seed, self._dist())
+            for kname, v in slots.items():
+                self._engine.slots[kname].copy_(torch.as_tensor(v))
+            if os.path.exists(filepath + ".json"):
+                self.optimizer.iterations = int(json.load(open(filepath + ".json")).get("iterations", 0))
+        self.is_fitted = True

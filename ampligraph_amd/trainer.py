@@ -1,0 +1,70 @@
+"""The training step loop shared by ScoringBasedEmbeddingModel.fit() and bench.py.
+
+One process drives one GPU (one `KgeEngine`).  With torch.distributed initialised the loop is data
+parallel over the positives of each *global* batch: tables and optimizer state are replicated, rank r
+takes the contiguous share [lo_r, hi_r) of the batch, the dense gradient buffers are summed with an
+all-reduce (RCCL over xGMI on GPUs; gloo in the CPU tests) and every rank applies the same dense
+optimizer sweep.  Negatives are drawn from a counter-based RNG indexed by the GLOBAL corruption row,
+so N ranks at batch B/N reproduce exactly the corruptions (and, up to fp32 summation order, the
+update) of one rank at batch B.  The reference has no multi-device path at all
+(/root/reference: no tf.distribute / NCCL / Horovod call sites); its step is
+ScoringBasedEmbeddingModel.train_step :370-429.
+"""
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous, balanced split of n rows over `world` ranks (first n % world ranks get one more)."""
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return lo, hi
+
+
+class StepLoop:
+    def __init__(self, engine, eta, loss, optimizer, regularizer=None, seed=0, dist=None):
+        """engine: KgeEngine-like backend; loss/optimizer: objects with .to_ffi(); dist: None or the
+        torch.distributed module (already initialised)."""
+        self.engine = engine
+        self.eta = int(eta)
+        self.loss_ffi = loss.to_ffi()
+        self.optimizer = optimizer
+        self.reg = regularizer
+        self.seed = int(seed)
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.n_steps = 0
+        engine.prepare_training(optimizer.name)
+
+    def step(self, global_batch, rng_step):
+        """global_batch: (Bg,3) int32 device tensor holding the WHOLE batch (same on every rank);
+        rng_step: the step counter the negatives are keyed by."""
+        eng = self.engine
+        bg = int(global_batch.shape[0])
+        lo, hi = shard_bounds(bg, self.world, self.rank)
+        if hi > lo:
+            eng.train_fwdbwd(global_batch[lo:hi], self.eta, self.loss_ffi, self.seed, rng_step,
+                             row_offset=lo, b_global=bg)
+        if self.world > 1:
+            for g in eng.grad_tensors():
+                self.dist.all_reduce(g)
+        self.optimizer.iterations += 1
+        lam = self.reg.lam if self.reg is not None else 0.0
+        eng.opt_step(self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2),
+                     lam, lam)
+        self.n_steps += 1
+
+    def reset_loss(self):
+        self.engine.loss_acc.zero_()
+        self.n_steps = 0
+
+    def mean_batch_loss(self):
+        """Keras Mean('loss') of the per-batch total loss (loss_functions.py:224): (sum over batches of
+        data loss + regulariser loss) / #batches.  The data loss is summed over ranks; the regulariser
+        term is identical on every rank (replicated tables) and counted once."""
+        acc = self.engine.loss_acc.clone()
+        if self.world > 1:
+            data = acc[0:1].clone()
+            self.dist.all_reduce(data)
+            acc[0] = data[0]
+        tot = float(acc[0].item()) + float(acc[1].item())
+        return tot / max(1, self.n_steps)

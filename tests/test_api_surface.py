@@ -1,0 +1,103 @@
+"""CPU-side checks of the drop-in surface: registries, defaults and error behaviour mirror the reference
+(loss_functions.py:720-766, optimizers.py:255-291, regularizers.py:40-73), and the C-ABI library loads
+and exports every symbol include/amdkge.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ampligraph_amd import _ffi
+
+    hdr = open(os.path.join(ROOT, "include", "amdkge.h")).read()
+    declared = set(re.findall(r"\b(amdkge_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _ffi.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/amdkge.h but not exported"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    assert lib.amdkge_abi_version() == 1
+    assert lib.amdkge_internal_k(2, 200) == 400 and lib.amdkge_internal_k(0, 50) == 50
+
+
+def test_abi_argument_validation_without_gpu():
+    """Error paths that return before touching the device work on a GPU-less box."""
+    from ampligraph_amd import _ffi
+
+    lib = _ffi.lib()
+    m = _ffi.Model(9, 10, 5, 5, 0, 0)
+    assert lib.amdkge_score(ctypes.byref(m), None, None, None, 1, None, None) == -1
+    assert b"scoring_type" in lib.amdkge_last_error()
+    m = _ffi.Model(2, 10, 5, 5, 0, 0)
+    assert lib.amdkge_score(ctypes.byref(m), None, None, None, 0, None, None) == 0       # empty input is a no-op
+    assert lib.amdkge_score(ctypes.byref(m), None, None, None, 3, None, None) == -1      # NULL pointers
+    assert lib.amdkge_rank_compose(None, None, 3, 7, None, 1, None) == -1                # unknown strategy
+    o = _ffi.Opt(2, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 0)
+    assert lib.amdkge_opt_step(ctypes.byref(o), None, None, None, None, 0, None, None) == 0
+    assert lib.amdkge_internal_k(7, 3) == -1
+
+
+def test_registries_and_defaults():
+    from ampligraph_amd.latent_features import loss_functions as lf
+    from ampligraph_amd.latent_features import optimizers, regularizers
+
+    assert set(lf.LOSS_REGISTRY) == {"pairwise", "nll", "absolute_margin", "self_adversarial", "multiclass_nll"}
+    assert lf.get("pairwise")._loss_parameters == {"reduction": "sum", "margin": 1}
+    sa = lf.get("self_adversarial")
+    assert sa._loss_parameters["margin"] == 3 and sa._loss_parameters["alpha"] == 0.5
+    assert lf.get("nll", {"reduction": "mean"}).to_ffi().reduction_mean == 1
+    with pytest.raises(ValueError):
+        lf.get("hinge")
+    with pytest.raises(AssertionError):
+        lf.get("nll", {"reduction": "median"})
+    with pytest.raises(NotImplementedError):
+        lf.get(lambda p, n: p)
+    o = optimizers.get("adam")
+    assert o.learning_rate == 0.001 and o.epsilon == 1e-7 and o.beta_1 == 0.9      # optimizers.py:284
+    assert optimizers.get("adam", {"learning_rate": 5e-3}).learning_rate == 5e-3
+    with pytest.raises(ValueError):
+        optimizers.get("lion")
+    with pytest.raises(ValueError):
+        optimizers.get(3.0)
+    r = regularizers.get("LP")
+    assert (r.p, r.lam) == (2, 1e-5)
+    assert regularizers.get("l3", {"lambda": 1e-3}).p == 3
+    assert regularizers.get(None) is None
+    with pytest.raises(ValueError):
+        regularizers.get("elastic")
+
+
+def test_model_surface_without_gpu():
+    import numpy as np
+
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel
+
+    with pytest.raises(KeyError):
+        ScoringBasedEmbeddingModel(eta=1, k=2, scoring_type="ConvE")
+    m = ScoringBasedEmbeddingModel(eta=5, k=10, scoring_type="RotatE")
+    assert m.internal_k == 20 and not m.is_fit()
+    with pytest.raises(AssertionError):   # RotatE forces GlorotUniform for relations (:1312-1315)
+        m.compile(optimizer="adam", loss="nll", entity_relation_initializer=["glorot_uniform", "random_normal"])
+    with pytest.raises(ValueError):
+        m.compile(optimizer="adam", loss="not-a-loss")
+    m.compile(optimizer="adam", loss="self_adversarial")
+    with pytest.raises(AssertionError):
+        m.get_count("e")
+    with pytest.raises(RuntimeError):
+        m.predict_proba(np.zeros((1, 3)))
+    with pytest.raises(NotImplementedError):
+        m.fit(np.array([["a", "b", "c"]]), partitioning_k=3)
+
+
+def test_product_has_no_oracle_or_cpu_fallback():
+    """The product package must never import the oracle (parity would be void)."""
+    pkg = os.path.join(ROOT, "ampligraph_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
