@@ -33,6 +33,7 @@ class StepLoop:
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
         self.n_steps = 0
+        self.kernel_hook = None   # bench.py: callable(phase) recording HIP events around the fused kernel
         engine.prepare_training(optimizer.name)
 
     def step(self, global_batch, rng_step):
@@ -41,9 +42,13 @@ class StepLoop:
         eng = self.engine
         bg = int(global_batch.shape[0])
         lo, hi = shard_bounds(bg, self.world, self.rank)
+        if self.kernel_hook is not None:
+            self.kernel_hook(0)
         if hi > lo:
             eng.train_fwdbwd(global_batch[lo:hi], self.eta, self.loss_ffi, self.seed, rng_step,
                              row_offset=lo, b_global=bg)
+        if self.kernel_hook is not None:
+            self.kernel_hook(1)
         if self.world > 1:
             for g in eng.grad_tensors():
                 self.dist.all_reduce(g)

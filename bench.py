@@ -52,17 +52,29 @@ def cpu_baseline(args, data, ent0, rel0):
     from oracle import ref_cpu
 
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    tr = ref_cpu.RefCpuTrainer(args.model, ent0, rel0, args.eta, args.loss, 1e-3, data["n_rels"])
     X = torch.as_tensor(data["train"].astype(np.int64))
     B = args.batch
-    tr.step(X[:B])  # warm-up (allocator, thread pool)
+    # torch's intra-op pool does not scale to hundreds of threads on this op mix: probe a few pool sizes
+    # with one step each and keep the fastest (threads actually used are reported as `cores`)
+    best = None
+    for th in sorted({min(cores, t) for t in (8, 16, 32, 64, cores)}):
+        torch.set_num_threads(th)
+        tr = ref_cpu.RefCpuTrainer(args.model, ent0, rel0, args.eta, args.loss, 1e-3, data["n_rels"])
+        tr.step(X[:B])  # warm-up (allocator, thread pool)
+        t0 = time.perf_counter()
+        tr.step(X[B:2 * B])
+        d1 = time.perf_counter() - t0
+        if best is None or d1 < best[0]:
+            best = (d1, th)
+    torch.set_num_threads(best[1])
+    tr = ref_cpu.RefCpuTrainer(args.model, ent0, rel0, args.eta, args.loss, 1e-3, data["n_rels"])
+    tr.step(X[:B])
     t0 = time.perf_counter()
     for s in range(1, args.cpu_steps + 1):
         tr.step(X[s * B:(s + 1) * B])
     dt = time.perf_counter() - t0
-    return {"value": args.cpu_steps * B * (1 + args.eta) / dt, "unit": "triples/s", "cores": cores,
-            "kind": "port", "threads": torch.get_num_threads(),
+    return {"value": args.cpu_steps * B * (1 + args.eta) / dt, "unit": "triples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "host_cores": cores,
             "sample": f"{args.cpu_steps} train steps of B={B} (after 1 warm-up step), same tables and triples; "
                       "oracle/ref_cpu.py = op-for-op torch-CPU restatement of the reference TF graph "
                       "(TensorFlow itself is not installable here)"}
@@ -123,6 +135,8 @@ def main():
     from ampligraph_amd import _ffi
     from ampligraph_amd.datasets import make_synthetic_kg
     from ampligraph_amd.engine import KgeEngine
+    from ampligraph_amd.latent_features import loss_functions, optimizers
+    from ampligraph_amd.trainer import StepLoop
 
     data = make_synthetic_kg(args.dataset, seed=0)
     N, R = data["n_ents"], data["n_rels"]
@@ -132,11 +146,11 @@ def main():
     ent0 = rng.uniform(-lim_e, lim_e, size=(N, eng.K)).astype(np.float32)  # Glorot uniform, same on every rank
     rel0 = rng.uniform(-lim_r, lim_r, size=(R, eng.K)).astype(np.float32)
     eng.set_tables(ent0, rel0)
-    eng.prepare_training("adam")
-    loss = _ffi.Loss(_ffi.LOSSES[args.loss], 0, 3.0 if args.loss == "self_adversarial" else 1.0, 0.5)
+    # the product's own step loop (what ScoringBasedEmbeddingModel.fit drives)
+    loop = StepLoop(eng, args.eta, loss_functions.get(args.loss), optimizers.get("adam"), None, seed=0, dist=dist)
 
     # the training set lives in HBM; a global batch is a contiguous slice (reference order: sequential,
-    # un-shuffled, graph_data_loader.py:472-523), each rank takes its B-row share of it
+    # un-shuffled, graph_data_loader.py:472-523); each rank takes its share of it inside StepLoop
     B = args.batch
     Bg = B * world
     train = torch.as_tensor(data["train"]).cuda()
@@ -144,49 +158,41 @@ def main():
     steps_per_epoch = max(1, n_train // Bg)
 
     def batch_of(step):
-        b0 = (step % steps_per_epoch) * Bg + rank * B
-        return train[b0:b0 + B]
+        b0 = (step % steps_per_epoch) * Bg
+        return train[b0:b0 + Bg]
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    cur = {"i": None}
 
-    def one_step(step, timed_idx=None):
-        xb = batch_of(step)
-        if timed_idx is not None:
-            ev[timed_idx][0].record()
-        eng.train_fwdbwd(xb, args.eta, loss, seed=0, step=step, row_offset=rank * B, b_global=Bg)
-        if timed_idx is not None:
-            ev[timed_idx][1].record()
-        if world > 1:
-            dist.all_reduce(eng.g_ent)
-            dist.all_reduce(eng.g_rel)
-        eng.opt_step(_ffi.Opt(_ffi.OPTIMIZERS["adam"], 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, step + 1))
+    def hook(phase):   # HIP events on the stream the kernel is launched on (torch's current stream)
+        if cur["i"] is not None:
+            ev[cur["i"]][phase].record()
 
+    loop.kernel_hook = hook
+    loop.reset_loss()
     for s in range(args.warmup):
-        one_step(s)
+        loop.step(batch_of(s), s)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        one_step(args.warmup + s, s)
+        cur["i"] = s
+        loop.step(batch_of(args.warmup + s), args.warmup + s)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    cur["i"] = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    loss_mean = loop.mean_batch_loss()
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
-    loss_mean = float(eng.loss_acc[0].item()) / max(1, args.warmup + args.steps)
-    if world > 1:
-        t = torch.tensor([loss_mean], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t)
-        loss_mean = float(t.item())
-
     if rank == 0:
         triples = float(world) * B * (1 + args.eta) * args.steps
         bytes_per_pos = 2.0 * (3 + args.eta) * 4.0 * eng.K   # each distinct row read once + its gradient written once

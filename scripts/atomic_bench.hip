@@ -63,9 +63,30 @@ float run(float* G, const int* rows, int nrows, int N, const char* name) {
     return ms;
 }
 
+static void flavors() {
+    const int nrows = 230000, N = 14505;
+    std::vector<int> h(nrows); srand(1);
+    for (auto& r : h) r = (int)(((unsigned)rand() * 2654435761u) % (unsigned)N);
+    int* rows; CK(hipMalloc(&rows, nrows * 4)); CK(hipMemcpy(rows, h.data(), nrows * 4, hipMemcpyHostToDevice));
+    struct { const char* name; unsigned flag; } fl[] = {{"hipDeviceMallocDefault", hipDeviceMallocDefault},
+        {"hipDeviceMallocFinegrained", hipDeviceMallocFinegrained}, {"hipDeviceMallocUncached", hipDeviceMallocUncached}};
+    for (auto& f : fl) {
+        float* G;
+        if (hipExtMallocWithFlags((void**)&G, (size_t)N * K * 4, f.flag) != hipSuccess) { printf("%s: alloc failed\n", f.name); continue; }
+        CK(hipMemset(G, 0, (size_t)N * K * 4));
+        printf("-- %s\n", f.name);
+        run<2>(G, rows, nrows, N, "2 f32 atomics, lane-contiguous");
+        run<7>(G, rows, nrows, N, "7 f64 atomics, contiguous");
+        run<4>(G, rows, nrows, N, "4 non-atomic RMW dword, contiguous");
+        CK(hipFree(G));
+    }
+    CK(hipFree(rows));
+}
+
 int main() {
+    flavors();
     const int nrows = 230000;
-    for (int N : {14505, 123182, 2000000}) {
+    for (int N : {14505}) {
         float* G; int* rows;
         CK(hipMalloc(&G, (size_t)N * K * 4)); CK(hipMemset(G, 0, (size_t)N * K * 4));
         std::vector<int> h(nrows); srand(1);

@@ -1,0 +1,94 @@
+"""N>1 path on CPU: world_size-2 gloo runs of the product's StepLoop (ampligraph_amd/trainer.py) with an
+oracle-backed engine.  Checks the sharding contract: 2 ranks at B/2 == 1 rank at B (same corruptions by
+construction, same update up to fp32 summation order), losses aggregate, ragged batches work."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    rng = np.random.default_rng(0)
+    N, R, k = 40, 3, 6
+    ent = (rng.normal(size=(N, 2 * k)) * 0.4).astype(np.float32)
+    rel = (rng.normal(size=(R, 2 * k)) * 0.4).astype(np.float32)
+    X = np.stack([rng.integers(0, N, 101), rng.integers(0, R, 101), rng.integers(0, N, 101)], 1).astype(np.int32)
+    return ent, rel, X, k
+
+
+def _run(world, rank, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleEngine
+
+    from ampligraph_amd.latent_features import loss_functions, optimizers, regularizers
+    from ampligraph_amd.trainer import StepLoop
+
+    d = None
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        d = dist
+    ent, rel, X, k = _problem()
+    eng = OracleEngine("ComplEx", k, ent, rel)
+    loop = StepLoop(eng, 3, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}),
+                    regularizers.get("LP", {"p": 2, "lambda": 1e-3}), seed=5, dist=d)
+    Xt = torch.as_tensor(X)
+    loop.reset_loss()
+    bs = 37   # ragged: batches of 37,37,27 and odd shard sizes
+    step = 0
+    for ep in range(2):
+        for b0 in range(0, X.shape[0], bs):
+            loop.step(Xt[b0:b0 + bs], step)
+            step += 1
+    loss = loop.mean_batch_loss()
+    if rank == 0:
+        np.savez(out, ent=eng.state.ent, rel=eng.state.rel, loss=loss, calls=np.array(eng.calls))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    from ampligraph_amd.trainer import shard_bounds
+
+    for n in (0, 1, 7, 10000, 10001):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_ranks_equal_one_rank(tmp_path):
+    single = str(tmp_path / "single.npz")
+    _run(1, 0, 0, single)
+    port = _free_port()
+    multi = str(tmp_path / "multi.npz")
+    mp.spawn(_run_spawn, args=(2, port, multi), nprocs=2, join=True)
+    a, b = np.load(single), np.load(multi)
+    assert np.abs(a["ent"] - b["ent"]).max() < 5e-6
+    assert np.abs(a["rel"] - b["rel"]).max() < 5e-6
+    assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5 * abs(float(a["loss"]))
+    # rank 0 of the 2-rank run processed the first half of every global batch with global RNG rows
+    calls = b["calls"]
+    assert (calls[:, 1] == 0).all() and set(calls[:, 2]) == {37, 27} and set(calls[:, 0]) == {18, 13}
+
+
+def _run_spawn(rank, world, port, out):
+    _run(world, rank, port, out)
