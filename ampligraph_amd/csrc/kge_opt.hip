@@ -4,47 +4,9 @@
 // third-party tensorflow==2.15 wheel, keras/optimizers/legacy/{adam,adagrad,gradient_descent}.py)
 // and LP_regularizer (regularizers.py:35-37).  Non-lazy like the reference: every row's slots
 // decay and every row moves each step.  HBM-bound: reads x,m,v,g and writes x,m,v,g(=0), 16 B/lane.
-#include "kge_host.h"
+#include "kge_opt.h"
 
 namespace kge {
-
-struct OptArgs {
-    float* x;
-    float* g;
-    float* s0;
-    float* s1;
-    int64_t n;
-    double* reg_loss;
-    float lr, lr_t, beta1, beta2, omb1, omb2, eps, lam;
-    int kind, reg_p;
-};
-
-__device__ __forceinline__ float ipowf(float a, int p) {
-    float r = 1.f;
-    for (int i = 0; i < p; ++i) r *= a;
-    return r;
-}
-
-template <int KIND>
-__device__ __forceinline__ void opt_elem(const OptArgs& a, float& x, float g, float& s0, float& s1, float& reg_acc) {
-    if (a.lam != 0.f) {
-        const float ax = fabsf(x);
-        // lambda * sum |x|^p ; d/dx = lambda * p * |x|^(p-1) * sign(x)
-        reg_acc += ipowf(ax, a.reg_p);
-        const float sg = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-        g += a.lam * (float)a.reg_p * ipowf(ax, a.reg_p - 1) * sg;
-    }
-    if constexpr (KIND == AMDKGE_OPT_ADAM) {
-        s0 = s0 * a.beta1 + g * a.omb1;
-        s1 = s1 * a.beta2 + (g * g) * a.omb2;
-        x -= (a.lr_t * s0) / (sqrtf(s1) + a.eps);
-    } else if constexpr (KIND == AMDKGE_OPT_ADAGRAD) {
-        s0 += g * g;
-        x -= a.lr * g / (sqrtf(s0) + a.eps);
-    } else {
-        x -= a.lr * g;
-    }
-}
 
 template <int KIND>
 __global__ __launch_bounds__(256) void opt_kernel(OptArgs a) {
@@ -95,25 +57,17 @@ using namespace kge;
 
 extern "C" int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_slot0, float* d_slot1,
                                int64_t n_elems, double* d_reg_loss, void* stream) {
-    if (!opt) return set_error(AMDKGE_EINVAL, "opt_step: NULL optimizer descriptor");
-    if (opt->kind < AMDKGE_OPT_SGD || opt->kind > AMDKGE_OPT_ADAM) return set_error(AMDKGE_EINVAL, "opt_step: unknown optimizer kind");
+    if (int rc = validate_opt(opt)) return rc;
     if (n_elems < 0) return set_error(AMDKGE_EINVAL, "opt_step: n_elems must be >= 0");
     if (n_elems == 0) return AMDKGE_OK;
     if (!d_x || !d_grad) return set_error(AMDKGE_EINVAL, "opt_step: NULL table / gradient pointer");
     if (opt->kind != AMDKGE_OPT_SGD && !d_slot0) return set_error(AMDKGE_EINVAL, "opt_step: optimizer slot 0 is NULL");
     if (opt->kind == AMDKGE_OPT_ADAM && !d_slot1) return set_error(AMDKGE_EINVAL, "opt_step: Adam slot 1 (v) is NULL");
-    if (opt->iteration < 1) return set_error(AMDKGE_EINVAL, "opt_step: iteration is 1-based");
-    if (opt->reg_lambda != 0.f && opt->reg_p < 1) return set_error(AMDKGE_EINVAL, "opt_step: regulariser p must be >= 1");
     if ((((uintptr_t)d_x | (uintptr_t)d_grad | (uintptr_t)d_slot0 | (uintptr_t)d_slot1) & 15) != 0)
         return set_error(AMDKGE_EINVAL, "opt_step: buffers must be 16-byte aligned");
     OptArgs a{};
     a.x = d_x; a.g = d_grad; a.s0 = d_slot0; a.s1 = d_slot1; a.n = n_elems; a.reg_loss = d_reg_loss;
-    a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->epsilon;
-    a.omb1 = (float)(1.0 - (double)opt->beta1);   // python: 1 - beta_1, cast to fp32 like the TF constant
-    a.omb2 = (float)(1.0 - (double)opt->beta2);
-    a.lam = opt->reg_lambda; a.kind = opt->kind; a.reg_p = opt->reg_p;
-    const double t = (double)opt->iteration;
-    a.lr_t = (float)((double)opt->lr * sqrt(1.0 - pow((double)opt->beta2, t)) / (1.0 - pow((double)opt->beta1, t)));
+    fill_opt_args(a, opt);
     const int64_t n4 = (n_elems + 3) / 4;
     unsigned grid = (unsigned)((n4 + 255) / 256);
     if (grid > 2048) grid = 2048;   // 256 CUs x 8 blocks, grid-stride beyond

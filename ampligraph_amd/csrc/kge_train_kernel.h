@@ -1,0 +1,453 @@
+// The fused forward(+backward) training kernel template, shared by the atomic-scatter path
+// (kge_train.hip) and the owner-computes path (kge_train_tiled.hip).  See kge_train.hip for the
+// description of the slot mapping.
+#pragma once
+#include "kge_device.h"
+#include "kge_host.h"
+
+namespace kge {
+
+// one row-gradient contribution, appended by the forward kernel to the bucket of the tile owning row `dest`
+struct __attribute__((aligned(16))) StageEntry {
+    uint32_t pos;    // positive (index into this launch's batch)
+    uint32_t meta;   // role | (row - first row of the tile) << 2 ; role 0/1 = corruption with object/subject replaced, 2/3 = the positive's own s/o row
+    float g;         // dL/dscore * score_sign * score_scale (1 for roles 2, 3)
+    uint32_t dest;   // global row id
+};
+
+struct TrainArgs {
+    const float* ent;
+    const float* rel;
+    const int32_t* triples;
+    const int32_t* neg_override;
+    float* g_ent;
+    float* g_rel;
+    double* loss_sum;
+    float* pos_scores;
+    float* neg_scores;
+    int64_t B;
+    int eta;
+    int k;       // user k (units per half for complex models)
+    int K;       // floats per row
+    int nq;      // quads per row ( = units / VEC )
+    SampleCfg sc;
+    ModelConst mc;
+    amdkge_loss loss;
+    // owner-computes (STAGE) outputs: see kge_train_tiled.hip
+    float* stage_rows;       // [B][4][K]: grad rows of s and o, then the two side rows A, B
+    StageEntry* st_lists;    // [n_tiles][cap] buckets of row-gradient entries, by owning tile
+    StageEntry* st_ovf;      // overflow of full buckets
+    int* st_counters;        // [(n_tiles + 1) * 32] bucket fill counts (128-byte stride), last = overflow count
+    int st_tile_rows, st_n_tiles, st_cap, st_ovf_cap;
+    int dbg;     // development ablation flags (env AMDKGE_DEBUG): 1 no neg-row atomics, 2 no s/p/o atomics, 4 no pass 2, 8 workgroup-scope atomics
+};
+
+__device__ __forceinline__ float log_sigmoid(float x) {
+    // -softplus(-x), stable on both tails
+    return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) {
+    return 1.f / (1.f + expf(-x));
+}
+
+// Loss.__call__ for one positive: neg scores in `sn[0..eta)` (LDS) are replaced by dL/dneg.
+// Returns per-sample loss and dL/dpos.  Executed by one whole wave (all lanes get the results).
+__device__ __forceinline__ void loss_and_dscore(const amdkge_loss& L, float P, float* sn, int eta, int lane,
+                                                float& per, float& dP) {
+    const float feta = (float)eta;
+    float red = L.reduction_mean ? feta : 1.f;
+    switch (L.kind) {
+        case AMDKGE_LOSS_PAIRWISE: {  // loss_functions.py:302-308
+            float acc = 0.f, cnt = 0.f;
+            for (int j = lane; j < eta; j += KGE_WAVE) {
+                const float h = L.margin - P + sn[j];
+                const bool act = h >= 0.f;
+                acc += fmaxf(h, 0.f);
+                cnt += act ? 1.f : 0.f;
+                sn[j] = act ? 1.f / red : 0.f;
+            }
+            per = wave_sum(acc) / red;
+            dP = -wave_sum(cnt) / red;
+        } break;
+        case AMDKGE_LOSS_NLL: {  // :376-382 (clip at :60-66)
+            if (L.reduction_mean) red = 2.f * feta;
+            const bool inP = (P >= -75.f) && (P <= 75.f);
+            const float Pc = fminf(fmaxf(P, -75.f), 75.f);
+            float acc = 0.f;
+            for (int j = lane; j < eta; j += KGE_WAVE) {
+                const float n = sn[j];
+                const bool in = (n >= -75.f) && (n <= 75.f);
+                const float nc = fminf(fmaxf(n, -75.f), 75.f);
+                acc += logf(1.f + expf(nc));
+                sn[j] = in ? sigmoidf(nc) / red : 0.f;
+            }
+            per = (feta * logf(1.f + expf(-Pc)) + wave_sum(acc)) / red;
+            dP = inP ? -feta * sigmoidf(-Pc) / red : 0.f;
+        } break;
+        case AMDKGE_LOSS_ABSOLUTE_MARGIN: {  // :458-464
+            float acc = 0.f;
+            for (int j = lane; j < eta; j += KGE_WAVE) {
+                const float h = L.margin + sn[j];
+                acc += fmaxf(h, 0.f);
+                sn[j] = (h >= 0.f) ? 1.f / red : 0.f;
+            }
+            per = (wave_sum(acc) - feta * P) / red;
+            dP = -feta / red;
+        } break;
+        case AMDKGE_LOSS_SELF_ADVERSARIAL: {  // :556-574 (softmax NOT stop-gradiented)
+            float mx = -INFINITY;
+            for (int j = lane; j < eta; j += KGE_WAVE) mx = fmaxf(mx, L.alpha * sn[j]);
+            mx = wave_max(mx);
+            float se = 0.f;
+            for (int j = lane; j < eta; j += KGE_WAVE) se += expf(L.alpha * sn[j] - mx);
+            se = wave_sum(se);
+            float lb = 0.f;
+            for (int j = lane; j < eta; j += KGE_WAVE) {
+                const float w = expf(L.alpha * sn[j] - mx) / se;
+                lb += w * log_sigmoid(-sn[j] - L.margin);
+            }
+            const float lbar = wave_sum(lb);
+            for (int j = lane; j < eta; j += KGE_WAVE) {
+                const float n = sn[j];
+                const float w = expf(L.alpha * n - mx) / se;
+                const float ell = log_sigmoid(-n - L.margin);
+                sn[j] = (w * sigmoidf(n + L.margin) - L.alpha * w * (ell - lbar)) / red;
+            }
+            per = -log_sigmoid(L.margin + P) - lbar / red;
+            dP = -sigmoidf(-(L.margin + P));
+        } break;
+        default: {  // AMDKGE_LOSS_MULTICLASS_NLL :647-654
+            const bool inP = (P >= -75.f) && (P <= 75.f);
+            const float eP = expf(fminf(fmaxf(P, -75.f), 75.f));
+            float acc = 0.f;
+            for (int j = lane; j < eta; j += KGE_WAVE) acc += expf(fminf(fmaxf(sn[j], -75.f), 75.f));
+            const float Z = wave_sum(acc) / red + eP;
+            for (int j = lane; j < eta; j += KGE_WAVE) {
+                const float n = sn[j];
+                const bool in = (n >= -75.f) && (n <= 75.f);
+                sn[j] = in ? expf(fminf(fmaxf(n, -75.f), 75.f)) / Z / red : 0.f;
+            }
+            per = -logf(eP / Z);
+            dP = inP ? -1.f + eP / Z : 0.f;
+        } break;
+    }
+}
+
+__host__ __device__ inline size_t slot_lds_bytes(int eta, int W) {
+    // neg[eta+1], repl[eta+1], keep[eta+1], part[W][eta+1] (W>1), rounded to 8 bytes
+    const size_t b = (size_t)(eta + 1) * (3 + (W > 1 ? W : 0)) * 4;
+    return (b + 7) & ~(size_t)7;
+}
+
+template <int W>
+__device__ __forceinline__ void slot_sync() {
+    if constexpr (W == 1) {
+        // single-wave slot: LDS ops of one wave complete in order; only stop compiler reordering
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+// LDS layout per slot: float neg[eta+1] (index eta = the positive); int repl[eta]; int keep[eta];
+// float part[W][eta+1] (W>1 only).  Tail of the block: double blockloss[SLOTS].
+template <int MODEL, int VEC, int W, int CH, bool STAGE = false>
+__global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
+    using T = ModelTraits<MODEL>;
+    constexpr int NC = T::NC;
+    constexpr int SLOTS = 4 / W;          // positives per 256-thread block
+    constexpr int TS = KGE_WAVE * W;      // threads per slot
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int slot = tid / TS;
+    const int ts = tid % TS;              // thread index inside the slot
+    const int lane = tid & 63;
+    const int wv = ts >> 6;               // wave index inside the slot
+    const int eta = a.eta;
+    const int64_t i_raw = (int64_t)blockIdx.x * SLOTS + slot;
+    const bool active = i_raw < a.B;
+    const int64_t i = active ? i_raw : (a.B - 1);  // tail slots recompute the last positive, write nothing
+
+    const int e1 = eta + 1;
+    const size_t per_slot = slot_lds_bytes(eta, W);
+    char* base = smem + (size_t)slot * per_slot;
+    float* sh_neg = reinterpret_cast<float*>(base);
+    int* sh_repl = reinterpret_cast<int*>(base + (size_t)e1 * 4);
+    int* sh_keep = reinterpret_cast<int*>(base + (size_t)e1 * 8);
+    float* sh_part = reinterpret_cast<float*>(base + (size_t)e1 * 12);
+    double* sh_loss = reinterpret_cast<double*>(smem + (size_t)SLOTS * per_slot);
+
+    const int ps = a.triples[3 * i + 0], pp = a.triples[3 * i + 1], po = a.triples[3 * i + 2];
+
+    // ---- negatives of this positive (a3) ------------------------------------------------------
+    for (int j = ts; j < eta; j += TS) {
+        int keep, repl;
+        if (a.neg_override) {
+            const int64_t r = (int64_t)j * a.B + i;
+            const int ns = a.neg_override[3 * r + 0], no = a.neg_override[3 * r + 2];
+            keep = (ns == ps) ? 1 : 0;
+            repl = keep ? no : ns;
+        } else {
+            draw_corruption(a.sc, i, j, keep, repl);
+        }
+        sh_keep[j] = keep;
+        sh_repl[j] = repl;
+    }
+
+    // ---- resident quads of s, p, o ------------------------------------------------------------
+    const float* rs = a.ent + (int64_t)ps * a.K;
+    const float* rp = a.rel + (int64_t)pp * a.K;
+    const float* ro = a.ent + (int64_t)po * a.K;
+    float s[CH][VEC][NC], p[CH][VEC][NC], o[CH][VEC][NC];
+    bool qok[CH];
+    int qoff[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int q = ts + c * TS;
+        qok[c] = q < a.nq;
+        qoff[c] = (qok[c] ? q : 0) * VEC;
+#pragma unroll
+        for (int h = 0; h < NC; ++h) {
+            const fvec<VEC> vs = ldg<VEC>(rs + qoff[c] + h * a.k);
+            const fvec<VEC> vp = ldg<VEC>(rp + qoff[c] + h * a.k);
+            const fvec<VEC> vo = ldg<VEC>(ro + qoff[c] + h * a.k);
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                s[c][u][h] = vs.v[u]; p[c][u][h] = vp.v[u]; o[c][u][h] = vo.v[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) prep_rel<MODEL>(a.mc, p[c][u]);
+    }
+    if constexpr (STAGE) {
+        // side rows for the owner kernel.  Trilinear models: d(score)/d(replaced row) does not depend on the
+        // replaced row, so the owner only needs g * A (A = d/do (s,p)) or g * B (B = d/ds (p,o)).
+        // TransE / RotatE: copies of s and o (the owner recomputes grad_unit with its own row).
+        static_assert(!STAGE || VEC == 4, "staging uses the 16-byte layout");
+        constexpr bool TRILINEAR = (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
+        if (active) {
+            float* qa = a.stage_rows + ((int64_t)i * 4 + 2) * a.K;
+            float* qb = a.stage_rows + ((int64_t)i * 4 + 3) * a.K;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (!qok[c]) continue;
+                float va[NC][4], vb[NC][4];
+#pragma unroll
+                for (int u = 0; u < VEC; ++u) {
+                    if constexpr (TRILINEAR) {
+                        float ds[NC], dp[NC], dd[NC];
+                        grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], 1.f, ds, dp, dd);
+#pragma unroll
+                        for (int h = 0; h < NC; ++h) { va[h][u] = dd[h]; vb[h][u] = ds[h]; }
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < NC; ++h) { va[h][u] = s[c][u][h]; vb[h][u] = o[c][u][h]; }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < NC; ++h) {
+                    *reinterpret_cast<float4*>(qa + qoff[c] + h * a.k) = make_float4(va[h][0], va[h][1], va[h][2], va[h][3]);
+                    *reinterpret_cast<float4*>(qb + qoff[c] + h * a.k) = make_float4(vb[h][0], vb[h][1], vb[h][2], vb[h][3]);
+                }
+            }
+        }
+    }
+    slot_sync<W>();
+
+    const float sgn_scale = a.mc.score_sign * a.mc.score_scale;
+
+    // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
+    for (int j = -1; j < eta; ++j) {
+        const int keep = (j < 0) ? 1 : sh_keep[j];
+        const int64_t er = (j < 0) ? (int64_t)po : (int64_t)sh_repl[j];
+        const float* re = a.ent + er * a.K;
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            float e[VEC][NC];
+#pragma unroll
+            for (int h = 0; h < NC; ++h) {
+                const fvec<VEC> ve = ldg<VEC>(re + qoff[c] + h * a.k);
+#pragma unroll
+                for (int u = 0; u < VEC; ++u) e[u][h] = ve.v[u];
+            }
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < VEC; ++u)
+                acc += keep ? score_unit<MODEL>(s[c][u], p[c][u], e[u]) : score_unit<MODEL>(e[u], p[c][u], o[c][u]);
+            part += qok[c] ? acc : 0.f;
+        }
+        const float tot = wave_sum(part);
+        const int jj = (j < 0) ? eta : j;
+        if constexpr (W > 1) {
+            if (lane == 0) sh_part[wv * e1 + jj] = tot;   // cross-wave hop, summed after the loop
+        } else {
+            // reference rounding: reduce_sum, then negate (TransE/RotatE) or scale (HolE)
+            if (lane == 0) sh_neg[jj] = sgn_scale * tot;
+        }
+    }
+    if constexpr (W > 1) {
+        __syncthreads();
+        for (int j = ts; j < e1; j += TS) {
+            float t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) t2 += sh_part[w * e1 + j];
+            sh_neg[j] = sgn_scale * t2;
+        }
+    }
+    slot_sync<W>();
+    const float P = sh_neg[eta];
+
+    if (active && a.neg_scores)
+        for (int j = ts; j < eta; j += TS) a.neg_scores[(int64_t)j * a.B + i] = sh_neg[j];
+    if (active && a.pos_scores && ts == 0) a.pos_scores[i] = P;
+    if constexpr (W > 1) __syncthreads();  // sh_neg is rewritten below by wave 0
+
+    // ---- loss + dL/dscore (a12-a16): wave 0 of the slot, results through LDS -------------------
+    float per = 0.f, dP = 0.f;
+    if (W == 1 || wv == 0) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP);
+    if constexpr (W > 1) {
+        if (wv == 0 && lane == 0) sh_part[0] = dP;
+        __syncthreads();
+        dP = sh_part[0];
+    } else {
+        slot_sync<W>();
+    }
+    if (ts == 0) sh_loss[slot] = active ? (double)per : 0.0;
+    if constexpr (STAGE) {
+        // one entry per row gradient that lands in the entity table, into the bucket of the owning tile
+        if (active)
+            for (int j = ts; j < eta + 2; j += TS) {
+                uint32_t dest, role;
+                float g;
+                if (j < eta) { dest = (uint32_t)sh_repl[j]; role = sh_keep[j] ? 0u : 1u; g = sh_neg[j] * sgn_scale; }
+                else { dest = (uint32_t)(j == eta ? ps : po); role = (j == eta) ? 2u : 3u; g = 1.f; }
+                if (g == 0.f) continue;   // inactive margin / clipped corruption: contributes nothing
+                const uint32_t tile = dest / (uint32_t)a.st_tile_rows;
+                StageEntry en{(uint32_t)i, role | ((dest - tile * (uint32_t)a.st_tile_rows) << 2), g, dest};
+                const int slotpos = atomicAdd(a.st_counters + (size_t)tile * 32, 1);
+                if (slotpos < a.st_cap) {
+                    a.st_lists[(size_t)tile * a.st_cap + slotpos] = en;
+                } else {
+                    const int op = atomicAdd(a.st_counters + (size_t)a.st_n_tiles * 32, 1);
+                    if (op < a.st_ovf_cap) a.st_ovf[op] = en;
+                }
+            }
+    }
+
+    // ---- pass 2: gradients -------------------------------------------------------------------
+    float gs[CH][VEC][NC], gp[CH][VEC][NC], go[CH][VEC][NC];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+            float ds[NC], dp[NC], dd[NC];
+            grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], dP * sgn_scale, ds, dp, dd);
+#pragma unroll
+            for (int h = 0; h < NC; ++h) { gs[c][u][h] = ds[h]; gp[c][u][h] = dp[h]; go[c][u][h] = dd[h]; }
+        }
+
+    // Row-gradient emit.  fp32 atomics retire per 128-byte line (measured ~10.4 G line-ops/s on MI355X,
+    // scripts/atomic_bench.hip), so every atomic wave-instruction must cover 64 CONSECUTIVE floats.
+    // VEC == 1: the lane's units already are consecutive across lanes.  VEC == 4 (16-byte loads): the row
+    // is transposed through a per-wave LDS staging row (ds_write_b128 -> ds_read_b32) first.
+    float* stage = reinterpret_cast<float*>(smem + (size_t)SLOTS * per_slot + SLOTS * sizeof(double)) + (size_t)(tid >> 6) * a.K;
+    auto emit_row = [&](float* grow, const float (&gr)[CH][VEC][NC], int nfloats, float mul) {
+        if constexpr (VEC == 1) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int h = 0; h < NC; ++h)
+                    if (qok[c] && qoff[c] + h * a.k < nfloats) atomic_add_f32(grow + qoff[c] + h * a.k, gr[c][0][h] * mul);
+        } else {
+            static_assert(VEC == 1 || W == 1, "LDS-transposed emit is per wave");
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int h = 0; h < NC; ++h)
+                    if (qok[c])
+                        *reinterpret_cast<float4*>(stage + qoff[c] + h * a.k) =
+                            make_float4(gr[c][0][h] * mul, gr[c][1][h] * mul, gr[c][2][h] * mul, gr[c][3][h] * mul);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int idx = lane; idx < nfloats; idx += KGE_WAVE) atomic_add_f32(grow + idx, stage[idx]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    const bool do_neg_atomics = active && !(a.dbg & 1);
+    for (int j = 0; j < ((a.dbg & 4) ? 0 : eta); ++j) {
+        const int keep = sh_keep[j];
+        const int64_t er = (int64_t)sh_repl[j];
+        const float g = sh_neg[j] * sgn_scale;
+        const float* re = a.ent + er * a.K;
+        float gr[CH][VEC][NC];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            float e[VEC][NC];
+#pragma unroll
+            for (int h = 0; h < NC; ++h) {
+                const fvec<VEC> ve = ldg<VEC>(re + qoff[c] + h * a.k);
+#pragma unroll
+                for (int u = 0; u < VEC; ++u) e[u][h] = ve.v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                float ds[NC], dp[NC], dd[NC];
+                if (keep) {   // (s, p, e): object replaced
+                    grad_unit<MODEL>(s[c][u], p[c][u], e[u], g, ds, dp, dd);
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) { gs[c][u][h] += ds[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = dd[h]; }
+                } else {      // (e, p, o): subject replaced
+                    grad_unit<MODEL>(e[u], p[c][u], o[c][u], g, ds, dp, dd);
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) { go[c][u][h] += dd[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = ds[h]; }
+                }
+            }
+        }
+        if constexpr (!STAGE) { if (do_neg_atomics) emit_row(a.g_ent + er * a.K, gr, a.K, 1.f); }
+    }
+
+    // ---- per-block loss: one fp64 atomic -------------------------------------------------------
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) t += sh_loss[q];
+        atomicAdd(a.loss_sum, t);
+    }
+
+    // ---- resident rows: one atomic row-add each, or (STAGE) plain 16-byte stores for the owner kernel ----
+    if constexpr (STAGE) {
+        if (active) {
+            float* ps_ = a.stage_rows + ((int64_t)i * 4 + 0) * a.K;
+            float* po_ = a.stage_rows + ((int64_t)i * 4 + 1) * a.K;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (!qok[c]) continue;
+#pragma unroll
+                for (int h = 0; h < NC; ++h) {
+                    *reinterpret_cast<float4*>(ps_ + qoff[c] + h * a.k) = make_float4(gs[c][0][h], gs[c][1][h], gs[c][2][h], gs[c][3][h]);
+                    *reinterpret_cast<float4*>(po_ + qoff[c] + h * a.k) = make_float4(go[c][0][h], go[c][1][h], go[c][2][h], go[c][3][h]);
+                }
+            }
+            // relation rows: few and hot -> atomic row-add into the dense relation gradient (swept by kge_opt.hip)
+            if constexpr (MODEL == AMDKGE_ROTATE) emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.k, 1.f / a.mc.phase_div);
+            else emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.K, 1.f);
+        }
+    } else if (active && !(a.dbg & 2)) {
+        emit_row(a.g_ent + (int64_t)ps * a.K, gs, a.K, 1.f);
+        emit_row(a.g_ent + (int64_t)po * a.K, go, a.K, 1.f);
+        if constexpr (MODEL == AMDKGE_ROTATE) {
+            // d/dtheta = d/dphi / phase_div ; the second half of the relation row gets no gradient
+            emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.k, 1.f / a.mc.phase_div);
+        } else {
+            emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.K, 1.f);
+        }
+    }
+}
+
+}  // namespace kge

@@ -1,0 +1,375 @@
+// Owner-computes training step for gfx950 (no global atomics on the entity table).
+//
+// Why: on MI355X `global_atomic_add_f32` retires ~10.4 G cache-line operations/s chip-wide whatever the
+// line's occupancy (scripts/atomic_bench.hip), which floors the atomic gradient scatter of
+// kge_train.hip at 230 000 rows x 12.5 lines = 0.28 ms per C2 step, 3x the HBM time of the same bytes.
+//
+// How: two kernels per step.
+//   F  train_fwdbwd_kernel<.., STAGE=true> (kge_train_kernel.h): the fused forward + loss + per-positive
+//      backward.  Instead of scattering replacement-row gradients it APPENDS one 16-byte entry
+//      {positive, role|local row, dL/dscore, row id} per corruption (and one per s / o row of the positive) to
+//      the bucket of the table TILE that owns the destination row (one returning atomic per entry on a
+//      128-byte-strided counter; full buckets spill to one shared overflow list), and stores per positive
+//      four K-float rows with plain 16-byte coalesced stores: the complete gradient rows of its own s and o,
+//      and two "side" rows A, B (trilinear models: A = d score/d o (s,p), B = d score/d s (p,o), which do not
+//      depend on the replaced row; TransE / RotatE: copies of the s and o rows as read by the forward pass).
+//      The relation-row gradient (237 hot rows at C2) keeps the atomic row-add into the dense relation
+//      gradient buffer, which the ordinary sweep (kge_opt.hip) consumes.
+//   T  tile_backward_kernel (this file): one workgroup OWNS a tile of entity rows and keeps their gradient
+//      accumulators in LDS (<= 150 KB).  It walks its bucket (+ the overflow list), adds g * A|B (trilinear)
+//      or grad_unit(side row, live relation row, own live row) (TransE, RotatE) with LDS atomics
+//      (ds_add_f32), and finally applies the optimizer + regulariser to its rows straight from LDS: the
+//      entity gradient never exists in HBM and the entity table needs no separate optimizer sweep.
+//      The side rows are staged copies because other tiles update their rows in place while this one
+//      is still reading.
+//
+// Replaces the same reference code as kge_train.hip + kge_opt.hip: ScoringBasedEmbeddingModel.train_step
+// (/root/reference/ampligraph/latent_features/models/ScoringBasedEmbeddingModel.py:370-429) including
+// optimizer.minimize (optimizers.py:136-168) and the LP regulariser (regularizers.py:35-37).
+#include <stdlib.h>
+
+#include "kge_opt.h"
+#include "kge_train_kernel.h"
+
+namespace kge {
+
+constexpr int TILE_THREADS = 1024;
+constexpr int TILE_WAVES = TILE_THREADS / 64;
+
+struct TileArgs {
+    float* x;                 // entity table (updated in place when g_out == NULL)
+    float* s0;                // optimizer slots
+    float* s1;
+    float* g_out;             // NULL, or dense gradient buffer that RECEIVES (=) the tile sums
+    const float* rel;         // live relation table (TransE / RotatE side of the gradient)
+    const int32_t* triples;
+    const float* stage_rows;  // [B][4][K]
+    const StageEntry* lists;  // [n_tiles][cap]
+    const StageEntry* ovf;    // overflow entries
+    const int* counters;      // [(n_tiles + 1) * 32]; the last one counts the overflow list
+    double* reg_loss;
+    int64_t n_rows;
+    int k, K, nq;
+    int tile_rows, n_tiles, cap, ovf_cap;
+    ModelConst mc;
+    OptArgs opt;
+};
+
+// LDS accumulators: [tile_rows][K] in table layout.  ds_add_f32 turned out to be far too slow for this
+// (measured 0.49 ms for the C2 tile pass: ~3.4 clocks per LDS float atomic per CU), so rows are PARTITIONED
+// over the waves of the workgroup instead (local row % TILE_WAVES) and every wave updates its own rows with
+// plain 16-byte LDS read-modify-writes; all waves scan the tile's whole bucket and pick their entries with a
+// ballot.
+template <int MODEL, int CH, int UNROLL>
+__global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a) {
+    using T = ModelTraits<MODEL>;
+    constexpr int NC = T::NC;
+    constexpr bool TRILINEAR = (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* acc = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = blockIdx.x;
+    const int64_t t0 = (int64_t)tile * a.tile_rows;
+    const int64_t t1 = min(a.n_rows, t0 + a.tile_rows);
+    const int nrow = (int)(t1 - t0);
+
+    // a wave zeroes the rows it owns: no workgroup barrier is needed anywhere in this kernel
+    bool qok[CH];
+    int qoff[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        qok[c] = q < a.nq;
+        qoff[c] = (qok[c] ? q : 0) * 4;
+    }
+    for (int r = wv; r < nrow; r += TILE_WAVES)
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int h = 0; h < NC; ++h)
+                if (qok[c]) *reinterpret_cast<float4*>(acc + (size_t)r * a.K + qoff[c] + h * a.k) = make_float4(0, 0, 0, 0);
+
+    // side-row loads of one staged entry.  All arguments are wave-uniform.
+    auto load_side = [&](uint32_t pos, uint32_t meta, float4 (&v)[CH][NC]) {
+        const int role = meta & 3;   // 0: corruption, object replaced; 1: corruption, subject replaced; 2: own s row; 3: own o row
+        const int which = (role == 0) ? 2 : (role == 1) ? 3 : (role == 2) ? 0 : 1;
+        const float* src = a.stage_rows + ((int64_t)pos * 4 + which) * a.K;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int h = 0; h < NC; ++h) v[c][h] = *reinterpret_cast<const float4*>(src + qoff[c] + h * a.k);
+    };
+    auto add_entry = [&](uint32_t pos, uint32_t meta, float g, const float4 (&v)[CH][NC]) {
+        const int role = meta & 3;
+        const int lr = (int)(meta >> 2);
+        float* arow = acc + (size_t)lr * a.K;
+        float4 out[CH][NC];
+        if (TRILINEAR || role >= 2) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int h = 0; h < NC; ++h) out[c][h] = make_float4(g * v[c][h].x, g * v[c][h].y, g * v[c][h].z, g * v[c][h].w);
+        } else {
+            // TransE / RotatE: the gradient w.r.t. the replaced row depends on that row -> same grad_unit
+            // arithmetic as the atomic path, on (side row copy, live relation row, own live row)
+            const int pp = a.triples[3 * (int64_t)pos + 1];
+            const float* rp = a.rel + (int64_t)pp * a.K;
+            const float* re = a.x + (t0 + lr) * a.K;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                float4 pv[NC], ev[NC];
+#pragma unroll
+                for (int h = 0; h < NC; ++h) {
+                    pv[h] = *reinterpret_cast<const float4*>(rp + qoff[c] + h * a.k);
+                    ev[h] = *reinterpret_cast<const float4*>(re + qoff[c] + h * a.k);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float p[NC], e[NC], sd[NC], ds[NC], dp[NC], dd[NC];
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) {
+                        p[h] = (&pv[h].x)[u]; e[h] = (&ev[h].x)[u]; sd[h] = (&v[c][h].x)[u];
+                    }
+                    prep_rel<MODEL>(a.mc, p);
+                    if (role == 0) grad_unit<MODEL>(sd, p, e, g, ds, dp, dd);
+                    else grad_unit<MODEL>(e, p, sd, g, ds, dp, dd);
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) (&out[c][h].x)[u] = (role == 0) ? dd[h] : ds[h];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (!qok[c]) continue;
+#pragma unroll
+            for (int h = 0; h < NC; ++h) {
+                float4* d = reinterpret_cast<float4*>(arow + qoff[c] + h * a.k);
+                float4 t = *d;
+                t.x += out[c][h].x; t.y += out[c][h].y; t.z += out[c][h].z; t.w += out[c][h].w;
+                *d = t;
+            }
+        }
+    };
+    // entries of `mine` selected by `mask`, UNROLL at a time so that the side-row loads of several entries are in flight
+    auto process = [&](const StageEntry& mine, unsigned long long mask) {
+        while (mask) {
+            uint32_t pos[UNROLL], meta[UNROLL];
+            float g[UNROLL];
+            float4 v[UNROLL][CH][NC];
+            int m = 0;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (mask) {
+                    const int tt = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    pos[u] = __builtin_amdgcn_readlane(mine.pos, tt);
+                    meta[u] = __builtin_amdgcn_readlane(mine.meta, tt);
+                    g[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.g), tt));
+                    load_side(pos[u], meta[u], v[u]);
+                    m = u + 1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                if (u < m) add_entry(pos[u], meta[u], g[u], v[u]);
+        }
+    };
+
+    // ---- this tile's bucket: every wave walks all of it, 64 entries per coalesced 16-byte load ----
+    const int cnt = min(a.counters[tile * 32], a.cap);
+    const StageEntry* list = a.lists + (size_t)tile * a.cap;
+    for (int base = 0; base < cnt; base += 64) {
+        StageEntry mine{0u, 0u, 0.f, 0u};
+        const bool in = base + lane < cnt;
+        if (in) mine = list[base + lane];
+        process(mine, __ballot(in && (int)((mine.meta >> 2) % TILE_WAVES) == wv));
+    }
+    // ---- overflow list (entries of buckets that were full): every tile filters all of it ----
+    const int on = min(a.counters[a.n_tiles * 32], a.ovf_cap);
+    for (int base = 0; base < on; base += 64) {
+        StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
+        if (base + lane < on) mine = a.ovf[base + lane];
+        const bool hit = (int64_t)mine.dest >= t0 && (int64_t)mine.dest < t1;
+        process(mine, __ballot(hit && (int)((mine.meta >> 2) % TILE_WAVES) == wv));
+    }
+
+    // ---- flush: the tile's rows leave LDS exactly once ------------------------------------------------
+    float reg_acc = 0.f;
+    for (int r = wv; r < nrow; r += TILE_WAVES) {
+        const float* arow = acc + (size_t)r * a.K;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (!qok[c]) continue;
+#pragma unroll
+            for (int h = 0; h < NC; ++h) {
+                float4 g = *reinterpret_cast<const float4*>(arow + qoff[c] + h * a.k);
+                const int64_t off = (t0 + r) * a.K + qoff[c] + h * a.k;
+                if (a.g_out) {
+                    *reinterpret_cast<float4*>(a.g_out + off) = g;
+                    continue;
+                }
+                float4* xp = reinterpret_cast<float4*>(a.x + off);
+                float4 x = *xp, m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
+                if (a.opt.kind == AMDKGE_OPT_ADAM) {
+                    m = *reinterpret_cast<float4*>(a.s0 + off);
+                    v = *reinterpret_cast<float4*>(a.s1 + off);
+                    opt_elem<AMDKGE_OPT_ADAM>(a.opt, x.x, g.x, m.x, v.x, reg_acc); opt_elem<AMDKGE_OPT_ADAM>(a.opt, x.y, g.y, m.y, v.y, reg_acc);
+                    opt_elem<AMDKGE_OPT_ADAM>(a.opt, x.z, g.z, m.z, v.z, reg_acc); opt_elem<AMDKGE_OPT_ADAM>(a.opt, x.w, g.w, m.w, v.w, reg_acc);
+                    *reinterpret_cast<float4*>(a.s0 + off) = m;
+                    *reinterpret_cast<float4*>(a.s1 + off) = v;
+                } else if (a.opt.kind == AMDKGE_OPT_ADAGRAD) {
+                    m = *reinterpret_cast<float4*>(a.s0 + off);
+                    opt_elem<AMDKGE_OPT_ADAGRAD>(a.opt, x.x, g.x, m.x, v.x, reg_acc); opt_elem<AMDKGE_OPT_ADAGRAD>(a.opt, x.y, g.y, m.y, v.y, reg_acc);
+                    opt_elem<AMDKGE_OPT_ADAGRAD>(a.opt, x.z, g.z, m.z, v.z, reg_acc); opt_elem<AMDKGE_OPT_ADAGRAD>(a.opt, x.w, g.w, m.w, v.w, reg_acc);
+                    *reinterpret_cast<float4*>(a.s0 + off) = m;
+                } else {
+                    opt_elem<AMDKGE_OPT_SGD>(a.opt, x.x, g.x, m.x, v.x, reg_acc); opt_elem<AMDKGE_OPT_SGD>(a.opt, x.y, g.y, m.y, v.y, reg_acc);
+                    opt_elem<AMDKGE_OPT_SGD>(a.opt, x.z, g.z, m.z, v.z, reg_acc); opt_elem<AMDKGE_OPT_SGD>(a.opt, x.w, g.w, m.w, v.w, reg_acc);
+                }
+                *xp = x;
+            }
+        }
+    }
+    if (!a.g_out && a.reg_loss && a.opt.lam != 0.f) {
+        const float w = wave_sum(reg_acc);
+        if (lane == 0) atomicAdd(a.reg_loss, (double)a.opt.lam * (double)w);
+    }
+}
+
+// ---- plan: tile size, bucket capacity and workspace layout (shared by the two entry points) ------------------
+struct TiledPlan {
+    int tile_rows, n_tiles, cap, ovf_cap;
+    size_t off_cnt, off_lists, off_ovf, off_rows, total;
+};
+
+// rows per tile: as many as fit the LDS budget, then shrunk so that the tiles fill whole waves of 256 CUs evenly
+static int pick_tile_rows(int64_t n_rows, int K) {
+    const size_t budget = 150 * 1024;
+    int fit = (int)(budget / ((size_t)K * 4));
+    if (fit < 1) return 0;
+    if (fit > 4096) fit = 4096;
+    for (int64_t m = 1;; ++m) {   // smallest number of block waves m whose tile size fits
+        const int64_t r = (n_rows + 256 * m - 1) / (256 * m);
+        if (r <= fit) return (int)(r < 1 ? 1 : r);
+    }
+}
+
+static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p) {
+    const int K = internal_k_of(m->scoring_type, m->k);
+    if (m->k % 4 != 0 || m->k > 512) return false;   // 16-byte layout, one wave per positive, <= 2 quads per lane
+    if ((size_t)4 * slot_lds_bytes(eta, 1) + 32 + 16 * (size_t)K > 64 * 1024) return false;
+    p.tile_rows = pick_tile_rows(m->n_ents, K);
+    if (p.tile_rows < 1) return false;
+    p.n_tiles = (int)((m->n_ents + p.tile_rows - 1) / p.tile_rows);
+    const int64_t entries = B * (eta + 2);
+    if (entries >= (1ll << 31)) return false;
+    p.cap = (int)(2 * ((entries + p.n_tiles - 1) / p.n_tiles) + 256);
+    p.ovf_cap = (int)(entries > 0 ? entries : 1);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    p.off_cnt = o; o += up((size_t)(p.n_tiles + 1) * 32 * 4);
+    p.off_lists = o; o += up((size_t)p.n_tiles * p.cap * sizeof(StageEntry));
+    p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
+    p.off_rows = o; o += up((size_t)B * 4 * K * 4);
+    p.total = o + 256;
+    return true;
+}
+
+template <int MODEL, int CH, int UNROLL>
+static int launch_tile(const TileArgs& a, size_t shmem, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)tile_backward_kernel<MODEL, CH, UNROLL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+            return set_error_hip(e, "hipFuncSetAttribute(tile_backward)");
+        attr = true;
+    }
+    hipLaunchKernelGGL((tile_backward_kernel<MODEL, CH, UNROLL>), dim3(a.n_tiles), dim3(TILE_THREADS), shmem, st, a);
+    return check_launch("tile_backward");
+}
+
+template <int MODEL>
+static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
+    constexpr bool TRILINEAR = (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
+    constexpr int U = TRILINEAR ? 8 : 4;   // entries in flight per wave
+    const int CH = f.nq <= 64 ? 1 : 2;
+    // F: forward + staging
+    const size_t shmem_f = 4 * slot_lds_bytes(f.eta, 1) + 4 * sizeof(double) + 4 * (size_t)f.K * 4;
+    const unsigned grid_f = (unsigned)((f.B + 3) / 4);
+    if (grid_f == 0) {}
+    else if (CH == 1) hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, 4, 1, 1, true>), dim3(grid_f), dim3(256), shmem_f, st, f);
+    else hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, 4, 1, 2, true>), dim3(grid_f), dim3(256), shmem_f, st, f);
+    if (int rc = check_launch("train_forward_stage")) return rc;
+    // T: entity tiles (the owner applies the optimizer)
+    const size_t shmem_t = (size_t)te.tile_rows * te.K * 4;
+    if (CH == 1) return launch_tile<MODEL, 1, U>(te, shmem_t, st);
+    return launch_tile<MODEL, 2, (TRILINEAR ? 4 : 2)>(te, shmem_t, st);
+}
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta) {
+    if (validate_model(m) != AMDKGE_OK || B < 0 || B >= (1ll << 30) || eta < 1) return -1;
+    TiledPlan p;
+    if (!make_plan(m, B, eta, p)) return 0;   // 0 = shape not supported by the owner-computes path
+    return (int64_t)p.total;
+}
+
+extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, const amdkge_opt* opt,
+                                       float* d_ent, const float* d_rel, float* d_ent_slot0, float* d_ent_slot1,
+                                       const int32_t* d_triples, int64_t B, int32_t eta, int64_t sample_base,
+                                       int64_t sample_range, uint64_t seed, uint64_t step, int64_t row_offset,
+                                       int64_t b_global, const int32_t* d_neg_override, float* d_grad_ent,
+                                       float* d_grad_rel, double* d_loss_sum, double* d_reg_loss, float* d_pos_scores,
+                                       float* d_neg_scores, void* d_work, void* stream) {
+    if (int rc = validate_model(m)) return rc;
+    if (int rc = validate_opt(opt)) return rc;
+    if (!loss || loss->kind < 0 || loss->kind > AMDKGE_LOSS_MULTICLASS_NLL) return set_error(AMDKGE_EINVAL, "train_step_tiled: unknown loss kind");
+    if (!d_ent || !d_rel || !d_grad_rel || !d_loss_sum || !d_work) return set_error(AMDKGE_EINVAL, "train_step_tiled: NULL pointer");
+    if (B < 0 || B >= (1ll << 30) || eta < 1) return set_error(AMDKGE_EINVAL, "train_step_tiled: B must be in [0, 2^30) and eta >= 1");
+    TiledPlan p;
+    if (!make_plan(m, B, eta, p))
+        return set_error(AMDKGE_EUNSUPPORTED, "train_step_tiled: shape not supported (k % 4 != 0, k > 512 or eta too large); use amdkge_train_fwdbwd + amdkge_opt_step");
+    if (!d_grad_ent) {
+        if (opt->kind != AMDKGE_OPT_SGD && !d_ent_slot0) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 0 is NULL");
+        if (opt->kind == AMDKGE_OPT_ADAM && !d_ent_slot1) return set_error(AMDKGE_EINVAL, "train_step_tiled: Adam slot 1 (v) is NULL");
+    }
+    if (B > 0 && !d_triples) return set_error(AMDKGE_EINVAL, "train_step_tiled: null triples");
+    if (!d_neg_override && (sample_range <= 0 || sample_range > 0xFFFFFFFFll || sample_base < 0 || sample_base + sample_range > m->n_ents))
+        return set_error(AMDKGE_EINVAL, "train_step_tiled: sampling range outside the entity table");
+    const int K = internal_k_of(m->scoring_type, m->k);
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    int* counters = (int*)(w + p.off_cnt);
+    StageEntry* lists = (StageEntry*)(w + p.off_lists);
+    StageEntry* ovf = (StageEntry*)(w + p.off_ovf);
+    float* stage_rows = (float*)(w + p.off_rows);
+    if (hipError_t e = hipMemsetAsync(counters, 0, (size_t)(p.n_tiles + 1) * 32 * 4, st)) return set_error_hip(e, "hipMemsetAsync(tile counters)");
+
+    TrainArgs f{};
+    f.ent = d_ent; f.rel = d_rel; f.triples = d_triples; f.neg_override = d_neg_override;
+    f.g_ent = nullptr; f.g_rel = d_grad_rel; f.loss_sum = d_loss_sum; f.pos_scores = d_pos_scores; f.neg_scores = d_neg_scores;
+    f.B = B; f.eta = eta; f.k = m->k; f.K = K; f.nq = m->k / 4;
+    f.sc = SampleCfg{sample_base, (uint32_t)sample_range, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step,
+                     (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
+    f.mc = model_const(m); f.loss = *loss;
+    f.stage_rows = stage_rows; f.st_lists = lists; f.st_ovf = ovf; f.st_counters = counters;
+    f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap; f.dbg = 0;
+
+    TileArgs te{};
+    te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_out = d_grad_ent; te.rel = d_rel;
+    te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
+    te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = m->k; te.K = K; te.nq = m->k / 4;
+    te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;
+    fill_opt_args(te.opt, opt);
+    // B == 0 still runs the tiles: with no gradient the optimizer sweep must decay the slots / apply the
+    // regulariser exactly like the dense path does
+    switch (m->scoring_type) {
+        case AMDKGE_TRANSE: return run_tiled<AMDKGE_TRANSE>(f, te, st);
+        case AMDKGE_DISTMULT: return run_tiled<AMDKGE_DISTMULT>(f, te, st);
+        case AMDKGE_ROTATE: return run_tiled<AMDKGE_ROTATE>(f, te, st);
+        default: return run_tiled<AMDKGE_COMPLEX>(f, te, st);   // ComplEx, HolE (scale folded into dL/dscore)
+    }
+}

@@ -10,6 +10,7 @@ update) of one rank at batch B.  The reference has no multi-device path at all
 (/root/reference: no tf.distribute / NCCL / Horovod call sites); its step is
 ScoringBasedEmbeddingModel.train_step :370-429.
 """
+import os
 
 
 def shard_bounds(n, world, rank):
@@ -33,6 +34,8 @@ class StepLoop:
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
         self.n_steps = 0
+        # AMDKGE_TRAIN_PATH=atomic forces the atomic-scatter kernel + dense sweep (kge_train.hip + kge_opt.hip)
+        self.use_tiled = hasattr(engine, "train_step_tiled") and os.environ.get("AMDKGE_TRAIN_PATH", "tiled") != "atomic"
         self.kernel_hook = None   # bench.py: callable(phase) recording HIP events around the fused kernel
         engine.prepare_training(optimizer.name)
 
@@ -42,9 +45,18 @@ class StepLoop:
         eng = self.engine
         bg = int(global_batch.shape[0])
         lo, hi = shard_bounds(bg, self.world, self.rank)
+        self.optimizer.iterations += 1
+        lam = self.reg.lam if self.reg is not None else 0.0
+        opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2)
+        # owner-computes path (kge_train_tiled.hip) whenever the shape allows it: no global atomics, no dense
+        # entity gradient; data-parallel runs take its gradient-only form and keep the dense sweep
+        tiled = self.use_tiled and hi > lo and eng.tiled_supported(hi - lo, self.eta)
         if self.kernel_hook is not None:
             self.kernel_hook(0)
-        if hi > lo:
+        if tiled:
+            eng.train_step_tiled(global_batch[lo:hi], self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step,
+                                 reg_e=lam, row_offset=lo, b_global=bg, grad_only=self.world > 1)
+        elif hi > lo:
             eng.train_fwdbwd(global_batch[lo:hi], self.eta, self.loss_ffi, self.seed, rng_step,
                              row_offset=lo, b_global=bg)
         if self.kernel_hook is not None:
@@ -52,10 +64,7 @@ class StepLoop:
         if self.world > 1:
             for g in eng.grad_tensors():
                 self.dist.all_reduce(g)
-        self.optimizer.iterations += 1
-        lam = self.reg.lam if self.reg is not None else 0.0
-        eng.opt_step(self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2),
-                     lam, lam)
+        eng.opt_step(opt_ffi, lam, lam, tables="rel" if (tiled and self.world == 1) else "both")
         self.n_steps += 1
 
     def reset_loss(self):

@@ -130,6 +130,27 @@ int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* loss,
 int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_slot0, float* d_slot1,
                     int64_t n_elems, double* d_reg_loss, void* stream);
 
+/* Owner-computes variant of one WHOLE train step for the entity table: a fused forward + staging kernel, then one
+ * workgroup per tile of entity rows accumulates the staged row gradients in LDS and applies the optimizer +
+ * regulariser to its rows in place.  Same reference code as amdkge_train_fwdbwd + amdkge_opt_step
+ * (ScoringBasedEmbeddingModel.py:370-429, optimizers.py:136-168, regularizers.py:35-37) without global atomics or a
+ * dense gradient buffer for the entity table.  Supported for all five models when k % 4 == 0 and k <= 512
+ * (amdkge_train_tiled_workspace_bytes returns 0 otherwise and the call returns AMDKGE_EUNSUPPORTED).
+ *   d_grad_ent : NULL  -> the entity table and its slots are updated in place (single GPU);
+ *                !NULL -> the entity gradient is STORED there (every row overwritten) and nothing is updated
+ *                         (data-parallel: the caller all-reduces it and calls amdkge_opt_step)
+ *   d_grad_rel : dense relation gradient (+=); the caller ALWAYS runs amdkge_opt_step on the relation table
+ *   d_reg_loss : double, += lambda*sum|x|^p of the entity table when it is updated in place (may be NULL)
+ *   d_work     : scratch of amdkge_train_tiled_workspace_bytes(m, B, eta) bytes (contents need not be preserved) */
+int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta);
+int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, const amdkge_opt* opt,
+                            float* d_ent, const float* d_rel, float* d_ent_slot0, float* d_ent_slot1,
+                            const int32_t* d_triples, int64_t B, int32_t eta,
+                            int64_t sample_base, int64_t sample_range, uint64_t seed, uint64_t step,
+                            int64_t row_offset, int64_t b_global, const int32_t* d_neg_override,
+                            float* d_grad_ent, float* d_grad_rel, double* d_loss_sum, double* d_reg_loss,
+                            float* d_pos_scores, float* d_neg_scores, void* d_work, void* stream);
+
 /* evaluate(): AbstractScoringLayer.get_ranks steps (1)+(2) (AbstractScoringLayer.py:156-258,
  * 309-366) for ONE side: quantised positive score vs the quantised score of every corruption.
  *   d_ent_ids : NULL = corruptions are table rows [ent_lo, ent_hi); else int32 [m] row ids

@@ -37,7 +37,14 @@ def test_abi_argument_validation_without_gpu():
     assert lib.amdkge_score(ctypes.byref(m), None, None, None, 3, None, None) == -1      # NULL pointers
     assert lib.amdkge_rank_compose(None, None, 3, 7, None, 1, None) == -1                # unknown strategy
     o = _ffi.Opt(2, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 0)
+    assert lib.amdkge_opt_step(ctypes.byref(o), None, None, None, None, 0, None, None) == -1   # iteration is 1-based
+    o = _ffi.Opt(2, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 1)
     assert lib.amdkge_opt_step(ctypes.byref(o), None, None, None, None, 0, None, None) == 0
+    assert lib.amdkge_train_tiled_workspace_bytes(ctypes.byref(m), 100, 5) == 0                 # k % 4 != 0: unsupported
+    m4 = _ffi.Model(2, 200, 14505, 237, 0, 0)
+    assert lib.amdkge_train_tiled_workspace_bytes(ctypes.byref(m4), 10000, 20) > 10000 * 4 * 400 * 4
+    assert lib.amdkge_train_step_tiled(ctypes.byref(m4), None, ctypes.byref(o), *([None] * 5), 1, 1, 0, 1, 0, 0, 0, 0,
+                                       *([None] * 9)) == -1
     assert lib.amdkge_internal_k(7, 3) == -1
 
 

@@ -31,7 +31,7 @@ def _problem():
     return ent, rel, X, k
 
 
-def _run(world, rank, port, out):
+def _run(world, rank, port, out, tiled=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_backend import OracleEngine
@@ -44,7 +44,7 @@ def _run(world, rank, port, out):
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         d = dist
     ent, rel, X, k = _problem()
-    eng = OracleEngine("ComplEx", k, ent, rel)
+    eng = OracleEngine("ComplEx", k, ent, rel, tiled=tiled)
     loop = StepLoop(eng, 3, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}),
                     regularizers.get("LP", {"p": 2, "lambda": 1e-3}), seed=5, dist=d)
     Xt = torch.as_tensor(X)
@@ -75,12 +75,21 @@ def test_shard_bounds():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_ranks_equal_one_rank(tmp_path):
+@pytest.mark.parametrize("tiled", [False, True])
+def test_two_ranks_equal_one_rank(tmp_path, tiled):
+    """tiled=True drives StepLoop through the owner-computes entry points: in-place entity update +
+    relation-only sweep on one rank, gradient-only form + all-reduce + dense sweep on two."""
     single = str(tmp_path / "single.npz")
-    _run(1, 0, 0, single)
+    _run(1, 0, 0, single, tiled)
+    if tiled:   # the two single-rank paths agree with each other as well
+        plain = str(tmp_path / "plain.npz")
+        _run(1, 0, 0, plain, False)
+        a, b = np.load(single), np.load(plain)
+        assert np.abs(a["ent"] - b["ent"]).max() < 5e-6 and np.abs(a["rel"] - b["rel"]).max() < 5e-6
+        assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5 * abs(float(a["loss"]))
     port = _free_port()
     multi = str(tmp_path / "multi.npz")
-    mp.spawn(_run_spawn, args=(2, port, multi), nprocs=2, join=True)
+    mp.spawn(_run_spawn, args=(2, port, multi, tiled), nprocs=2, join=True)
     a, b = np.load(single), np.load(multi)
     assert np.abs(a["ent"] - b["ent"]).max() < 5e-6
     assert np.abs(a["rel"] - b["rel"]).max() < 5e-6
@@ -90,5 +99,5 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert (calls[:, 1] == 0).all() and set(calls[:, 2]) == {37, 27} and set(calls[:, 0]) == {18, 13}
 
 
-def _run_spawn(rank, world, port, out):
-    _run(world, rank, port, out)
+def _run_spawn(rank, world, port, out, tiled=False):
+    _run(world, rank, port, out, tiled)

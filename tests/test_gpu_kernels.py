@@ -179,6 +179,133 @@ def test_train_neg_override_and_duplicates(gpu_lib):
     assert_grads_close(Gr, Tr)
 
 
+# -------------------------------------------------------------------------------- owner-computes step
+def run_tiled_grads(eng, X, eta, loss_name, reduction, seed, step, negs=None):
+    """amdkge_train_step_tiled in its gradient-only form: g_ent is STORED, g_rel accumulated."""
+    from ampligraph_amd import _ffi
+
+    eng.prepare_training("adam")
+    eng.loss_acc.zero_()
+    eng.g_ent.fill_(123.0)   # must be overwritten, every row
+    B = X.shape[0]
+    ps = torch.empty(B, dtype=torch.float32, device="cuda")
+    ns = torch.empty(B * eta, dtype=torch.float32, device="cuda")
+    d = _ffi.Opt(_ffi.OPTIMIZERS["adam"], 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, 1)
+    eng.train_step_tiled(dev(X), eta, loss_desc(loss_name, reduction), d, seed, step, grad_only=True,
+                         neg_override=None if negs is None else dev(negs), pos_scores=ps, neg_scores=ns)
+    torch.cuda.synchronize()
+    return (float(eng.loss_acc[0].item()), eng.g_ent.cpu().numpy(), eng.g_rel.cpu().numpy(),
+            ps.cpu().numpy(), ns.cpu().numpy())
+
+
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("loss", LOSSES)
+def test_tiled_gradients_parity(gpu_lib, model, loss):
+    """Bucketed owner-computes backward == oracle dense gradients (all models x losses x reductions)."""
+    N, R, k, B, eta = 300, 5, 32, 257, 6
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.6)
+    assert eng.tiled_supported(B, eta)
+    rng = np.random.default_rng(3)
+    X = rand_triples(rng, B, N, R)
+    for reduction in ("sum", "mean"):
+        L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, loss, reduction, seed=9, step=4)
+        negs = O.generate_corruptions(X, N, eta, 9, 4)
+        total, Te, Tr, (sp, sn, per) = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, reduction, R)
+        assert np.allclose(ps, sp, rtol=1e-5, atol=1e-5 * np.abs(sp).max())
+        assert np.allclose(ns, sn, rtol=1e-5, atol=1e-5 * np.abs(sn).max())
+        assert abs(L - float(per.astype(np.float64).sum())) <= 1e-5 * max(1.0, abs(L))
+        assert_grads_close(Ge, Te)
+        assert_grads_close(Gr, Tr)
+
+
+@pytest.mark.parametrize("model,k,N", [("ComplEx", 200, 700), ("DistMult", 400, 5000), ("ComplEx", 352, 300),
+                                         ("TransE", 52, 40000), ("RotatE", 260, 200), ("HolE", 100, 64),
+                                         ("DistMult", 4, 3), ("TransE", 512, 1000)])
+def test_tiled_geometries(gpu_lib, model, k, N):
+    """1 and 2 quads per lane, one-row tiles, tiles larger than the table, ragged last tile."""
+    R, B, eta = 4, 37, 5
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.3 if k < 100 else 0.08)
+    rng = np.random.default_rng(4)
+    X = rand_triples(rng, B, N, R)
+    L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, "self_adversarial", "sum", seed=1, step=0)
+    negs = O.generate_corruptions(X, N, eta, 1, 0)
+    total, Te, Tr, (sp, sn, per) = O.dense_gradients(model, ent, rel, X, negs, eta, "self_adversarial", None, "sum", R)
+    assert abs(L - float(total)) <= 2e-5 * max(1.0, abs(L))
+    assert_grads_close(Ge, Te)
+    assert_grads_close(Gr, Tr)
+
+
+def test_tiled_unsupported_shapes(gpu_lib):
+    from ampligraph_amd import _ffi
+
+    for model, k in (("DistMult", 6), ("ComplEx", 1024), ("TransE", 7)):
+        eng, _, _ = make_engine(model, k, 50, 3, scale=0.1)
+        assert not eng.tiled_supported(10, 2)
+        eng.prepare_training("sgd")
+        with pytest.raises(_ffi.AmdKgeError):
+            eng._twork = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+            _ffi.check(eng.lib.amdkge_train_step_tiled(
+                C.byref(eng.model), C.byref(loss_desc("nll")), C.byref(_ffi.Opt(0, 2, 1e-2, .9, .999, 1e-7, 0.0, 1)),
+                eng.ent.data_ptr(), eng.rel.data_ptr(), None, None, dev(np.zeros((10, 3), np.int32)).data_ptr(), 10, 2,
+                0, 50, 0, 0, 0, 0, None, None, eng.g_rel.data_ptr(), eng.loss_acc.data_ptr(), None, None, None,
+                eng._twork.data_ptr(), None))
+
+
+@pytest.mark.parametrize("model", ["ComplEx", "TransE"])
+def test_tiled_overflow_buckets_and_duplicates(gpu_lib, model):
+    """Every positive shares one subject (its tile's bucket overflows into the shared list), s == o triples,
+    identity corruptions, inactive margins (g == 0 entries are skipped)."""
+    N, R, k, eta, B = 300, 3, 16, 2, 3000
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.4)
+    rng = np.random.default_rng(8)
+    X = rand_triples(rng, B, N, R)
+    X[:, 0] = 7
+    X[::5, 2] = 7
+    negs = O.generate_corruptions(X, N, eta, 5, 2)
+    negs[:B // 2] = X[:B // 2]
+    negs[:B // 2, 2] = 11   # first half of the j = 0 corruptions: object replaced by one hot row
+    for loss in ("pairwise", "nll"):
+        L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, loss, "sum", 5, 2, negs=negs)
+        total, Te, Tr, _ = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, "sum", R)
+        assert abs(L - float(total)) <= 2e-5 * max(1.0, abs(L))
+        assert_grads_close(Ge, Te, tol=1e-4)   # thousands of fp32 terms per hot row, unordered
+        assert_grads_close(Gr, Tr, tol=1e-4)
+
+
+@pytest.mark.parametrize("opt", ["adam", "adagrad", "sgd"])
+@pytest.mark.parametrize("model,reg", [("ComplEx", None), ("DistMult", (2, 1e-3)), ("RotatE", (3, 1e-2)), ("TransE", None)])
+def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg):
+    """Whole owner-computes steps (tables + slots updated from LDS) == oracle train_step, 3 steps."""
+    from ampligraph_amd import _ffi
+
+    N, R, k, B, eta = 150, 4, 12, 200, 4
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.5)
+    eng.prepare_training(opt)
+    st = O.TrainState(ent, rel, opt, 1e-2)
+    rng = np.random.default_rng(6)
+    oreg = None if reg is None else dict(p=reg[0], lam_e=reg[1], lam_r=reg[1])
+    lam = reg[1] if reg else 0.0
+    for t in range(1, 4):
+        X = rand_triples(rng, B, N, R)
+        eng.loss_acc.zero_()
+        d = _ffi.Opt(_ffi.OPTIMIZERS[opt], reg[0] if reg else 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, t)
+        eng.train_step_tiled(dev(X), eta, loss_desc("self_adversarial"), d, 77, t, reg_e=lam)
+        eng.opt_step(d, lam, lam, tables="rel")
+        ref_loss = float(O.train_step(st, model, X, eta, "self_adversarial", 77, t, max_rel_size=R, reg=oreg))
+        torch.cuda.synchronize()
+        got_loss = float(eng.loss_acc[0].item()) + float(eng.loss_acc[1].item())
+        assert abs(got_loss - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss)), (t, got_loss, ref_loss)
+        e, r = eng.get_tables()
+        # Adam's m/(sqrt(v)+eps) amplifies fp32 summation-order noise where g ~ 0: compare the bulk tightly
+        ce = np.abs(e - st.ent) <= 1e-5 + 1e-4 * np.abs(st.ent)
+        cr = np.abs(r - st.rel) <= 1e-5 + 1e-4 * np.abs(st.rel)
+        assert ce.mean() > 0.995 and cr.mean() > 0.99, (opt, model, t, ce.mean(), cr.mean())
+        assert np.abs(e - st.ent).max() < 2.5e-2   # a sign flip of a ~0 gradient moves Adam by at most 2*lr
+        names = {"adam": ("m_e", "v_e"), "adagrad": ("a_e",), "sgd": ()}[opt]
+        for nme in names:
+            assert np.allclose(eng.slots[nme].cpu().numpy(), st.slots[nme], rtol=1e-3, atol=1e-6), (nme, t)
+
+
 # -------------------------------------------------------------------------------- optimizer (a17/a18)
 @pytest.mark.parametrize("opt", ["adam", "adagrad", "sgd"])
 @pytest.mark.parametrize("reg", [None, (2, 1e-3), (3, 1e-2)])
