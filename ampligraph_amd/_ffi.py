@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libamdkge.so")
+LIB_PATH = os.environ.get("AMDKGE_LIB") or os.path.join(_HERE, "lib", "libamdkge.so")   # AMDKGE_LIB: development builds
 ABI_VERSION = 1
 
 # enums of include/amdkge.h
@@ -72,7 +72,8 @@ SIGNATURES = {
                                       I64, I64, P, P, P, P, P, P, P]),
     "amdkge_opt_step": (C.c_int, [C.POINTER(Opt), P, P, P, P, I64, P, P]),
     "amdkge_train_tiled_workspace_bytes": (I64, [C.POINTER(Model), I64, I32]),
-    "amdkge_train_step_tiled": (C.c_int, [C.POINTER(Model), C.POINTER(Loss), C.POINTER(Opt), P, P, P, P, P, I64, I32,
+    "amdkge_train_step_tiled": (C.c_int, [C.POINTER(Model), C.POINTER(Loss), C.POINTER(Opt), P, P, P, P, P, P, C.c_float,
+                                          P, I64, I32,
                                           I64, I64, U64, U64, I64, I64, P, P, P, P, P, P, P, P, P]),
     "amdkge_rank_workspace_bytes": (I64, [C.POINTER(Model), I64]),
     "amdkge_rank_counts": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, I64, I64, P, P, P]),

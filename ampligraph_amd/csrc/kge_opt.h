@@ -44,6 +44,44 @@ __device__ __forceinline__ void opt_elem(const OptArgs& a, float& x, float g, fl
 }
 
 
+// Grid-stride dense sweep over a.n elements (float4 body + scalar tail): optimizer + regulariser + gradient
+// reset.  `first` = this thread's index among `stride` cooperating threads.  Returns the thread's sum |x|^p.
+template <int KIND>
+__device__ __forceinline__ float opt_sweep(const OptArgs& a, int64_t first, int64_t stride) {
+    const int64_t n4 = a.n >> 2;
+    float reg_acc = 0.f;
+    float4* x4 = reinterpret_cast<float4*>(a.x);
+    float4* g4 = reinterpret_cast<float4*>(a.g);
+    float4* m4 = reinterpret_cast<float4*>(a.s0);
+    float4* v4 = reinterpret_cast<float4*>(a.s1);
+    for (int64_t i = first; i < n4; i += stride) {
+        float4 x = x4[i], g = g4[i];
+        float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
+        if constexpr (KIND != AMDKGE_OPT_SGD) m = m4[i];
+        if constexpr (KIND == AMDKGE_OPT_ADAM) v = v4[i];
+        opt_elem<KIND>(a, x.x, g.x, m.x, v.x, reg_acc);
+        opt_elem<KIND>(a, x.y, g.y, m.y, v.y, reg_acc);
+        opt_elem<KIND>(a, x.z, g.z, m.z, v.z, reg_acc);
+        opt_elem<KIND>(a, x.w, g.w, m.w, v.w, reg_acc);
+        x4[i] = x;
+        g4[i] = make_float4(0, 0, 0, 0);
+        if constexpr (KIND != AMDKGE_OPT_SGD) m4[i] = m;
+        if constexpr (KIND == AMDKGE_OPT_ADAM) v4[i] = v;
+    }
+    // scalar tail (n % 4)
+    for (int64_t i = (n4 << 2) + first; i < a.n; i += stride) {
+        float x = a.x[i], g = a.g[i], m = 0.f, v = 0.f;
+        if constexpr (KIND != AMDKGE_OPT_SGD) m = a.s0[i];
+        if constexpr (KIND == AMDKGE_OPT_ADAM) v = a.s1[i];
+        opt_elem<KIND>(a, x, g, m, v, reg_acc);
+        a.x[i] = x;
+        a.g[i] = 0.f;
+        if constexpr (KIND != AMDKGE_OPT_SGD) a.s0[i] = m;
+        if constexpr (KIND == AMDKGE_OPT_ADAM) a.s1[i] = v;
+    }
+    return reg_acc;
+}
+
 // host-side: fill the derived fields of OptArgs from the ABI descriptor
 inline void fill_opt_args(OptArgs& a, const amdkge_opt* opt) {
     a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->epsilon;

@@ -39,7 +39,7 @@ struct TrainArgs {
     StageEntry* st_ovf;      // overflow of full buckets
     int* st_counters;        // [(n_tiles + 1) * 32] bucket fill counts (128-byte stride), last = overflow count
     int st_tile_rows, st_n_tiles, st_cap, st_ovf_cap;
-    int dbg;     // development ablation flags (env AMDKGE_DEBUG): 1 no neg-row atomics, 2 no s/p/o atomics, 4 no pass 2, 8 workgroup-scope atomics
+    int dbg;     // development ablation flags (env AMDKGE_DEBUG): 1 no neg-row atomics, 2 no s/p/o atomics, 4 no pass 2, 8 workgroup-scope atomics, 32 no bucket appends, 64 no staged-row stores
 };
 
 __device__ __forceinline__ float log_sigmoid(float x) {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         // TransE / RotatE: copies of s and o (the owner recomputes grad_unit with its own row).
         static_assert(!STAGE || VEC == 4, "staging uses the 16-byte layout");
         constexpr bool TRILINEAR = (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
-        if (active) {
+        if (active && !(a.dbg & 64)) {
             float* qa = a.stage_rows + ((int64_t)i * 4 + 2) * a.K;
             float* qb = a.stage_rows + ((int64_t)i * 4 + 3) * a.K;
 #pragma unroll
@@ -258,34 +258,53 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 
     const float sgn_scale = a.mc.score_sign * a.mc.score_scale;
 
-    // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
-    for (int j = -1; j < eta; ++j) {
-        const int keep = (j < 0) ? 1 : sh_keep[j];
-        const int64_t er = (j < 0) ? (int64_t)po : (int64_t)sh_repl[j];
-        const float* re = a.ent + er * a.K;
-        float part = 0.f;
+    // Rows in flight per slot: the replacement rows of PF corruptions are requested together (the row loads are
+    // dependent on nothing but LDS-resident ids), then reduced one by one.  One row at a time left the kernel
+    // latency-bound (21 serial L2/MALL round trips per pass per positive).
+    constexpr int PF = (CH * NC * VEC <= 8) ? 4 : 2;
+    auto load_row = [&](const float* re, float (&e)[CH][VEC][NC]) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            float e[VEC][NC];
+        for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int h = 0; h < NC; ++h) {
                 const fvec<VEC> ve = ldg<VEC>(re + qoff[c] + h * a.k);
 #pragma unroll
-                for (int u = 0; u < VEC; ++u) e[u][h] = ve.v[u];
+                for (int u = 0; u < VEC; ++u) e[c][u][h] = ve.v[u];
             }
-            float acc = 0.f;
+    };
+
+    // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
+    for (int j0 = -1; j0 < eta; j0 += PF) {
+        float e[PF][CH][VEC][NC];
+        int keepv[PF];
 #pragma unroll
-            for (int u = 0; u < VEC; ++u)
-                acc += keep ? score_unit<MODEL>(s[c][u], p[c][u], e[u]) : score_unit<MODEL>(e[u], p[c][u], o[c][u]);
-            part += qok[c] ? acc : 0.f;
+        for (int f = 0; f < PF; ++f) {
+            const int j = min(j0 + f, eta - 1);   // past the end: reload the last row, result unused
+            keepv[f] = (j < 0) ? 1 : __builtin_amdgcn_readfirstlane(sh_keep[j]);
+            const int64_t er = (j < 0) ? (int64_t)po : (int64_t)__builtin_amdgcn_readfirstlane(sh_repl[j]);
+            load_row(a.ent + er * a.K, e[f]);
         }
-        const float tot = wave_sum(part);
-        const int jj = (j < 0) ? eta : j;
-        if constexpr (W > 1) {
-            if (lane == 0) sh_part[wv * e1 + jj] = tot;   // cross-wave hop, summed after the loop
-        } else {
-            // reference rounding: reduce_sum, then negate (TransE/RotatE) or scale (HolE)
-            if (lane == 0) sh_neg[jj] = sgn_scale * tot;
+#pragma unroll
+        for (int f = 0; f < PF; ++f) {
+            const int j = j0 + f;
+            if (j >= eta) break;
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int u = 0; u < VEC; ++u)
+                    acc += keepv[f] ? score_unit<MODEL>(s[c][u], p[c][u], e[f][c][u]) : score_unit<MODEL>(e[f][c][u], p[c][u], o[c][u]);
+                part += qok[c] ? acc : 0.f;
+            }
+            const float tot = wave_sum(part);
+            const int jj = (j < 0) ? eta : j;
+            if constexpr (W > 1) {
+                if (lane == 0) sh_part[wv * e1 + jj] = tot;   // cross-wave hop, summed after the loop
+            } else {
+                // reference rounding: reduce_sum, then negate (TransE/RotatE) or scale (HolE)
+                if (lane == 0) sh_neg[jj] = sgn_scale * tot;
+            }
         }
     }
     if constexpr (W > 1) {
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     if (ts == 0) sh_loss[slot] = active ? (double)per : 0.0;
     if constexpr (STAGE) {
         // one entry per row gradient that lands in the entity table, into the bucket of the owning tile
-        if (active)
+        if (active && !(a.dbg & 32))
             for (int j = ts; j < eta + 2; j += TS) {
                 uint32_t dest, role;
                 float g;
@@ -379,36 +398,42 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     };
 
     const bool do_neg_atomics = active && !(a.dbg & 1);
-    for (int j = 0; j < ((a.dbg & 4) ? 0 : eta); ++j) {
-        const int keep = sh_keep[j];
-        const int64_t er = (int64_t)sh_repl[j];
-        const float g = sh_neg[j] * sgn_scale;
-        const float* re = a.ent + er * a.K;
-        float gr[CH][VEC][NC];
+    for (int j0 = 0; j0 < ((a.dbg & 4) ? 0 : eta); j0 += PF) {
+        float e[PF][CH][VEC][NC];
+        int keepv[PF];
+        int64_t erv[PF];
+        float gv[PF];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            float e[VEC][NC];
+        for (int f = 0; f < PF; ++f) {
+            const int j = min(j0 + f, eta - 1);
+            keepv[f] = __builtin_amdgcn_readfirstlane(sh_keep[j]);
+            erv[f] = (int64_t)__builtin_amdgcn_readfirstlane(sh_repl[j]);
+            gv[f] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh_neg[j]))) * sgn_scale;
+            load_row(a.ent + erv[f] * a.K, e[f]);
+        }
 #pragma unroll
-            for (int h = 0; h < NC; ++h) {
-                const fvec<VEC> ve = ldg<VEC>(re + qoff[c] + h * a.k);
+        for (int f = 0; f < PF; ++f) {
+            if (j0 + f >= eta) break;
+            const float g = gv[f];
+            float gr[CH][VEC][NC];
 #pragma unroll
-                for (int u = 0; u < VEC; ++u) e[u][h] = ve.v[u];
-            }
+            for (int c = 0; c < CH; ++c) {
 #pragma unroll
-            for (int u = 0; u < VEC; ++u) {
-                float ds[NC], dp[NC], dd[NC];
-                if (keep) {   // (s, p, e): object replaced
-                    grad_unit<MODEL>(s[c][u], p[c][u], e[u], g, ds, dp, dd);
+                for (int u = 0; u < VEC; ++u) {
+                    float ds[NC], dp[NC], dd[NC];
+                    if (keepv[f]) {   // (s, p, e): object replaced
+                        grad_unit<MODEL>(s[c][u], p[c][u], e[f][c][u], g, ds, dp, dd);
 #pragma unroll
-                    for (int h = 0; h < NC; ++h) { gs[c][u][h] += ds[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = dd[h]; }
-                } else {      // (e, p, o): subject replaced
-                    grad_unit<MODEL>(e[u], p[c][u], o[c][u], g, ds, dp, dd);
+                        for (int h = 0; h < NC; ++h) { gs[c][u][h] += ds[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = dd[h]; }
+                    } else {          // (e, p, o): subject replaced
+                        grad_unit<MODEL>(e[f][c][u], p[c][u], o[c][u], g, ds, dp, dd);
 #pragma unroll
-                    for (int h = 0; h < NC; ++h) { go[c][u][h] += dd[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = ds[h]; }
+                        for (int h = 0; h < NC; ++h) { go[c][u][h] += dd[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = ds[h]; }
+                    }
                 }
             }
+            if constexpr (!STAGE) { if (do_neg_atomics) emit_row(a.g_ent + erv[f] * a.K, gr, a.K, 1.f); }
         }
-        if constexpr (!STAGE) { if (do_neg_atomics) emit_row(a.g_ent + er * a.K, gr, a.K, 1.f); }
     }
 
     // ---- per-block loss: one fp64 atomic -------------------------------------------------------
@@ -422,7 +447,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 
     // ---- resident rows: one atomic row-add each, or (STAGE) plain 16-byte stores for the owner kernel ----
     if constexpr (STAGE) {
-        if (active) {
+        if (active && !(a.dbg & 64)) {
             float* ps_ = a.stage_rows + ((int64_t)i * 4 + 0) * a.K;
             float* po_ = a.stage_rows + ((int64_t)i * 4 + 1) * a.K;
 #pragma unroll
@@ -434,6 +459,8 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                     *reinterpret_cast<float4*>(po_ + qoff[c] + h * a.k) = make_float4(go[c][0][h], go[c][1][h], go[c][2][h], go[c][3][h]);
                 }
             }
+        }
+        if (active && !(a.dbg & 2)) {
             // relation rows: few and hot -> atomic row-add into the dense relation gradient (swept by kge_opt.hip)
             if constexpr (MODEL == AMDKGE_ROTATE) emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.k, 1.f / a.mc.phase_div);
             else emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.K, 1.f);

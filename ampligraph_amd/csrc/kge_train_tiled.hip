@@ -46,8 +46,10 @@ struct TileArgs {
     const float* stage_rows;  // [B][4][K]
     const StageEntry* lists;  // [n_tiles][cap]
     const StageEntry* ovf;    // overflow entries
-    const int* counters;      // [(n_tiles + 1) * 32]; the last one counts the overflow list
+    int* counters;            // [(n_tiles + 2) * 32]: bucket fills, overflow count, finished-tiles ticket
     double* reg_loss;
+    OptArgs rel_opt;          // fused relation-table sweep (rel_blocks > 0): blocks [n_tiles, n_tiles + rel_blocks)
+    int rel_blocks;
     int64_t n_rows;
     int k, K, nq;
     int tile_rows, n_tiles, cap, ovf_cap;
@@ -70,6 +72,23 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tile = blockIdx.x;
+    if (tile >= a.n_tiles) {
+        // relation table: ordinary dense sweep (its gradient was completed by the forward kernel's atomics)
+        const int64_t first = (int64_t)(tile - a.n_tiles) * TILE_THREADS + tid, stride = (int64_t)a.rel_blocks * TILE_THREADS;
+        float racc;
+        if (a.rel_opt.kind == AMDKGE_OPT_ADAM) racc = opt_sweep<AMDKGE_OPT_ADAM>(a.rel_opt, first, stride);
+        else if (a.rel_opt.kind == AMDKGE_OPT_ADAGRAD) racc = opt_sweep<AMDKGE_OPT_ADAGRAD>(a.rel_opt, first, stride);
+        else racc = opt_sweep<AMDKGE_OPT_SGD>(a.rel_opt, first, stride);
+        if (a.rel_opt.reg_loss && a.rel_opt.lam != 0.f) {
+            const float w = wave_sum(racc);
+            if (lane == 0) atomicAdd(a.rel_opt.reg_loss, (double)a.rel_opt.lam * (double)w);
+        }
+        return;
+    }
+    // bucket fill + overflow count are read by every wave up front: the counters are reset behind the
+    // workgroup barrier at the end of the kernel (the library keeps them zero between steps)
+    const int cnt = min(a.counters[tile * 32], a.cap);
+    const int on = min(a.counters[a.n_tiles * 32], a.ovf_cap);
     const int64_t t0 = (int64_t)tile * a.tile_rows;
     const int64_t t1 = min(a.n_rows, t0 + a.tile_rows);
     const int nrow = (int)(t1 - t0);
@@ -177,7 +196,6 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     };
 
     // ---- this tile's bucket: every wave walks all of it, 64 entries per coalesced 16-byte load ----
-    const int cnt = min(a.counters[tile * 32], a.cap);
     const StageEntry* list = a.lists + (size_t)tile * a.cap;
     for (int base = 0; base < cnt; base += 64) {
         StageEntry mine{0u, 0u, 0.f, 0u};
@@ -186,7 +204,6 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         process(mine, __ballot(in && (int)((mine.meta >> 2) % TILE_WAVES) == wv));
     }
     // ---- overflow list (entries of buckets that were full): every tile filters all of it ----
-    const int on = min(a.counters[a.n_tiles * 32], a.ovf_cap);
     for (int base = 0; base < on; base += 64) {
         StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
         if (base + lane < on) mine = a.ovf[base + lane];
@@ -235,6 +252,16 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         const float w = wave_sum(reg_acc);
         if (lane == 0) atomicAdd(a.reg_loss, (double)a.opt.lam * (double)w);
     }
+    // ---- leave the bookkeeping zeroed for the next step: own bucket now, overflow count by the last tile ----
+    __syncthreads();
+    if (tid == 0) {
+        a.counters[tile * 32] = 0;
+        __threadfence();
+        if (atomicAdd(a.counters + (size_t)(a.n_tiles + 1) * 32, 1) == a.n_tiles - 1) {
+            a.counters[a.n_tiles * 32] = 0;
+            a.counters[(a.n_tiles + 1) * 32] = 0;
+        }
+    }
 }
 
 // ---- plan: tile size, bucket capacity and workspace layout (shared by the two entry points) ------------------
@@ -268,7 +295,7 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     p.ovf_cap = (int)(entries > 0 ? entries : 1);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
-    p.off_cnt = o; o += up((size_t)(p.n_tiles + 1) * 32 * 4);
+    p.off_cnt = o; o += up((size_t)(p.n_tiles + 2) * 32 * 4);
     p.off_lists = o; o += up((size_t)p.n_tiles * p.cap * sizeof(StageEntry));
     p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
     p.off_rows = o; o += up((size_t)B * 4 * K * 4);
@@ -284,7 +311,7 @@ static int launch_tile(const TileArgs& a, size_t shmem, hipStream_t st) {
             return set_error_hip(e, "hipFuncSetAttribute(tile_backward)");
         attr = true;
     }
-    hipLaunchKernelGGL((tile_backward_kernel<MODEL, CH, UNROLL>), dim3(a.n_tiles), dim3(TILE_THREADS), shmem, st, a);
+    hipLaunchKernelGGL((tile_backward_kernel<MODEL, CH, UNROLL>), dim3(a.n_tiles + a.rel_blocks), dim3(TILE_THREADS), shmem, st, a);
     return check_launch("tile_backward");
 }
 
@@ -318,7 +345,8 @@ extern "C" int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int
 }
 
 extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, const amdkge_opt* opt,
-                                       float* d_ent, const float* d_rel, float* d_ent_slot0, float* d_ent_slot1,
+                                       float* d_ent, float* d_rel, float* d_ent_slot0, float* d_ent_slot1,
+                                       float* d_rel_slot0, float* d_rel_slot1, float rel_reg_lambda,
                                        const int32_t* d_triples, int64_t B, int32_t eta, int64_t sample_base,
                                        int64_t sample_range, uint64_t seed, uint64_t step, int64_t row_offset,
                                        int64_t b_global, const int32_t* d_neg_override, float* d_grad_ent,
@@ -336,6 +364,9 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
         if (opt->kind != AMDKGE_OPT_SGD && !d_ent_slot0) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 0 is NULL");
         if (opt->kind == AMDKGE_OPT_ADAM && !d_ent_slot1) return set_error(AMDKGE_EINVAL, "train_step_tiled: Adam slot 1 (v) is NULL");
     }
+    const bool d_rel_slot_ok = (opt->kind == AMDKGE_OPT_SGD || d_rel_slot0) && (opt->kind != AMDKGE_OPT_ADAM || d_rel_slot1);
+    if (!d_grad_ent && !d_rel_slot_ok && (d_rel_slot0 || d_rel_slot1))
+        return set_error(AMDKGE_EINVAL, "train_step_tiled: relation optimizer slots incomplete for this optimizer");
     if (B > 0 && !d_triples) return set_error(AMDKGE_EINVAL, "train_step_tiled: null triples");
     if (!d_neg_override && (sample_range <= 0 || sample_range > 0xFFFFFFFFll || sample_base < 0 || sample_base + sample_range > m->n_ents))
         return set_error(AMDKGE_EINVAL, "train_step_tiled: sampling range outside the entity table");
@@ -346,7 +377,6 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     StageEntry* lists = (StageEntry*)(w + p.off_lists);
     StageEntry* ovf = (StageEntry*)(w + p.off_ovf);
     float* stage_rows = (float*)(w + p.off_rows);
-    if (hipError_t e = hipMemsetAsync(counters, 0, (size_t)(p.n_tiles + 1) * 32 * 4, st)) return set_error_hip(e, "hipMemsetAsync(tile counters)");
 
     TrainArgs f{};
     f.ent = d_ent; f.rel = d_rel; f.triples = d_triples; f.neg_override = d_neg_override;
@@ -356,7 +386,8 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
                      (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
     f.mc = model_const(m); f.loss = *loss;
     f.stage_rows = stage_rows; f.st_lists = lists; f.st_ovf = ovf; f.st_counters = counters;
-    f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap; f.dbg = 0;
+    f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap;
+    { const char* e = getenv("AMDKGE_DEBUG"); f.dbg = e ? atoi(e) : 0; }
 
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_out = d_grad_ent; te.rel = d_rel;
@@ -364,12 +395,32 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = m->k; te.K = K; te.nq = m->k / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;
     fill_opt_args(te.opt, opt);
+    // Whole step in two launches when nothing in the tile pass reads the live relation table (trilinear models)
+    // and the tables are updated in place: the relation sweep rides in extra workgroups of the tile kernel.
+    // TransE / RotatE tiles read live relation rows, so their relation sweep stays a separate launch behind.
+    const bool rel_here = !d_grad_ent && d_rel_slot_ok;
+    const bool fuse_rel = rel_here && (m->scoring_type == AMDKGE_DISTMULT || m->scoring_type == AMDKGE_COMPLEX || m->scoring_type == AMDKGE_HOLE);
+    te.rel_blocks = 0;
+    if (rel_here) {
+        te.rel_opt = te.opt;
+        te.rel_opt.x = d_rel; te.rel_opt.g = d_grad_rel; te.rel_opt.s0 = d_rel_slot0; te.rel_opt.s1 = d_rel_slot1;
+        te.rel_opt.n = (int64_t)m->n_rels * K; te.rel_opt.reg_loss = d_reg_loss; te.rel_opt.lam = rel_reg_lambda;
+        if (fuse_rel) {
+            const int64_t n4 = (te.rel_opt.n + 3) / 4;
+            te.rel_blocks = (int)((n4 + TILE_THREADS - 1) / TILE_THREADS < 64 ? (n4 + TILE_THREADS - 1) / TILE_THREADS : 64);
+        }
+    }
     // B == 0 still runs the tiles: with no gradient the optimizer sweep must decay the slots / apply the
     // regulariser exactly like the dense path does
+    int rc;
     switch (m->scoring_type) {
-        case AMDKGE_TRANSE: return run_tiled<AMDKGE_TRANSE>(f, te, st);
-        case AMDKGE_DISTMULT: return run_tiled<AMDKGE_DISTMULT>(f, te, st);
-        case AMDKGE_ROTATE: return run_tiled<AMDKGE_ROTATE>(f, te, st);
-        default: return run_tiled<AMDKGE_COMPLEX>(f, te, st);   // ComplEx, HolE (scale folded into dL/dscore)
+        case AMDKGE_TRANSE: rc = run_tiled<AMDKGE_TRANSE>(f, te, st); break;
+        case AMDKGE_DISTMULT: rc = run_tiled<AMDKGE_DISTMULT>(f, te, st); break;
+        case AMDKGE_ROTATE: rc = run_tiled<AMDKGE_ROTATE>(f, te, st); break;
+        default: rc = run_tiled<AMDKGE_COMPLEX>(f, te, st); break;   // ComplEx, HolE (scale folded into dL/dscore)
     }
+    if (rc != AMDKGE_OK || !rel_here || fuse_rel) return rc;
+    amdkge_opt ro = *opt;
+    ro.reg_lambda = rel_reg_lambda;
+    return amdkge_opt_step(&ro, d_rel, d_grad_rel, d_rel_slot0, d_rel_slot1, (int64_t)m->n_rels * K, d_reg_loss, stream);
 }

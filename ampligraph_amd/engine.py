@@ -102,39 +102,41 @@ class KgeEngine:
         """True when the owner-computes step (amdkge_train_step_tiled) covers this shape."""
         return int(self.lib.amdkge_train_tiled_workspace_bytes(C.byref(self.model), int(B), int(eta))) > 0
 
-    def train_step_tiled(self, triples, eta, loss, opt_desc, seed, step, reg_e=0.0, sample_base=0,
+    def train_step_tiled(self, triples, eta, loss, opt_desc, seed, step, reg_e=0.0, reg_r=0.0, sample_base=0,
                          sample_range=None, row_offset=0, b_global=0, neg_override=None, pos_scores=None,
                          neg_scores=None, grad_only=False):
-        """Owner-computes step: fused forward + staging, then per-tile LDS accumulation.  With
-        grad_only=False the entity table and its slots are updated in place (the relation gradient is
-        left in g_rel for `opt_step(tables="rel")`); with grad_only=True the entity gradient is stored
-        in g_ent instead (data-parallel: all-reduce, then the dense sweep)."""
+        """Owner-computes step (kge_train_tiled.hip).  grad_only=False: the COMPLETE step -- entity table
+        from the LDS tiles, relation table by the fused sweep.  grad_only=True (data-parallel): the entity
+        gradient is stored in g_ent and the relation gradient added to g_rel; nothing is updated."""
         B = int(triples.shape[0])
         need = int(self.lib.amdkge_train_tiled_workspace_bytes(C.byref(self.model), B, int(eta)))
         if need <= 0:
             raise ValueError("shape not supported by the owner-computes path")
         if self._twork is None or self._twork.numel() < need:
-            self._twork = torch.empty(need, dtype=torch.uint8, device=self.device)
+            # zero-filled once; the library keeps its bookkeeping region zero between steps
+            self._twork = torch.zeros(need, dtype=torch.uint8, device=self.device)
         if sample_range is None:
             sample_range = self.n_ents
         s0, s1 = self._slots_of(("m_e", "v_e", "a_e"))
+        r0, r1 = self._slots_of(("m_r", "v_r", "a_r"))
         opt_desc.reg_lambda = float(reg_e)
-        check(self.lib.amdkge_train_step_tiled(
-            C.byref(self.model), C.byref(loss), C.byref(opt_desc), _ptr(self.ent), _ptr(self.rel), _ptr(s0), _ptr(s1),
-            _ptr(triples), B, int(eta), int(sample_base), int(sample_range), int(seed), int(step), int(row_offset),
-            int(b_global), _ptr(neg_override), _ptr(self.g_ent if grad_only else None), _ptr(self.g_rel),
-            C.c_void_p(self.loss_acc.data_ptr()), C.c_void_p(self.loss_acc.data_ptr() + 8),
-            _ptr(pos_scores), _ptr(neg_scores), _ptr(self._twork), _stream()))
+        try:
+            check(self.lib.amdkge_train_step_tiled(
+                C.byref(self.model), C.byref(loss), C.byref(opt_desc), _ptr(self.ent), _ptr(self.rel), _ptr(s0), _ptr(s1),
+                _ptr(r0), _ptr(r1), float(reg_r), _ptr(triples), B, int(eta), int(sample_base), int(sample_range),
+                int(seed), int(step), int(row_offset), int(b_global), _ptr(neg_override),
+                _ptr(self.g_ent if grad_only else None), _ptr(self.g_rel),
+                C.c_void_p(self.loss_acc.data_ptr()), C.c_void_p(self.loss_acc.data_ptr() + 8),
+                _ptr(pos_scores), _ptr(neg_scores), _ptr(self._twork), _stream()))
+        except Exception:
+            self._twork = None   # bookkeeping may be dirty after a failed launch: start from a fresh zeroed buffer
+            raise
 
-    def opt_step(self, opt_desc, reg_e=0.0, reg_r=0.0, tables="both"):
-        """Dense sweep over both tables (optimizer + regulariser + gradient reset); tables="rel" sweeps
-        only the relation table (after train_step_tiled, which has already updated the entity table)."""
+    def opt_step(self, opt_desc, reg_e=0.0, reg_r=0.0):
+        """Dense sweep over both tables (optimizer + regulariser + gradient reset)."""
         reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8)
-        todo = ((self.ent, self.g_ent, ("m_e", "v_e", "a_e"), reg_e),
-                (self.rel, self.g_rel, ("m_r", "v_r", "a_r"), reg_r))
-        if tables == "rel":
-            todo = todo[1:]
-        for x, g, names, lam in todo:
+        for x, g, names, lam in ((self.ent, self.g_ent, ("m_e", "v_e", "a_e"), reg_e),
+                                 (self.rel, self.g_rel, ("m_r", "v_r", "a_r"), reg_r)):
             opt_desc.reg_lambda = float(lam)
             if self.opt_kind == "adam":
                 s0, s1 = self.slots[names[0]], self.slots[names[1]]

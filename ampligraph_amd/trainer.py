@@ -55,7 +55,7 @@ class StepLoop:
             self.kernel_hook(0)
         if tiled:
             eng.train_step_tiled(global_batch[lo:hi], self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step,
-                                 reg_e=lam, row_offset=lo, b_global=bg, grad_only=self.world > 1)
+                                 reg_e=lam, reg_r=lam, row_offset=lo, b_global=bg, grad_only=self.world > 1)
         elif hi > lo:
             eng.train_fwdbwd(global_batch[lo:hi], self.eta, self.loss_ffi, self.seed, rng_step,
                              row_offset=lo, b_global=bg)
@@ -64,7 +64,8 @@ class StepLoop:
         if self.world > 1:
             for g in eng.grad_tensors():
                 self.dist.all_reduce(g)
-        eng.opt_step(opt_ffi, lam, lam, tables="rel" if (tiled and self.world == 1) else "both")
+        if not (tiled and self.world == 1):   # the single-GPU owner-computes call is the complete step
+            eng.opt_step(opt_ffi, lam, lam)
         self.n_steps += 1
 
     def reset_loss(self):

@@ -4,12 +4,15 @@
 Metric (BASELINE.json): training triples/s INCLUDING negatives, ComplEx k=200, eta=20,
 self-adversarial NLL, Adam, on an FB15K-237-shaped synthetic graph (configs[1]); batch 10 000
 positives per GPU per step (the reference docstring's batch, ScoringBasedEmbeddingModel.py:66).
-One "step" = one pass of the hot path over one batch: fused lookup/sampling/score/loss/backward
-kernel + (N>1: gradient all-reduce over RCCL) + dense optimizer sweep of both tables.
+One "step" = one pass of the hot path over one batch = the product's StepLoop.step: at N=1 the
+owner-computes pair (kge_train_tiled.hip: fused lookup/sampling/score/loss/backward + staging kernel,
+then the per-tile LDS accumulation kernel that also applies Adam to both tables); at N>1 the same pair
+in its gradient-only form + gradient all-reduce over RCCL + dense optimizer sweep.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run
-(one rank per GPU).  Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel =
-train_fwdbwd, HBM-bound, algorithmic bytes 2*(3+eta)*4K per positive), `cpu_baseline`
+(one rank per GPU).  Rank 0 prints ONE JSON line.  Extra objects: `roofline` (the train-step kernel pair,
+HBM-bound, algorithmic bytes 2*(3+eta)*4K per positive; duration = HIP events on the launch
+stream around the pair, i.e. the sum of the two kernels' durations + one launch gap), `cpu_baseline`
 (oracle/ref_cpu.py, the op-for-op torch-CPU port, on a bounded sample) and `eval` (filtered
 ranks/s of evaluate() on the 20 438 synthetic test triples, N=1 only).
 """
@@ -199,11 +202,13 @@ def main():
         achieved = bytes_per_pos * B / (kern_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1:
             try:
-                traffic = json.load(open(pmc)).get("train_fwdbwd_hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("train_step_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        tiled = loop.use_tiled and eng.tiled_supported(B, args.eta)
+        kernel_names = (["train_fwdbwd_kernel<..., STAGE=true>", "tile_backward_kernel"] if tiled else ["train_fwdbwd_kernel"])
         out = {
             "metric": "training triples/sec (incl. negatives), ComplEx k=200 eta=20 FB15K-237-shaped",
             "value": triples / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,13 +216,16 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.dataset} (uniform, seed 0) {args.model} k={args.k} eta={args.eta} "
                                    f"{args.loss} adam lr=1e-3, {B} positives/GPU/step, tables resident in HBM, "
-                                   f"dense Keras-legacy Adam sweep every step",
+                                   f"dense (non-lazy) Keras-legacy Adam every step",
                        "global_batch": Bg, "n_ents": N, "n_rels": R, "row_floats": eng.K,
                        "parallelism": f"dp{world} (replicated tables, gradient all-reduce)" if world > 1 else "single GPU"},
             "mean_batch_loss": loss_mean,
-            "roofline": {"bound": "hbm", "kernel": "train_fwdbwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": " + ".join(kernel_names), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_pos * B},
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_pos * B,
+                         "note": "launch = one train step's kernel pair (HIP events on the launch stream around both); "
+                                 "the pair also applies the optimizer (7*4K*(N+R) B/step), which is NOT counted in "
+                                 "the algorithmic bytes; traffic = L2<->fabric bytes (PMC, Infinity-Cache hits included)"},
         }
         if world == 1 and not args.no_eval:
             out["eval"] = eval_bench(eng, data, rank)

@@ -130,21 +130,29 @@ int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* loss,
 int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_slot0, float* d_slot1,
                     int64_t n_elems, double* d_reg_loss, void* stream);
 
-/* Owner-computes variant of one WHOLE train step for the entity table: a fused forward + staging kernel, then one
- * workgroup per tile of entity rows accumulates the staged row gradients in LDS and applies the optimizer +
- * regulariser to its rows in place.  Same reference code as amdkge_train_fwdbwd + amdkge_opt_step
- * (ScoringBasedEmbeddingModel.py:370-429, optimizers.py:136-168, regularizers.py:35-37) without global atomics or a
- * dense gradient buffer for the entity table.  Supported for all five models when k % 4 == 0 and k <= 512
- * (amdkge_train_tiled_workspace_bytes returns 0 otherwise and the call returns AMDKGE_EUNSUPPORTED).
+/* Owner-computes variant of one WHOLE train step: a fused forward + staging kernel, then one workgroup per tile
+ * of entity rows accumulates the staged row gradients in LDS and applies the optimizer + regulariser to its rows in
+ * place.  Same reference code as amdkge_train_fwdbwd + amdkge_opt_step (ScoringBasedEmbeddingModel.py:370-429,
+ * optimizers.py:136-168, regularizers.py:35-37) without global atomics or a dense gradient buffer for the entity
+ * table.  Supported for all five models when k % 4 == 0 and k <= 512 (amdkge_train_tiled_workspace_bytes returns 0
+ * otherwise and the call returns AMDKGE_EUNSUPPORTED).
  *   d_grad_ent : NULL  -> the entity table and its slots are updated in place (single GPU);
- *                !NULL -> the entity gradient is STORED there (every row overwritten) and nothing is updated
- *                         (data-parallel: the caller all-reduces it and calls amdkge_opt_step)
- *   d_grad_rel : dense relation gradient (+=); the caller ALWAYS runs amdkge_opt_step on the relation table
- *   d_reg_loss : double, += lambda*sum|x|^p of the entity table when it is updated in place (may be NULL)
- *   d_work     : scratch of amdkge_train_tiled_workspace_bytes(m, B, eta) bytes (contents need not be preserved) */
+ *                !NULL -> the entity gradient is STORED there (every row overwritten), the relation gradient is
+ *                         ADDED to d_grad_rel and nothing is updated (data-parallel: the caller all-reduces both
+ *                         and calls amdkge_opt_step)
+ *   d_grad_rel : dense relation gradient buffer (+=), zero on entry
+ *   d_rel_slot0/1, rel_reg_lambda : with d_grad_ent == NULL and the slots the optimizer needs given, the relation
+ *                table is swept as well (d_grad_rel is consumed and left zero): the call is the complete step.
+ *                With NULL relation slots (and an optimizer that needs them) the caller sweeps the relation table.
+ *   opt->reg_lambda : regulariser weight of the ENTITY table; d_reg_loss (double, may be NULL) += lambda*sum|x|^p of
+ *                every table this call updates
+ *   d_work     : scratch of amdkge_train_tiled_workspace_bytes(m, B, eta) bytes.  It must be zero-filled before
+ *                its FIRST use; the library leaves its bookkeeping region zeroed after every successful call, so
+ *                one buffer (sized for the largest B) serves every later step of the same model. */
 int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta);
 int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, const amdkge_opt* opt,
-                            float* d_ent, const float* d_rel, float* d_ent_slot0, float* d_ent_slot1,
+                            float* d_ent, float* d_rel, float* d_ent_slot0, float* d_ent_slot1,
+                            float* d_rel_slot0, float* d_rel_slot1, float rel_reg_lambda,
                             const int32_t* d_triples, int64_t B, int32_t eta,
                             int64_t sample_base, int64_t sample_range, uint64_t seed, uint64_t step,
                             int64_t row_offset, int64_t b_global, const int32_t* d_neg_override,

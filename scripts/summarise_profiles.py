@@ -1,0 +1,63 @@
+"""gpurun_out/prof_<tag>/ (written by scripts/profile_bench.sh on the GPU box) -> profiles/<tag>_*.
+Usage: python scripts/summarise_profiles.py r01"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+
+
+def find(sub, suffix):
+    g = glob.glob(os.path.join(src, sub, "**", f"*{suffix}"), recursive=True)
+    return g[0] if g else None
+
+
+for suffix in ("kernel_stats.csv", "domain_stats.csv"):
+    f = find("stats", suffix)
+    if f:
+        shutil.copy(f, os.path.join(dst, f"{tag}_bench_{suffix}"))
+b = os.path.join(src, "bench_under_rocprof.json")
+if os.path.exists(b):
+    shutil.copy(b, os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+
+
+def pmc(sub, counter):
+    f = find(sub, "counter_collection.csv")
+    per = {}
+    if not f:
+        return per
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] != counter:
+            continue
+        name = row["Kernel_Name"].split("(")[0]
+        per.setdefault(name, []).append(float(row["Counter_Value"]))
+    return {k: {"launches": len(v), "mean_kb_per_launch": sum(v) / len(v)} for k, v in per.items() if k.startswith("void kge::")}
+
+
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+out = {"command": "scripts/profile_bench.sh " + tag + " : rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes), "
+                  "each over `python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-eval`",
+       "correction": "MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the bytes of 16 B/lane coalesced "
+                     "reads -> doubled here; WRITE_SIZE used as reported (KB). Both count L2<->fabric traffic, Infinity-Cache "
+                     "hits included, so for these cache-resident tables they bound HBM traffic from above.",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    e = {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)}
+    fb = 2.0 * 1024 * fetch[k]["mean_kb_per_launch"] if k in fetch else None
+    wb = 1024.0 * write[k]["mean_kb_per_launch"] if k in write else None
+    e["fetch_bytes_per_launch_corrected"] = fb
+    e["write_bytes_per_launch"] = wb
+    e["bytes_per_launch"] = (fb or 0.0) + (wb or 0.0)
+    out["kernels"][k] = e
+step = [k for k in out["kernels"] if "train_fwdbwd_kernel" in k or "tile_backward_kernel" in k]
+out["train_step_kernels"] = step
+out["train_step_hbm_bytes_per_launch"] = sum(out["kernels"][k]["bytes_per_launch"] for k in step)
+json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps({k: out["kernels"][k]["bytes_per_launch"] for k in out["kernels"]}, indent=1))
+print("train step:", out["train_step_hbm_bytes_per_launch"])

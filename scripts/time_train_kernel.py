@@ -41,7 +41,6 @@ def run(model="ComplEx", k=200, eta=20, B=10000, reps=30, loss_name="self_advers
             else:
                 eng.train_step_tiled(xb, eta, loss, o, 0, s + 3)
                 ev[1].record()
-                eng.opt_step(o, tables="rel")
             ev[2].record()
             torch.cuda.synchronize()
             if s >= 0:

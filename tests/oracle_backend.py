@@ -41,31 +41,16 @@ class OracleEngine:
         self.g_rel += torch.as_tensor(Gr.astype(np.float32))
         self.loss_acc[0] += float(total)
 
-    def _train_step_tiled(self, triples, eta, loss, opt, seed, step, reg_e=0.0, row_offset=0, b_global=0,
-                          grad_only=False, **kw):
+    def _train_step_tiled(self, triples, eta, loss, opt, seed, step, reg_e=0.0, reg_r=0.0, row_offset=0,
+                          b_global=0, grad_only=False, **kw):
         """amdkge_train_step_tiled: grad_only stores the entity gradient (overwrite) and adds the relation
-        gradient; otherwise the entity table is updated in place and only g_rel is left for opt_step."""
+        gradient; otherwise it is the complete step (both tables updated, gradients left zero)."""
         self.g_ent.zero_()
         self.train_fwdbwd(triples, eta, loss, seed, step, row_offset=row_offset, b_global=b_global)
         if not grad_only:
-            keep_rel = self.g_rel.clone()
-            rel_before = self.state.rel.copy()
-            slots_before = {k: v.copy() for k, v in self.state.slots.items() if k.endswith("_r")}
-            self.opt_step(opt, reg_e, 0.0)
-            self.state.rel[...] = rel_before          # the relation table is swept by the caller
-            for k, v in slots_before.items():
-                self.state.slots[k][...] = v
-            self.g_rel.copy_(keep_rel)
+            self.opt_step(opt, reg_e, reg_r)
 
-    def opt_step(self, opt, lam_e=0.0, lam_r=0.0, tables="both"):
-        if tables == "rel":
-            ent_before = self.state.ent.copy()
-            slots_before = {k: v.copy() for k, v in self.state.slots.items() if k.endswith("_e")}
-            self.opt_step(opt, 0.0, lam_r)
-            self.state.ent[...] = ent_before
-            for k, v in slots_before.items():
-                self.state.slots[k][...] = v
-            return
+    def opt_step(self, opt, lam_e=0.0, lam_r=0.0):
         self.state.lr = opt.lr
         self.state.iterations = opt.iteration - 1
         Ge, Gr = self.g_ent.numpy().astype(np.float64), self.g_rel.numpy().astype(np.float64)

@@ -246,7 +246,8 @@ def test_tiled_unsupported_shapes(gpu_lib):
             eng._twork = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
             _ffi.check(eng.lib.amdkge_train_step_tiled(
                 C.byref(eng.model), C.byref(loss_desc("nll")), C.byref(_ffi.Opt(0, 2, 1e-2, .9, .999, 1e-7, 0.0, 1)),
-                eng.ent.data_ptr(), eng.rel.data_ptr(), None, None, dev(np.zeros((10, 3), np.int32)).data_ptr(), 10, 2,
+                eng.ent.data_ptr(), eng.rel.data_ptr(), None, None, None, None, 0.0,
+                dev(np.zeros((10, 3), np.int32)).data_ptr(), 10, 2,
                 0, 50, 0, 0, 0, 0, None, None, eng.g_rel.data_ptr(), eng.loss_acc.data_ptr(), None, None, None,
                 eng._twork.data_ptr(), None))
 
@@ -289,8 +290,8 @@ def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg):
         X = rand_triples(rng, B, N, R)
         eng.loss_acc.zero_()
         d = _ffi.Opt(_ffi.OPTIMIZERS[opt], reg[0] if reg else 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, t)
-        eng.train_step_tiled(dev(X), eta, loss_desc("self_adversarial"), d, 77, t, reg_e=lam)
-        eng.opt_step(d, lam, lam, tables="rel")
+        eng.train_step_tiled(dev(X), eta, loss_desc("self_adversarial"), d, 77, t, reg_e=lam, reg_r=lam)
+        assert float(eng.g_rel.abs().max()) == 0.0   # relation gradient consumed by the fused / trailing sweep
         ref_loss = float(O.train_step(st, model, X, eta, "self_adversarial", 77, t, max_rel_size=R, reg=oreg))
         torch.cuda.synchronize()
         got_loss = float(eng.loss_acc[0].item()) + float(eng.loss_acc[1].item())
@@ -302,7 +303,7 @@ def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg):
         assert ce.mean() > 0.995 and cr.mean() > 0.99, (opt, model, t, ce.mean(), cr.mean())
         assert np.abs(e - st.ent).max() < 2.5e-2   # a sign flip of a ~0 gradient moves Adam by at most 2*lr
         names = {"adam": ("m_e", "v_e"), "adagrad": ("a_e",), "sgd": ()}[opt]
-        for nme in names:
+        for nme in names + tuple(n.replace("_e", "_r") for n in names):
             assert np.allclose(eng.slots[nme].cpu().numpy(), st.slots[nme], rtol=1e-3, atol=1e-6), (nme, t)
 
 
