@@ -13,6 +13,8 @@
 //                 accumulation chain (bitwise the scores the tile kernel produced) and counts those that
 //                 outrank the positive (always "<=", AbstractScoringLayer.py:292-303).
 //   rank_compose: tie strategy + filter subtraction + 1 (ScoringBasedEmbeddingModel.py:1684).
+#include <stdlib.h>
+
 #include "kge_host.h"
 
 namespace kge {
@@ -138,6 +140,7 @@ struct CountArgs {
     int ent_per_block;
     RankGeom g;
     float sgn_scale;
+    int qtiles, splits;   // MFMA kernel: logical grid, decoded from a 1-D XCD-aware launch
 };
 
 template <int MODE, bool V4>
@@ -258,6 +261,194 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
             if (e) atomicAdd(&a.counts[2 * qi + 1], e);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA tile kernel for the contraction models (DistMult / ComplEx / HolE: score = query . entity row).
+// v_mfma_f32_32x32x2_f32 is exact fp32 and bit-for-bit a k-ordered fmaf chain (cdna_hip_programming.md,
+// "FP32-input MFMA"), i.e. it produces the very bits of rank_op<MODE_DOT> accumulated in unit order: the
+// VALU tile kernel above, this kernel and the filter kernel stay bitwise interchangeable.
+//   workgroup = 4 waves = 128 queries x 128 entities; each wave owns 64 x 64 = 2 x 2 MFMA tiles (64 accumulator
+//   registers); K is streamed through LDS 32 units at a time in [unit][row] layout (the lane->operand map of
+//   the instruction, A[i = l & 31][k = l >> 5], then reads consecutive LDS words), next stage prefetched into
+//   registers while the current one is multiplied; epilogue = quantise -> compare with q(pos) -> packed count.
+// ------------------------------------------------------------------------------------------------
+constexpr int MQ = 128, ME = 128, MK = 32, MLD = 132;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr size_t MFMA_LDS_BYTES = (size_t)2 * 2 * MK * MLD * sizeof(float) + MQ * sizeof(int);
+
+template <bool V4>
+__global__ __launch_bounds__(256, 2) void rank_count_mfma_kernel(CountArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_rank[];
+    typedef float (*tile_t)[MK][MLD];
+    tile_t Qs = reinterpret_cast<tile_t>(smem_rank);                                     // [2][MK][MLD]
+    tile_t Es = reinterpret_cast<tile_t>(smem_rank + (size_t)2 * MK * MLD * sizeof(float));
+    int* qps = reinterpret_cast<int*>(smem_rank + (size_t)4 * MK * MLD * sizeof(float));
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wq = (wv >> 1) * 64, we = (wv & 1) * 64;   // this wave's 64 x 64 corner of the 128 x 128 tile
+    const int l31 = lane & 31, lh = lane >> 5;
+    // XCD-aware work order (speed only, no correctness dependence): workgroup b lands on XCD b % 8 (round-robin
+    // dispatch), every XCD has its own 4 MB L2.  XCD c takes a contiguous eighth of the query tiles and walks it
+    // in groups of 8 query tiles x all entity splits, so the ~64 workgroups resident on one XCD at a time are
+    // 8 query tiles x 8 entity ranges: their Q and E slabs (~3 MB) are shared through that L2 instead of each
+    // workgroup streaming its own from the Infinity Cache.
+    int bx, by;
+    {
+        const int xcd = blockIdx.x & 7;
+        const int64_t i = blockIdx.x >> 3;
+        const int qlo = (int)(((int64_t)a.qtiles * xcd) / 8), qhi = (int)(((int64_t)a.qtiles * (xcd + 1)) / 8);
+        const int nq = qhi - qlo;
+        if (i >= (int64_t)nq * a.splits) return;
+        const int full = nq / 8;
+        const int64_t per_group = (int64_t)8 * a.splits;
+        if (i < full * per_group) {
+            const int64_t r = i % per_group;
+            bx = qlo + (int)(i / per_group) * 8 + (int)(r & 7);
+            by = (int)(r >> 3);
+        } else {
+            const int rem = nq - full * 8;
+            const int64_t r = i - full * per_group;
+            bx = qlo + full * 8 + (int)(r % rem);
+            by = (int)(r / rem);
+        }
+    }
+    const int64_t q0 = (int64_t)bx * MQ;
+    const int64_t e_begin = a.ent_lo + (int64_t)by * a.ent_per_block;
+    const int64_t e_end = min(a.ent_hi, e_begin + a.ent_per_block);
+    const int U = a.g.U;
+    const int S = (U + MK - 1) / MK;                       // LDS stages per tile
+    const int64_t ntile = (e_end - e_begin + ME - 1) / ME;
+
+    if (tid < MQ) { const int64_t qi = q0 + tid; qps[tid] = a.qpos[qi < a.n ? qi : a.n - 1]; }
+
+    // loader: float4 f = tid + 256 * i, i < 4 : row = f >> 3 (128 rows), 4-unit group = f & 7 (8 groups = 32 units)
+    const float* qrow[4];
+    const float* erow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t lq = q0 + ((tid + 256 * i) >> 3);
+        qrow[i] = a.Q + (lq < a.n ? lq : a.n - 1) * (int64_t)a.g.QW + ((tid + 256 * i) & 7) * 4;
+    }
+    auto set_erow = [&](int64_t et) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t le = et + ((tid + 256 * i) >> 3);
+            const int64_t le_c = le < e_end ? le : e_end - 1;
+            const int64_t id = a.ent_ids ? (int64_t)a.ent_ids[le_c] : le_c;
+            erow[i] = a.ent + id * a.g.K + ((tid + 256 * i) & 7) * 4;
+        }
+    };
+    auto fetch = [&](const float* src, int ku) -> float4 {   // 4 consecutive units starting at ku, zero beyond U
+        if (V4) {
+            if (ku < U) return *reinterpret_cast<const float4*>(src);
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 t;
+        t.x = (ku + 0 < U) ? src[0] : 0.f; t.y = (ku + 1 < U) ? src[1] : 0.f;
+        t.z = (ku + 2 < U) ? src[2] : 0.f; t.w = (ku + 3 < U) ? src[3] : 0.f;
+        return t;
+    };
+    float4 pq[4], pe[4];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ku = k0 + ((tid + 256 * i) & 7) * 4;
+            pq[i] = fetch(qrow[i] + k0, ku);
+            pe[i] = fetch(erow[i] + k0, ku);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, kg = (f & 7) * 4;
+            Qs[buf][kg + 0][row] = pq[i].x; Qs[buf][kg + 1][row] = pq[i].y; Qs[buf][kg + 2][row] = pq[i].z; Qs[buf][kg + 3][row] = pq[i].w;
+            Es[buf][kg + 0][row] = pe[i].x; Es[buf][kg + 1][row] = pe[i].y; Es[buf][kg + 2][row] = pe[i].z; Es[buf][kg + 3][row] = pe[i].w;
+        }
+    };
+
+    int cnt[2][16];   // per (query tile mi, accumulator register): gt | eq << 16 over this lane's entity columns
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cnt[mi][r] = 0;
+
+    // The (tile, stage) sequence is one software pipeline: while stage s is multiplied out of LDS buffer `buf`,
+    // the global loads of the next stage (possibly the first stage of the NEXT entity tile) are in flight and are
+    // written to the other buffer afterwards: one workgroup barrier per stage.
+    set_erow(e_begin);
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t t = 0; t < ntile; ++t) {
+        const int64_t et = e_begin + t * ME;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int st = 0; st < S; ++st) {
+            const bool last_stage = (st == S - 1);
+            const bool has_next = !(last_stage && t == ntile - 1);
+            if (has_next) {
+                if (last_stage) set_erow(et + ME);
+                load_stage(last_stage ? 0 : (st + 1) * MK);
+            }
+            // operands of unit pair kk + 2 are read from LDS before the four MFMAs of pair kk are issued, so the
+            // LDS latency hides behind 256 cycles of matrix-pipe work even for a lone wave on the SIMD
+            float opa[2][2], opb[2][2];
+            opa[0][0] = Qs[buf][lh][wq + l31]; opa[0][1] = Qs[buf][lh][wq + 32 + l31];
+            opb[0][0] = Es[buf][lh][we + l31]; opb[0][1] = Es[buf][lh][we + 32 + l31];
+#pragma unroll
+            for (int kk = 0; kk < MK; kk += 2) {
+                const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+                if (kk + 2 < MK) {
+                    opa[nxt][0] = Qs[buf][kk + 2 + lh][wq + l31]; opa[nxt][1] = Qs[buf][kk + 2 + lh][wq + 32 + l31];
+                    opb[nxt][0] = Es[buf][kk + 2 + lh][we + l31]; opb[nxt][1] = Es[buf][kk + 2 + lh][we + 32 + l31];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them otherwise)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][0], opb[cur][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][0], opb[cur][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][1], opb[cur][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][1], opb[cur][1], acc[1][1], 0, 0, 0);
+            }
+            if (has_next) store_stage(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const bool valid = (et + we + ni * 32 + l31) < e_end;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qp = qps[wq + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                    const int q = quantise(a.sgn_scale * acc[mi][ni][r]);
+                    cnt[mi][r] += (valid && qp < q) ? 1 : 0;
+                    cnt[mi][r] += (valid && qp == q) ? 0x10000 : 0;
+                }
+        }
+    }
+    // ---- per query row: sum over the 32 lanes that share it, one atomic pair per row per wave ----
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int g = cnt[mi][r] & 0xFFFF, e = cnt[mi][r] >> 16;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); e += __shfl_xor(e, o, 64); }
+            const int64_t qi = q0 + wq + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (l31 == 0 && qi < a.n) {
+                if (g) atomicAdd(&a.counts[2 * qi + 0], g);
+                if (e) atomicAdd(&a.counts[2 * qi + 1], e);
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -415,18 +606,46 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
     CountArgs a{};
     a.ent = d_ent; a.Q = w.Q; a.qpos = w.qpos; a.ent_ids = d_ent_ids; a.counts = d_counts; a.n = n;
     a.ent_lo = ent_lo; a.ent_hi = ent_hi; a.g = g; a.sgn_scale = mc.score_sign * mc.score_scale;
-    const int64_t qtiles = (n + QT - 1) / QT;
-    const int64_t etiles = (ent_hi - ent_lo + ET - 1) / ET;
-    int64_t splits = (2048 + qtiles - 1) / qtiles;   // aim for >= 2048 blocks (256 CUs x 8)
-    if (splits > etiles) splits = etiles;
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
-    const int64_t tiles_per = (etiles + splits - 1) / splits;
-    a.ent_per_block = (int)(tiles_per * ET);
-    splits = (etiles + tiles_per - 1) / tiles_per;
-    const dim3 grid((unsigned)qtiles, (unsigned)splits);
     const bool v4 = (g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
     const int mode = mode_of(m->scoring_type, side);
+    const char* force = getenv("AMDKGE_RANK_PATH");   // development: "valu" forces the VALU tile kernel
+    const bool mfma = (mode == MODE_DOT) && !(force && force[0] == 'v');
+    const int qt = mfma ? MQ : QT, et_ = mfma ? ME : ET;
+    const int64_t qtiles = (n + qt - 1) / qt;
+    const int64_t etiles = (ent_hi - ent_lo + et_ - 1) / et_;
+    // Entity tiles per block: the grid is (query tiles) x (entity splits).  Pick the split that minimises
+    // (rounds of resident blocks) x (tiles per block), i.e. the tail of the last round, with a mild bias towards
+    // longer blocks (one counter flush per block).
+    const int64_t slots = mfma ? 512 : 2048;   // resident workgroups on 256 CUs (2 resp. 8 per CU)
+    int64_t tiles_per = 1, best_cost = -1;
+    for (int64_t tp = 1; tp <= (mfma ? 256 : 4096) && tp <= etiles; ++tp) {
+        const int64_t sp = (etiles + tp - 1) / tp;
+        if (sp > 65535) continue;
+        const int64_t rounds = (qtiles * sp + slots - 1) / slots;
+        const int64_t cost = rounds * (tp * 16 + 1);   // +1/16 tile per block for the flush
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; tiles_per = tp; }
+    }
+    if (best_cost < 0) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: entity range too large for one launch; split [ent_lo, ent_hi)");
+    int64_t splits;
+    a.ent_per_block = (int)(tiles_per * et_);
+    splits = (etiles + tiles_per - 1) / tiles_per;
+    const dim3 grid((unsigned)qtiles, (unsigned)splits);
+    if (mfma) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)rank_count_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_BYTES);
+            hipError_t e2 = hipFuncSetAttribute((const void*)rank_count_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_BYTES);
+            if (e1 != hipSuccess || e2 != hipSuccess) return set_error_hip(e1 != hipSuccess ? e1 : e2, "hipFuncSetAttribute(rank_count_mfma)");
+            attr_done = true;
+        }
+        a.qtiles = (int)qtiles; a.splits = (int)splits;
+        const int64_t nblk = 8 * ((qtiles + 7) / 8) * splits;
+        if (nblk > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch; split the triples or the entity range");
+        const dim3 grid1((unsigned)nblk);
+        if (v4) hipLaunchKernelGGL((rank_count_mfma_kernel<true>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
+        else hipLaunchKernelGGL((rank_count_mfma_kernel<false>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
+        return check_launch("rank_counts_mfma");
+    }
 #define KGE_CNT(MODE) do { if (v4) hipLaunchKernelGGL((rank_count_kernel<MODE, true>), grid, dim3(256), 0, st, a); \
                            else hipLaunchKernelGGL((rank_count_kernel<MODE, false>), grid, dim3(256), 0, st, a); } while (0)
     switch (mode) {

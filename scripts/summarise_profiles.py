@@ -59,5 +59,25 @@ step = [k for k in out["kernels"] if "train_fwdbwd_kernel" in k or "tile_backwar
 out["train_step_kernels"] = step
 out["train_step_hbm_bytes_per_launch"] = sum(out["kernels"][k]["bytes_per_launch"] for k in step)
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+
+# MFMA utilisation of the rank kernel: MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD * #SIMD)
+f = find("mfma", "counter_collection.csv")
+if f:
+    per = {}
+    for row in csv.DictReader(open(f)):
+        if "rank_count_mfma" in row["Kernel_Name"]:
+            per.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    if per:
+        m = {k: sum(v) / len(v) for k, v in per.items()}
+        gui = m.get("GRBM_GUI_ACTIVE", 0.0) / 8.0          # summed over the 8 XCDs
+        mf = {"kernel": "rank_count_mfma_kernel", "launches": len(next(iter(per.values()))), "mean_per_launch": m,
+              "gui_active_cycles_per_xcd": gui,
+              "mfma_flop_per_launch": m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0,
+              "mfma_util": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0) if gui else None,
+              "note": "SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per v_mfma_f32_32x32x2_f32; 1024 SIMDs; GRBM_GUI_ACTIVE is reported "
+                      "summed over 8 XCDs.  scripts/mfma_peak.hip (pure MFMA loop, same instruction) sustains 124-144 TFLOP/s on "
+                      "this box, i.e. the practical ceiling is ~0.9 of the 157.3 TFLOP/s spec."}
+        json.dump(mf, open(os.path.join(dst, "pmc_mfma.json"), "w"), indent=1)
+        print("mfma util:", mf["mfma_util"])
 print(json.dumps({k: out["kernels"][k]["bytes_per_launch"] for k in out["kernels"]}, indent=1))
 print("train step:", out["train_step_hbm_bytes_per_launch"])

@@ -471,3 +471,25 @@ def test_rank_filter_consistent_with_tile_kernel(gpu_lib):
         allids = [np.arange(N, dtype=np.int32)] * n
         got = gpu_ranks(eng, X, "s,o", "worst", allids, allids)
         assert (got == 1).all(), (model, got.min(), got.max())
+
+
+@pytest.mark.parametrize("model,k,N,n", [("DistMult", 37, 130, 50), ("ComplEx", 200, 1000, 333), ("HolE", 66, 257, 129),
+                                           ("DistMult", 400, 4100, 300)])
+def test_rank_mfma_kernel_bitwise_equals_valu_kernel(gpu_lib, model, k, N, n, monkeypatch):
+    """v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain: the MFMA tile kernel must return exactly the
+    (greater, equal) counts of the VALU tile kernel on random fp32 tables (ragged tiles, both sides, subset)."""
+    from ampligraph_amd import _ffi
+
+    rng = np.random.default_rng(11)
+    eng, ent, rel = make_engine(model, k, N, 5, scale=0.3)
+    X = rand_triples(rng, n, N, 5)
+    sub = dev(np.sort(rng.choice(N, N // 3, replace=False)).astype(np.int32))
+    for side in (_ffi.SIDE_S, _ffi.SIDE_O):
+        for ent_ids in (None, sub):
+            monkeypatch.delenv("AMDKGE_RANK_PATH", raising=False)
+            c_mfma = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
+            monkeypatch.setenv("AMDKGE_RANK_PATH", "valu")
+            c_valu = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
+            assert (c_mfma == c_valu).all(), (model, side, np.abs(c_mfma - c_valu).max())
+            m = N if ent_ids is None else int(ent_ids.shape[0])
+            assert (c_mfma.sum(1) <= m).all() and c_mfma.min() >= 0
