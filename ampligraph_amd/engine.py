@@ -43,7 +43,8 @@ class KgeEngine:
         self.g_rel = None
         self.slots = {}
         self.opt_kind = None
-        self.loss_acc = torch.zeros(2, dtype=torch.float64, device=self.device)  # [data loss, reg loss]
+        # [data loss, regulariser loss, second regulariser slot (row-sharded mode: relation-table part)]
+        self.loss_acc = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._work = None
         self._twork = None
 
@@ -64,8 +65,13 @@ class KgeEngine:
         if optimizer not in _ffi.OPTIMIZERS:
             raise ValueError(f"unknown optimizer {optimizer!r}")
         self.opt_kind = optimizer
-        self.g_ent = torch.zeros_like(self.ent)
-        self.g_rel = torch.zeros_like(self.rel)
+        # one flat allocation (entity part first, 16-byte aligned parts) so that the data-parallel merge is a
+        # SINGLE all-reduce over xGMI instead of one per table
+        ne, nr = self.ent.numel(), self.rel.numel()
+        off = (ne + 63) // 64 * 64   # relation part starts on a 256-byte boundary
+        self.g_flat = torch.zeros(off + nr, dtype=torch.float32, device=self.device)
+        self.g_ent = self.g_flat[:ne].view_as(self.ent)
+        self.g_rel = self.g_flat[off:off + nr].view_as(self.rel)
         self.slots = {}
         if optimizer == "adam":
             for n in ("m_e", "v_e"):
@@ -77,7 +83,7 @@ class KgeEngine:
             self.slots["a_r"] = torch.full_like(self.rel, 0.1)
 
     def grad_tensors(self):
-        return [self.g_ent, self.g_rel]
+        return [self.g_flat]
 
     def train_fwdbwd(self, triples, eta, loss, seed, step, sample_base=0, sample_range=None,
                      row_offset=0, b_global=0, neg_override=None, pos_scores=None, neg_scores=None):
@@ -132,11 +138,14 @@ class KgeEngine:
             self._twork = None   # bookkeeping may be dirty after a failed launch: start from a fresh zeroed buffer
             raise
 
-    def opt_step(self, opt_desc, reg_e=0.0, reg_r=0.0):
-        """Dense sweep over both tables (optimizer + regulariser + gradient reset)."""
-        reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8)
-        for x, g, names, lam in ((self.ent, self.g_ent, ("m_e", "v_e", "a_e"), reg_e),
-                                 (self.rel, self.g_rel, ("m_r", "v_r", "a_r"), reg_r)):
+    def opt_step(self, opt_desc, reg_e=0.0, reg_r=0.0, rows_e=None, reg_slots=(1, 1)):
+        """Dense sweep over both tables (optimizer + regulariser + gradient reset).  rows_e limits the entity
+        sweep to the first rows_e rows (row-sharded mode: the rows behind them are fetched copies of remote
+        rows); reg_slots = loss_acc slots receiving the entity / relation regulariser values."""
+        n_e = self.ent.numel() if rows_e is None else int(rows_e) * self.K
+        for x, g, names, lam, n_el, slot in ((self.ent, self.g_ent, ("m_e", "v_e", "a_e"), reg_e, n_e, reg_slots[0]),
+                                             (self.rel, self.g_rel, ("m_r", "v_r", "a_r"), reg_r, self.rel.numel(), reg_slots[1])):
+            reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(slot))
             opt_desc.reg_lambda = float(lam)
             if self.opt_kind == "adam":
                 s0, s1 = self.slots[names[0]], self.slots[names[1]]
@@ -145,7 +154,7 @@ class KgeEngine:
             else:
                 s0 = s1 = None
             check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(x), _ptr(g), _ptr(s0), _ptr(s1),
-                                           x.numel(), reg_ptr, _stream()))
+                                           n_el, reg_ptr, _stream()))
 
     def sample_corruptions(self, triples, eta, seed, step, sample_base=0, sample_range=None,
                            row_offset=0, b_global=0):

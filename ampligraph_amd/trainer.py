@@ -81,5 +81,5 @@ class StepLoop:
             data = acc[0:1].clone()
             self.dist.all_reduce(data)
             acc[0] = data[0]
-        tot = float(acc[0].item()) + float(acc[1].item())
+        tot = float(acc[0].item()) + float(acc[1].item()) + float(acc[2].item())
         return tot / max(1, self.n_steps)

@@ -18,22 +18,67 @@ class OracleEngine:
             self.tiled_supported = lambda B, eta: True
         self.ent0, self.rel0 = ent.copy(), rel.copy()
         self.n_ents, self.n_rels = ent.shape[0], rel.shape[0]
-        self.loss_acc = torch.zeros(2, dtype=torch.float64)
+        self.loss_acc = torch.zeros(3, dtype=torch.float64)
         self.state = None
         self.calls = []
 
+    @property
+    def ent(self):
+        """The entity table as a torch tensor sharing memory with the oracle state (row-sharded plumbing writes
+        fetched rows into it)."""
+        return torch.from_numpy(self.state.ent if self.state is not None else self.ent0)
+
+    @property
+    def rel(self):
+        return torch.from_numpy(self.state.rel if self.state is not None else self.rel0)
+
+    def sample_corruptions(self, triples, eta, seed, step, sample_base=0, sample_range=None, row_offset=0, b_global=0):
+        X = triples.numpy()
+        negs = O.generate_corruptions(X, int(sample_range or self.n_ents), eta, seed, step, row_offset,
+                                      b_global or X.shape[0])
+        assert sample_base == 0
+        return torch.as_tensor(negs.astype(np.int32))
+
+    def rank_side(self, triples, side, strategy="worst", flt=None, ent_ids=None, subset_pos=None, ent_lo=0,
+                  ent_hi=None, out=None, out_stride=1):
+        """(None, counts (n,2) [greater, equal], sub (n,) or None) like KgeEngine.rank_side, on rows [ent_lo, ent_hi)."""
+        X = triples.numpy().astype(np.int64)
+        ent, rel = self.ent.numpy(), self.rel.numpy()
+        s, p, o = O.lookup(ent, rel, X)
+        tq = O.quantise(O.compute_scores(self.model, s, p, o, max_rel_size=self.n_rels))
+        cq = O.quantise(O.corruption_scores(self.model, "s" if side == 1 else "o", s, p, o, ent[ent_lo:ent_hi], self.n_rels))
+        counts = np.stack([(tq[:, None] < cq).sum(1), (tq[:, None] == cq).sum(1)], 1).astype(np.int32)
+        sub = None
+        if flt is not None:
+            lo, hi, ids = (t.numpy() for t in flt)
+            sub = np.zeros(len(X), dtype=np.int32)
+            for i in range(len(X)):
+                f = ids[lo[i]:hi[i]].astype(np.int64)
+                f = f[(f >= ent_lo) & (f < ent_hi)] - ent_lo
+                sub[i] = int((tq[i] <= cq[i, f]).sum())
+            sub = torch.as_tensor(sub)
+        return None, torch.as_tensor(counts), sub
+
     def prepare_training(self, optimizer):
         self.state = O.TrainState(self.ent0, self.rel0, optimizer, 0.0)
-        self.g_ent = torch.zeros(self.ent0.shape, dtype=torch.float32)
-        self.g_rel = torch.zeros(self.rel0.shape, dtype=torch.float32)
+        ne, nr = self.ent0.size, self.rel0.size
+        self.g_flat = torch.zeros(ne + nr, dtype=torch.float32)
+        self.g_ent = self.g_flat[:ne].view(self.ent0.shape)
+        self.g_rel = self.g_flat[ne:].view(self.rel0.shape)
 
     def grad_tensors(self):
-        return [self.g_ent, self.g_rel]
+        return [self.g_flat]
 
-    def train_fwdbwd(self, triples, eta, loss, seed, step, row_offset=0, b_global=0, **kw):
+    def train_fwdbwd(self, triples, eta, loss, seed, step, row_offset=0, b_global=0, sample_base=0,
+                     sample_range=None, neg_override=None, **kw):
         X = triples.numpy()
         self.calls.append((int(X.shape[0]), int(row_offset), int(b_global), int(step)))
-        negs = O.generate_corruptions(X, self.n_ents, eta, seed, step, row_offset, b_global or X.shape[0])
+        if neg_override is not None:
+            negs = neg_override.numpy()
+        else:
+            assert sample_base == 0
+            negs = O.generate_corruptions(X, int(sample_range or self.n_ents), eta, seed, step, row_offset,
+                                          b_global or X.shape[0])
         total, Ge, Gr, _ = O.dense_gradients(self.model, self.state.ent, self.state.rel, X, negs, eta,
                                              LOSS_BY_ID[loss.kind], {"margin": loss.margin, "alpha": loss.alpha},
                                              "mean" if loss.reduction_mean else "sum", self.n_rels)
@@ -46,18 +91,33 @@ class OracleEngine:
         """amdkge_train_step_tiled: grad_only stores the entity gradient (overwrite) and adds the relation
         gradient; otherwise it is the complete step (both tables updated, gradients left zero)."""
         self.g_ent.zero_()
-        self.train_fwdbwd(triples, eta, loss, seed, step, row_offset=row_offset, b_global=b_global)
+        self.train_fwdbwd(triples, eta, loss, seed, step, row_offset=row_offset, b_global=b_global, **kw)
         if not grad_only:
             self.opt_step(opt, reg_e, reg_r)
 
-    def opt_step(self, opt, lam_e=0.0, lam_r=0.0):
+    def opt_step(self, opt, lam_e=0.0, lam_r=0.0, rows_e=None, reg_slots=(1, 1)):
+        if rows_e is not None:   # row-sharded mode: only the first rows_e rows are this rank's
+            keep = self.state.ent[rows_e:].copy()
+            keep_slots = {k: v[rows_e:].copy() for k, v in self.state.slots.items() if k.endswith("_e")}
+            self.g_ent[rows_e:].zero_()
+            self._sweep(opt, lam_e, lam_r, reg_slots, rows_e)
+            self.state.ent[rows_e:] = keep
+            for k, v in keep_slots.items():
+                self.state.slots[k][rows_e:] = v
+            return
+        self._sweep(opt, lam_e, lam_r, reg_slots, None)
+
+    def _sweep(self, opt, lam_e, lam_r, reg_slots, rows_e):
         self.state.lr = opt.lr
         self.state.iterations = opt.iteration - 1
         Ge, Gr = self.g_ent.numpy().astype(np.float64), self.g_rel.numpy().astype(np.float64)
-        for x, G, lam in ((self.state.ent, Ge, lam_e), (self.state.rel, Gr, lam_r)):
+        for x, G, lam, slot, rows in ((self.state.ent, Ge, lam_e, reg_slots[0], rows_e), (self.state.rel, Gr, lam_r, reg_slots[1], None)):
             if lam:
                 xx = x.astype(np.float64)
-                self.loss_acc[1] += lam * float((np.abs(xx) ** opt.reg_p).sum())
+                if rows is not None:
+                    xx = xx.copy()
+                    xx[rows:] = 0.0   # scratch rows carry no regulariser
+                self.loss_acc[slot] += lam * float((np.abs(xx) ** opt.reg_p).sum())
                 G += lam * opt.reg_p * np.abs(xx) ** (opt.reg_p - 1) * np.sign(xx)
         O.apply_optimizer(self.state, Ge, Gr, opt.beta1, opt.beta2, opt.epsilon)
         self.g_ent.zero_()

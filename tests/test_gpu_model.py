@@ -169,3 +169,111 @@ def test_save_load_weights_roundtrip(gpu_lib, tmp_path):
     h1 = m.fit(X, batch_size=100, epochs=3, initial_epoch=2, verbose=False)
     h2 = m2.fit(X, batch_size=100, epochs=3, initial_epoch=2, verbose=False)
     assert np.allclose(h1.history["loss"], h2.history["loss"], rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ row-sharded mode
+@pytest.mark.parametrize("model,k,negatives", [("ComplEx", 8, "global"), ("TransE", 12, "global"), ("DistMult", 7, "global"),
+                                               ("ComplEx", 8, "local")])
+def test_row_sharded_engines_on_one_gpu(gpu_lib, model, k, negatives):
+    """ampligraph_amd/sharded.py driving TWO real KgeEngines (half the entity table each, scratch rows behind the
+    shard) through an in-process rendezvous (tests/threaded_dist.py).  negatives="global": == one engine with the
+    whole table (same Philox corruptions).  negatives="local": == the oracle restatement of shard-local sampling.
+    Also the sharded evaluation: partial counts summed over shards == whole-table ranks."""
+    import torch
+    from threaded_dist import ThreadedWorld
+
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+    from ampligraph_amd.latent_features import loss_functions, optimizers, regularizers
+    from ampligraph_amd.sharded import ShardedStepLoop, ShardSpec, sharded_rank_counts
+    from ampligraph_amd.trainer import StepLoop, shard_bounds
+
+    rng = np.random.default_rng(2)
+    N, R, eta, bs, seed, W = 83, 4, 3, 64, 11, 2
+    K = O.internal_k(model, k)
+    ent = (rng.normal(size=(N, K)) * 0.4).astype(np.float32)
+    rel = (rng.normal(size=(R, K)) * 0.4).astype(np.float32)
+    X = np.stack([rng.integers(0, N, 200), rng.integers(0, R, 200), rng.integers(0, N, 200)], 1).astype(np.int32)
+    mk = lambda: (loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}),
+                  regularizers.get("LP", {"p": 2, "lambda": 1e-3}))
+    T = X[:40]
+
+    def body(dist):
+        sp = ShardSpec(N, W, dist.get_rank())
+        cap = ShardedStepLoop.rows_needed(bs, eta, negatives) + 2 * len(T)
+        eng = KgeEngine(model, k, sp.n_local + cap, R, max_rel_size=R)
+        shard = np.zeros((sp.n_local + cap, K), dtype=np.float32)
+        shard[:sp.n_local] = ent[sp.lo:sp.hi]
+        eng.set_tables(shard, rel)
+        loss, opt, reg = mk()
+        loop = ShardedStepLoop(eng, sp, eta, loss, opt, reg, seed, dist, negatives=negatives)
+        Xt = torch.as_tensor(X).cuda()
+        loop.reset_loss()
+        step = 0
+        for ep in range(2):
+            for b0 in range(0, len(X), bs):
+                loop.step(Xt[b0:b0 + bs], step)
+                step += 1
+        lossv = loop.mean_batch_loss()
+        full = loop.gather_entity_table().cpu().numpy()
+        cs, _ = sharded_rank_counts(eng, sp, dist, torch.as_tensor(T).cuda(), _ffi.SIDE_S)
+        co, _ = sharded_rank_counts(eng, sp, dist, torch.as_tensor(T).cuda(), _ffi.SIDE_O)
+        return full, eng.rel.cpu().numpy(), lossv, cs.cpu().numpy(), co.cpu().numpy()
+
+    res = ThreadedWorld(W).run(body)
+    full, relg, lossv, cs, co = res[0]
+    assert np.array_equal(full, res[1][0]) and np.array_equal(relg, res[1][1])   # replicas agree
+
+    if negatives == "global":   # one engine, whole table, same schedule
+        eng1 = KgeEngine(model, k, N, R, max_rel_size=R)
+        eng1.set_tables(ent, rel)
+        loss, opt, reg = mk()
+        loop1 = StepLoop(eng1, eta, loss, opt, reg, seed, None)
+        Xt = torch.as_tensor(X).cuda()
+        loop1.reset_loss()
+        step = 0
+        for ep in range(2):
+            for b0 in range(0, len(X), bs):
+                loop1.step(Xt[b0:b0 + bs], step)
+                step += 1
+        e1, r1 = eng1.get_tables()
+        ref_loss = loop1.mean_batch_loss()
+    else:
+        st = O.TrainState(ent, rel, "adam", 1e-2)
+        specs = [ShardSpec(N, W, r) for r in range(W)]
+        step, tot, ns = 0, 0.0, 0
+        for ep in range(2):
+            for b0 in range(0, len(X), bs):
+                xb = X[b0:b0 + bs]
+                Ge, Gr = np.zeros(ent.shape), np.zeros(rel.shape)
+                for r in range(W):
+                    lo, hi = shard_bounds(len(xb), W, r)
+                    xr, sp = xb[lo:hi], specs[r]
+                    B = len(xr)
+                    j = np.repeat(np.arange(eta, dtype=np.uint64), B)
+                    i = np.tile(np.arange(B, dtype=np.uint64), eta)
+                    keep, repl = O.sample_corruption_draws(j * np.uint64(len(xb)) + np.uint64(lo) + i, step, seed, sp.n_local)
+                    data = np.tile(xr, (eta, 1))
+                    repl = repl.astype(np.int64) + sp.lo
+                    ng = np.stack([np.where(keep == 1, data[:, 0], repl), data[:, 1], np.where(keep == 1, repl, data[:, 2])], 1)
+                    l, ge, gr, _ = O.dense_gradients(model, st.ent, st.rel, xr, ng, eta, "self_adversarial", None, "sum", R)
+                    Ge += ge; Gr += gr; tot += float(l)
+                for x, G in ((st.ent, Ge), (st.rel, Gr)):
+                    xx = x.astype(np.float64)
+                    tot += 1e-3 * float((xx ** 2).sum())
+                    G += 2e-3 * xx
+                O.apply_optimizer(st, Ge, Gr)
+                step += 1
+                ns += 1
+        e1, r1, ref_loss = st.ent, st.rel, tot / ns
+    close = np.abs(full - e1) <= 1e-5 + 1e-3 * np.abs(e1)
+    assert close.mean() > 0.995, close.mean()
+    assert np.abs(full - e1).max() < 2.5e-2 and np.abs(relg - r1).max() < 2.5e-2
+    assert abs(lossv - ref_loss) <= 2e-4 * abs(ref_loss), (lossv, ref_loss)
+    # sharded evaluation == one engine holding the gathered table
+    engf = KgeEngine(model, k, N, R, max_rel_size=R)
+    engf.set_tables(full, relg)
+    Td = torch.as_tensor(T).cuda()
+    for side, got in ((_ffi.SIDE_S, cs), (_ffi.SIDE_O, co)):
+        ref = engf.rank_side(Td, side, "worst")[1].cpu().numpy()
+        assert np.array_equal(got, ref), side
