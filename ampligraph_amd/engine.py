@@ -165,6 +165,16 @@ class KgeEngine:
             int(step), int(row_offset), int(b_global), _ptr(out), _stream()))
         return out
 
+    def compose_ranks(self, counts, sub, strategy, out=None, out_stride=1):
+        """(greater, equal) counts [+ filter subtraction] -> 1-based ranks (amdkge_rank_compose)."""
+        n = int(counts.shape[0])
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
+            out_stride = 1
+        check(self.lib.amdkge_rank_compose(_ptr(counts), _ptr(sub), n, _ffi.RANK_STRATEGY[strategy], _ptr(out),
+                                           int(out_stride), _stream()))
+        return out
+
     # ------------------------------------------------------------------ predict
     def score(self, triples):
         n = int(triples.shape[0])

@@ -72,12 +72,27 @@ class ScoringBasedEmbeddingModel:
         self.stop_training = False
         self._engine = None
         self._loop = None
+        self._spec = None            # ShardSpec in row-sharded mode
+        self._sharding = "replicated"
+        self._sharded_negatives = "local"
+        self._dist_override = None   # tests: an object with the torch.distributed collective surface
+        self._full_ent = None        # row-sharded mode: cached gathered entity table
 
     # ------------------------------------------------------------------------------------ compile
     def compile(self, optimizer="adam", loss=None, entity_relation_initializer="glorot_uniform",
                 entity_relation_regularizer=None, **kwargs):
         """:1145-1152.  optimizer: name | OptimizerWrapper; loss: name | Loss; initializer: one value or
-        [entity_init, relation_init]; regularizer: None | 'LP'/'l1'/'l2'/'l3' | LPRegularizer | pair."""
+        [entity_init, relation_init]; regularizer: None | 'LP'/'l1'/'l2'/'l3' | LPRegularizer | pair.
+
+        Extra keywords of this engine (multi-GPU, one process per GPU under torch.distributed):
+        entity_sharding="replicated" (default: tables replicated, gradient all-reduce) | "rows" (entity table
+        row-sharded over the ranks, ampligraph_amd/sharded.py); sharded_negatives="local" | "global"."""
+        self._sharding = kwargs.pop("entity_sharding", "replicated")
+        self._sharded_negatives = kwargs.pop("sharded_negatives", "local")
+        if self._sharding not in ("replicated", "rows"):
+            raise ValueError("entity_sharding must be 'replicated' or 'rows'")
+        if self._sharded_negatives not in ("local", "global"):
+            raise ValueError("sharded_negatives must be 'local' or 'global'")
         self.optimizer = optimizers.get(optimizer)
         if loss is None:
             raise ValueError("compile(): a loss is required")
@@ -103,20 +118,89 @@ class ScoringBasedEmbeddingModel:
             raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
 
     # ------------------------------------------------------------------------------------ engine
-    def _build(self, n_ents, n_rels):
+    EVAL_CHUNK_SHARDED = 4096   # test triples per sharded evaluation / prediction pass (2 scratch rows each)
+
+    def _build(self, n_ents, n_rels, batch_size=None, tables=None):
         from ..engine import KgeEngine  # raises loudly without the HIP library / a GPU
 
         self.max_ent_size, self.max_rel_size = int(n_ents), int(n_rels)
-        self._engine = KgeEngine(self.scoring_type, self.k, n_ents, n_rels, max_rel_size=n_rels)
-        rng = np.random.Generator(np.random.PCG64(self.seed))
-        ent = initialise(self._initializers[0], (n_ents, self.internal_k), rng)
-        rel = initialise(self._initializers[1], (n_rels, self.internal_k), rng)
-        self._engine.set_tables(ent, rel)
+        self._n_ents, self._n_rels = int(n_ents), int(n_rels)
+        if tables is None:
+            rng = np.random.Generator(np.random.PCG64(self.seed))
+            ent = initialise(self._initializers[0], (n_ents, self.internal_k), rng)
+            rel = initialise(self._initializers[1], (n_rels, self.internal_k), rng)
+        else:
+            ent, rel = tables
+        d = self._dist()
+        self._spec = None
+        if self._sharding == "rows" and d is not None:
+            from ..sharded import ShardedStepLoop, ShardSpec
+
+            # same initial values as one GPU (whole table drawn from the same stream, then sliced): fine up to
+            # host-RAM-sized tables; C5-scale tables need a counter-based per-row initialiser (not built)
+            sp = self._spec = ShardSpec(n_ents, d.get_world_size(), d.get_rank())
+            per_rank = -(-int(batch_size or 1000) // sp.world)
+            cap = max(ShardedStepLoop.rows_needed(per_rank, self.eta, self._sharded_negatives), 2 * self.EVAL_CHUNK_SHARDED)
+            self._engine = KgeEngine(self.scoring_type, self.k, sp.n_local + cap, n_rels, max_rel_size=n_rels)
+            shard = np.zeros((sp.n_local + cap, self.internal_k), dtype=np.float32)
+            shard[:sp.n_local] = ent[sp.lo:sp.hi]
+            self._engine.set_tables(shard, rel)
+        else:
+            self._engine = KgeEngine(self.scoring_type, self.k, n_ents, n_rels, max_rel_size=n_rels)
+            self._engine.set_tables(ent, rel)
+        self._full_ent = None
 
     def _dist(self):
+        if self._dist_override is not None:
+            return self._dist_override if self._dist_override.get_world_size() > 1 else None
         import torch.distributed as dist
 
         return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+    def _make_loop(self):
+        reg = self._regularizers[0]
+        if reg is not None and self._regularizers[1].lam != reg.lam:
+            raise NotImplementedError("different lambdas for entity / relation tables")
+        if self._spec is not None:
+            from ..sharded import ShardedStepLoop
+
+            return ShardedStepLoop(self._engine, self._spec, self.eta, self.loss, self.optimizer, reg, self.seed,
+                                   self._dist(), negatives=self._sharded_negatives)
+        return StepLoop(self._engine, self.eta, self.loss, self.optimizer, reg, self.seed, self._dist())
+
+    def _entity_table(self):
+        """(N, K) entity table as a device tensor (row-sharded mode: gathered once and cached until the next fit)."""
+        if self._spec is None:
+            return self._engine.ent
+        if self._full_ent is None:
+            import torch
+
+            sp, eng = self._spec, self._engine
+            mine = torch.zeros(sp.rows_per, eng.K, dtype=eng.ent.dtype, device=eng.ent.device)
+            mine[:sp.n_local] = eng.ent[:sp.n_local]
+            parts = [torch.empty_like(mine) for _ in range(sp.world)]
+            self._dist().all_gather(parts, mine)
+            self._full_ent = torch.cat(parts)[:sp.n_ents]
+        return self._full_ent
+
+    def _localise(self, Xd):
+        """Row-sharded mode: fetch the remote s/o rows of the int32 device triples Xd behind the shard and return
+        the triples re-indexed into the local index space."""
+        import torch
+
+        from ..sharded import RowExchange
+
+        sp, eng = self._spec, self._engine
+        x = Xd.to(torch.int64)
+        n = int(x.shape[0])
+        ids = torch.cat([x[:, 0], x[:, 2]])
+        remote = (ids < sp.lo) | (ids >= sp.hi)
+        rid, rinv = torch.unique(ids[remote], return_inverse=True)
+        ex = RowExchange(sp, self._dist(), rid)
+        ex.fetch(eng.ent, sp.n_local)
+        loc = ids - sp.lo
+        loc[remote] = sp.n_local + ex.slots()[rinv]
+        return torch.stack([loc[:n], x[:, 1], loc[n:]], 1).to(torch.int32).contiguous()
 
     # ------------------------------------------------------------------------------------ fit
     def fit(self, x=None, batch_size=1000, epochs=100, verbose=True, callbacks=None, validation_split=0.0,
@@ -139,16 +223,14 @@ class ScoringBasedEmbeddingModel:
         if self.data_indexer is None or not self.is_fitted:
             self.data_indexer = DataIndexer(X)
             Xi = self.data_indexer.get_indexes(X[:, :3])
-            self._build(self.data_indexer.get_entities_count(), self.data_indexer.get_relations_count())
+            self._build(self.data_indexer.get_entities_count(), self.data_indexer.get_relations_count(), batch_size)
         else:  # continue training (initial_epoch > 0): same id map, same tables
             Xi = self.data_indexer.get_indexes(X[:, :3])
         eng = self._engine
         if self._loop is None:
-            reg = self._regularizers[0]
-            if reg is not None and self._regularizers[1].lam != reg.lam:
-                raise NotImplementedError("different lambdas for entity / relation tables")
-            self._loop = StepLoop(eng, self.eta, self.loss, self.optimizer, reg, self.seed, self._dist())
+            self._loop = self._make_loop()
         loop = self._loop
+        self._full_ent = None
         train = torch.as_tensor(np.ascontiguousarray(Xi, dtype=np.int32)).to(eng.device)
         n = int(train.shape[0])
         batch_size = int(batch_size)
@@ -208,8 +290,13 @@ class ScoringBasedEmbeddingModel:
         Xi = self._index_test(x)
         if Xi.shape[0] == 0:
             return np.zeros(0, dtype=np.float32)
-        out = self._engine.score(torch.as_tensor(Xi).to(self._engine.device))
-        return out.cpu().numpy()
+        Xd = torch.as_tensor(Xi).to(self._engine.device)
+        if self._spec is None:
+            return self._engine.score(Xd).cpu().numpy()
+        outs = []   # row-sharded: every rank fetches the rows it lacks and scores all triples (replicated result)
+        for c0 in range(0, Xi.shape[0], self.EVAL_CHUNK_SHARDED):
+            outs.append(self._engine.score(self._localise(Xd[c0:c0 + self.EVAL_CHUNK_SHARDED])))
+        return torch.cat(outs).cpu().numpy()
 
     # ------------------------------------------------------------------------------------ evaluate
     def evaluate(self, x=None, batch_size=32, verbose=True, use_filter=False, corrupt_side="s,o",
@@ -226,14 +313,16 @@ class ScoringBasedEmbeddingModel:
         sides = [sd for sd in ("s", "o") if sd in corrupt_side]
         if n == 0:
             return np.zeros((0, 1 if corrupt_side in ("s", "o", "s+o") else 2), dtype=np.int32)
+        if self._spec is not None:
+            return self._evaluate_sharded(Xi, sides, use_filter, corrupt_side, entities_subset, ranking_strategy)
         # filters (graph_data_loader.py:184-190,652-653): True -> the evaluated data filters itself;
         # dict -> union of the given datasets, all indexed with the training id map
         fi = None
         if isinstance(use_filter, dict):
             fi = FilterIndex([self.data_indexer.get_indexes(_load_triples(v)[:, :3]) for v in use_filter.values()],
-                             eng.n_ents, eng.n_rels)
+                             self._n_ents, self._n_rels)
         elif use_filter:
-            fi = FilterIndex([Xi], eng.n_ents, eng.n_rels)
+            fi = FilterIndex([Xi], self._n_ents, self._n_rels)
         dev = eng.device
         ent_ids = subset_pos = None
         if entities_subset is not None and len(entities_subset) > 0:
@@ -262,6 +351,45 @@ class ScoringBasedEmbeddingModel:
             r = (r.sum(1, keepdims=True) - 1).astype(np.int32)
         return r
 
+    def _evaluate_sharded(self, Xi, sides, use_filter, corrupt_side, entities_subset, ranking_strategy):
+        """Row-sharded evaluate(): every rank counts against ITS rows, counts are summed over ranks
+        (the reference's loop over entity partitions, :1431-1452, across GPUs); identical result on every rank."""
+        import torch
+
+        from ..sharded import sharded_rank_counts
+
+        if entities_subset is not None and len(entities_subset) > 0:
+            raise NotImplementedError("entities_subset with a row-sharded entity table")
+        eng, d = self._engine, self._dist()
+        fi = None
+        if isinstance(use_filter, dict):
+            fi = FilterIndex([self.data_indexer.get_indexes(_load_triples(v)[:, :3]) for v in use_filter.values()],
+                             self._n_ents, self._n_rels)
+        elif use_filter:
+            fi = FilterIndex([Xi], self._n_ents, self._n_rels)
+        dev = eng.device
+        n = Xi.shape[0]
+        ranks = torch.empty(n, len(sides), dtype=torch.int32, device=dev)
+        flt_ids = {}
+        if fi is not None:
+            flt_ids = {"s": torch.as_tensor(fi.s_ids if fi.s_ids.size else np.zeros(1, np.int32)).to(dev),
+                       "o": torch.as_tensor(fi.o_ids if fi.o_ids.size else np.zeros(1, np.int32)).to(dev)}
+        CH = self.EVAL_CHUNK_SHARDED
+        Xd = torch.as_tensor(Xi).to(dev)
+        for c0 in range(0, n, CH):
+            for col, sd in enumerate(sides):
+                flt = None
+                if fi is not None:
+                    lo, hi = (fi.subject_ranges if sd == "s" else fi.object_ranges)(Xi[c0:c0 + CH])
+                    flt = (torch.as_tensor(lo).to(dev), torch.as_tensor(hi).to(dev), flt_ids[sd])
+                counts, sub = sharded_rank_counts(eng, self._spec, d, Xd[c0:c0 + CH],
+                                                  _ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, flt)
+                eng.compose_ranks(counts, sub, ranking_strategy, out=ranks[c0:c0 + CH, col], out_stride=len(sides))
+        r = ranks.cpu().numpy()
+        if corrupt_side == "s+o":
+            r = (r.sum(1, keepdims=True) - 1).astype(np.int32)
+        return r
+
     # ------------------------------------------------------------------------------------ accessors
     def is_fit(self):
         return self.is_fitted
@@ -279,7 +407,7 @@ class ScoringBasedEmbeddingModel:
 
     def get_train_embedding_matrix_size(self):
         assert self.is_fitted, "Model is not fit on the data yet!"
-        return {"e": (self._engine.n_ents, self.internal_k), "r": (self._engine.n_rels, self.internal_k)}
+        return {"e": (self._n_ents, self.internal_k), "r": (self._n_rels, self.internal_k)}
 
     def get_embeddings(self, entities, embedding_type="e"):
         """:2214-2277."""
@@ -289,7 +417,7 @@ class ScoringBasedEmbeddingModel:
         idx = np.asarray(self.data_indexer.get_indexes(np.asarray(entities), embedding_type), dtype=np.int64)
         import torch
 
-        tab = self._engine.ent if embedding_type == "e" else self._engine.rel
+        tab = self._entity_table() if embedding_type == "e" else self._engine.rel
         return tab[torch.as_tensor(idx).to(tab.device)].cpu().numpy()
 
     # calibration is a "next" row; keep the reference's error for the uncalibrated case
@@ -305,10 +433,15 @@ class ScoringBasedEmbeddingModel:
         """Own flat format (the reference writes a TF checkpoint, :1046-1071): <filepath>.npz holds tables,
         optimizer slots and id maps; <filepath>.json the hyper-parameters."""
         assert self.is_fitted, "Model is not fit on the data yet!"
-        ent, rel = self._engine.get_tables()
-        arrays = {"ent": ent, "rel": rel}
-        for kname, t in self._engine.slots.items():
-            arrays["slot_" + kname] = t.cpu().numpy()
+        if self._spec is not None:
+            # row-sharded: the gathered tables (every rank can write them; optimizer slots stay per rank and are
+            # not part of this file -- sharded checkpoints are a "next" row, SURVEY.md 8f.2)
+            arrays = {"ent": self._entity_table().cpu().numpy(), "rel": self._engine.rel.cpu().numpy()}
+        else:
+            ent, rel = self._engine.get_tables()
+            arrays = {"ent": ent, "rel": rel}
+            for kname, t in self._engine.slots.items():
+                arrays["slot_" + kname] = t.cpu().numpy()
         st = self.data_indexer.state()
         arrays["ent_raw"], arrays["rel_raw"] = st["ent_raw"], st["rel_raw"]
         np.savez(filepath + ".npz", **arrays)
@@ -324,14 +457,12 @@ class ScoringBasedEmbeddingModel:
         self.data_indexer = DataIndexer.from_state({"ent_raw": z["ent_raw"], "rel_raw": z["rel_raw"]})
         if not self.is_compiled:
             self._initializers = ["zeros", "zeros"]
-        self._build(z["ent"].shape[0], z["rel"].shape[0])
-        self._engine.set_tables(z["ent"], z["rel"])
+        self._build(z["ent"].shape[0], z["rel"].shape[0], tables=(z["ent"], z["rel"]))
         slots = {k[5:]: z[k] for k in z.files if k.startswith("slot_")}
-        if slots and self.is_compiled:
+        if slots and self.is_compiled and self._spec is None:
             import torch
 
-            self._loop = StepLoop(self._engine, self.eta, self.loss, self.optimizer, self._regularizers[0],
-                                  self.seed, self._dist())
+            self._loop = self._make_loop()
             for kname, v in slots.items():
                 self._engine.slots[kname].copy_(torch.as_tensor(v))
             if os.path.exists(filepath + ".json"):

@@ -114,6 +114,7 @@ class ShardedStepLoop:
             raise ValueError("engine table is smaller than the local shard")
         self.n_steps = 0
         self.use_tiled = hasattr(engine, "train_step_tiled")
+        self.kernel_hook = None   # bench.py: callable(phase) recording HIP events around the fused kernels
         engine.prepare_training(optimizer.name)
 
     @staticmethod
@@ -154,6 +155,8 @@ class ShardedStepLoop:
         self.optimizer.iterations += 1
         lam = self.reg.lam if self.reg is not None else 0.0
         opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2)
+        if self.kernel_hook is not None:
+            self.kernel_hook(0)
         if b > 0:
             kw = dict(row_offset=lo, b_global=bg, neg_override=nl)
             if nl is None:   # shard-local negatives: replacement rows are local rows [0, n_local)
@@ -162,6 +165,8 @@ class ShardedStepLoop:
                 eng.train_step_tiled(xl, self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step, grad_only=True, **kw)
             else:
                 eng.train_fwdbwd(xl, self.eta, self.loss_ffi, self.seed, rng_step, **kw)
+        if self.kernel_hook is not None:
+            self.kernel_hook(1)
         # ---- 3. gradients of fetched copies go home; relation gradient is summed over ranks ----------------
         ex.return_grads(eng.g_ent, sp.n_local)
         if ex.n:

@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--parallelism", default="replicated", choices=["replicated", "sharded-local", "sharded-global"],
+                    help="N>1: replicated tables + gradient all-reduce (default, right for tables that fit one GPU), or the "
+                         "row-sharded entity table of ampligraph_amd/sharded.py with shard-local / global negatives")
     return ap.parse_args()
 
 
@@ -143,14 +146,29 @@ def main():
 
     data = make_synthetic_kg(args.dataset, seed=0)
     N, R = data["n_ents"], data["n_rels"]
-    eng = KgeEngine(args.model, args.k, N, R, max_rel_size=R)
+    sharded = args.parallelism != "replicated" and world > 1
     rng = np.random.Generator(np.random.PCG64(0))
-    lim_e, lim_r = np.sqrt(6.0 / (N + eng.K)), np.sqrt(6.0 / (R + eng.K))
-    ent0 = rng.uniform(-lim_e, lim_e, size=(N, eng.K)).astype(np.float32)  # Glorot uniform, same on every rank
-    rel0 = rng.uniform(-lim_r, lim_r, size=(R, eng.K)).astype(np.float32)
-    eng.set_tables(ent0, rel0)
-    # the product's own step loop (what ScoringBasedEmbeddingModel.fit drives)
-    loop = StepLoop(eng, args.eta, loss_functions.get(args.loss), optimizers.get("adam"), None, seed=0, dist=dist)
+    Kf = 2 * args.k if args.model in ("ComplEx", "HolE", "RotatE") else args.k
+    lim_e, lim_r = np.sqrt(6.0 / (N + Kf)), np.sqrt(6.0 / (R + Kf))
+    ent0 = rng.uniform(-lim_e, lim_e, size=(N, Kf)).astype(np.float32)  # Glorot uniform, same on every rank
+    rel0 = rng.uniform(-lim_r, lim_r, size=(R, Kf)).astype(np.float32)
+    if sharded:
+        from ampligraph_amd.sharded import ShardedStepLoop, ShardSpec
+
+        negs = args.parallelism.split("-")[1]
+        spec = ShardSpec(N, world, rank)
+        cap = ShardedStepLoop.rows_needed(args.batch, args.eta, negs)
+        eng = KgeEngine(args.model, args.k, spec.n_local + cap, R, max_rel_size=R)
+        shard = np.zeros((spec.n_local + cap, Kf), dtype=np.float32)
+        shard[:spec.n_local] = ent0[spec.lo:spec.hi]
+        eng.set_tables(shard, rel0)
+        loop = ShardedStepLoop(eng, spec, args.eta, loss_functions.get(args.loss), optimizers.get("adam"), None, 0, dist,
+                               negatives=negs)
+    else:
+        eng = KgeEngine(args.model, args.k, N, R, max_rel_size=R)
+        eng.set_tables(ent0, rel0)
+        # the product's own step loop (what ScoringBasedEmbeddingModel.fit drives)
+        loop = StepLoop(eng, args.eta, loss_functions.get(args.loss), optimizers.get("adam"), None, seed=0, dist=dist)
 
     # the training set lives in HBM; a global batch is a contiguous slice (reference order: sequential,
     # un-shuffled, graph_data_loader.py:472-523); each rank takes its share of it inside StepLoop
@@ -218,7 +236,9 @@ def main():
                                    f"{args.loss} adam lr=1e-3, {B} positives/GPU/step, tables resident in HBM, "
                                    f"dense (non-lazy) Keras-legacy Adam every step",
                        "global_batch": Bg, "n_ents": N, "n_rels": R, "row_floats": eng.K,
-                       "parallelism": f"dp{world} (replicated tables, gradient all-reduce)" if world > 1 else "single GPU"},
+                       "parallelism": (f"rows{world} (row-sharded entity table, {args.parallelism.split('-')[1]} negatives, "
+                                       "all_to_all row/gradient exchange)" if sharded else
+                                       f"dp{world} (replicated tables, gradient all-reduce)" if world > 1 else "single GPU")},
             "mean_batch_loss": loss_mean,
             "roofline": {"bound": "hbm", "kernel": " + ".join(kernel_names), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -277,3 +277,59 @@ def test_row_sharded_engines_on_one_gpu(gpu_lib, model, k, negatives):
     for side, got in ((_ffi.SIDE_S, cs), (_ffi.SIDE_O, co)):
         ref = engf.rank_side(Td, side, "worst")[1].cpu().numpy()
         assert np.array_equal(got, ref), side
+
+
+def test_model_row_sharded_matches_single_gpu(gpu_lib):
+    """Drop-in surface in row-sharded mode (compile(entity_sharding="rows")): two model replicas (threads, in-process
+    rendezvous) holding half the entity table each == one model on one GPU: loss history, embeddings, predict,
+    filtered evaluate.  sharded_negatives="global" draws the single-GPU corruptions, so the runs are comparable."""
+    from threaded_dist import ThreadedWorld
+
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers
+
+    X = toy_graph(n=600, N=50, R=3)
+    Xtest = X[:60]
+    k, eta, bs, epochs = 8, 3, 128, 3
+
+    def make():
+        m = ScoringBasedEmbeddingModel(eta=eta, k=k, scoring_type="ComplEx", seed=4)
+        return m
+
+    def body(dist):
+        m = make()
+        m._dist_override = dist
+        m.compile(optimizer=optimizers.get("adam", {"learning_rate": 1e-2}), loss="self_adversarial",
+                  entity_relation_regularizer="l2", entity_sharding="rows", sharded_negatives="global")
+        h = m.fit(X, batch_size=bs, epochs=epochs, verbose=False)
+        assert m._spec is not None and m._engine.ent.shape[0] < 50 + 2 * m.EVAL_CHUNK_SHARDED + 1000
+        ents = np.array([f"e{i}" for i in range(50)])
+        return (h.history["loss"], m.get_embeddings(ents), m.predict(Xtest),
+                m.evaluate(Xtest, use_filter={"train": X}, corrupt_side="s,o", verbose=False),
+                m.evaluate(Xtest, corrupt_side="s+o", ranking_strategy="middle", verbose=False))
+
+    res = ThreadedWorld(2).run(body)
+    m1 = make()
+    m1.compile(optimizer=optimizers.get("adam", {"learning_rate": 1e-2}), loss="self_adversarial",
+               entity_relation_regularizer="l2")
+    h1 = m1.fit(X, batch_size=bs, epochs=epochs, verbose=False)
+    ents = np.array([f"e{i}" for i in range(50)])
+    e1, p1 = m1.get_embeddings(ents), m1.predict(Xtest)
+    for hist, emb, pred, rf, rm in res:
+        assert np.allclose(hist, h1.history["loss"], rtol=2e-4)
+        close = np.abs(emb - e1) <= 1e-5 + 1e-3 * np.abs(e1)
+        assert close.mean() > 0.995
+        assert np.allclose(pred, p1, rtol=1e-3, atol=1e-4)
+    # the two replicas agree exactly with each other; ranks are compared on THEIR (gathered) tables
+    assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4])
+    m1._engine.set_tables(_reorder(res[0][1], m1, ents), m1._engine.rel.cpu().numpy())
+    # relation tables differ by fp32 summation order only; compare ranks up to that noise
+    rf1 = m1.evaluate(Xtest, use_filter={"train": X}, corrupt_side="s,o", verbose=False)
+    assert (np.abs(rf1 - res[0][3]) <= 1).mean() > 0.97
+
+
+def _reorder(emb_by_name, model, ents):
+    """embeddings listed by entity name -> table order of `model`'s indexer"""
+    idx = model.data_indexer.get_indexes(ents, "e")
+    tab = np.zeros_like(emb_by_name)
+    tab[idx] = emb_by_name
+    return tab
