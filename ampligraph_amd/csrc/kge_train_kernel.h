@@ -133,9 +133,150 @@ __device__ __forceinline__ void loss_and_dscore(const amdkge_loss& L, float P, f
     }
 }
 
+// Single-pass backward for the trilinear models (DistMult / ComplEx / HolE).  There d(score)/d(s,p,o) is LINEAR in
+// the replaced row e_j, so  sum_j g_j * d/d(.)(e_j) = d/d(.)(sum_j g_j e_j): the replacement rows need not be read
+// a second time if sum_j g_j e_j can be formed while they stream by.  Every loss's dL/dneg_j factors as
+//     g_j = kappa1 * c1_j + kappa2 * c2_j
+// with c1_j, c2_j known when row j is scored (given the positive's score and running statistics) and
+// kappa1, kappa2 known after the last row:
+//   pairwise / nll / absolute_margin : c1_j = g_j * red, kappa1 = 1/red                     (loss_functions.py:302-308,376-382,458-464)
+//   multiclass_nll                   : c1_j = exp(clip n_j) [in range], kappa1 = 1/(Z red)  (:647-654)
+//   self_adversarial (softmax in-graph, :556-574), online softmax with running max m of alpha*n:
+//        u_j = exp(alpha n_j - m), c1_j = u_j (sigma(n_j+gamma) - alpha l_j), c2_j = u_j, l_j = log sigma(-n_j-gamma)
+//        kappa1 = 1/(S red), kappa2 = alpha (sum u l / S)/(S red), S = sum u   (accumulators rescaled when m grows)
+struct OnePassState {
+    float m;             // running maximum of alpha * n (wave-uniform)
+    float S, Lw, Zs;     // PER-LANE partial sums (lane f accumulates the rows it evaluated):
+                         //   self_adversarial: S = sum u, Lw = sum u*l ; nll: Lw = sum softplus(n) ; multiclass: Zs = sum exp(n)
+};
+
+// The single-pass path evaluates the loss terms once per GROUP of rows (4 lanes busy), so their instruction count
+// matters: hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each) instead of the libm expansions.
+__device__ __forceinline__ float fast_exp(float x) {
+    // 2^(x*log2e) with the rounding error of the product folded back in: ~2 ulp over the clipped range |x| <= 75
+    const float t = x * 1.4426950216293335f;                                       // fl(log2 e)
+    const float r = fmaf(x, 1.4426950216293335f, -t) + x * 1.9259629911266175e-8f;  // exact residual + low part of log2 e
+    return __builtin_amdgcn_exp2f(t) * fmaf(r, 0.6931471805599453f, 1.f);
+}
+// sigma(y) and log sigma(-y) = -softplus(y) from one exponential
+__device__ __forceinline__ void fast_sig_logsig(float y, float& sig, float& logsig_neg) {
+    const float t = fast_exp(-fabsf(y));
+    const float r = __builtin_amdgcn_rcpf(1.f + t);
+    sig = (y >= 0.f) ? r : t * r;
+    logsig_neg = fminf(-y, 0.f) - __builtin_amdgcn_logf(1.f + t) * 0.6931471805599453f;
+}
+
+// Coefficients of up to 64 rows at once: lane f holds the score n of one row (valid == false: no row).  Returns the
+// lane's c1, c2 and the wave-uniform factor by which everything accumulated so far must be rescaled (self-adversarial
+// loss: the running softmax maximum grew), 1 otherwise.
+__device__ __forceinline__ float onepass_coeff(const amdkge_loss& L, float P, float n, bool valid, OnePassState& st,
+                                               float& c1, float& c2) {
+    c1 = 0.f;
+    c2 = 0.f;
+    float rescale = 1.f;
+    switch (L.kind) {
+        case AMDKGE_LOSS_PAIRWISE: c1 = (valid && (L.margin - P + n >= 0.f)) ? 1.f : 0.f; break;
+        case AMDKGE_LOSS_NLL: {
+            const bool in = valid && (n >= -75.f) && (n <= 75.f);
+            float sg, lsn;
+            fast_sig_logsig(fminf(fmaxf(n, -75.f), 75.f), sg, lsn);
+            st.Lw += valid ? -lsn : 0.f;   // softplus(clip n) = log(1 + exp(clip n))
+            c1 = in ? sg : 0.f;
+        } break;
+        case AMDKGE_LOSS_ABSOLUTE_MARGIN: c1 = (valid && (L.margin + n >= 0.f)) ? 1.f : 0.f; break;
+        case AMDKGE_LOSS_SELF_ADVERSARIAL: {
+            const float x = L.alpha * n;
+            const float gm = wave_max(valid ? x : -INFINITY);
+            if (gm > st.m) {
+                rescale = (st.m == -INFINITY) ? 0.f : fast_exp(st.m - gm);   // nothing accumulated before the first group
+                st.S *= rescale; st.Lw *= rescale; st.m = gm;
+            }
+            const float u = valid ? fast_exp(x - st.m) : 0.f;
+            float sg, ell;
+            fast_sig_logsig(n + L.margin, sg, ell);   // sigma(n + gamma), l = log sigma(-n - gamma)
+            st.S += u; st.Lw += valid ? u * ell : 0.f;
+            c1 = valid ? u * (sg - L.alpha * ell) : 0.f;
+            c2 = u;
+        } break;
+        default: {
+            const bool in = valid && (n >= -75.f) && (n <= 75.f);
+            const float ex = valid ? fast_exp(fminf(fmaxf(n, -75.f), 75.f)) : 0.f;
+            st.Zs += ex;
+            c1 = in ? ex : 0.f;
+        } break;
+    }
+    return rescale;
+}
+
+// st holds the wave totals here (wave_sum of the per-lane partials)
+__device__ __forceinline__ void onepass_kappa(const amdkge_loss& L, float P, int eta, const OnePassState& st, float& k1, float& k2) {
+    const float feta = (float)eta;
+    float red = L.reduction_mean ? feta : 1.f;
+    k2 = 0.f;
+    switch (L.kind) {
+        case AMDKGE_LOSS_NLL: if (L.reduction_mean) red = 2.f * feta; k1 = 1.f / red; break;
+        case AMDKGE_LOSS_SELF_ADVERSARIAL: k1 = 1.f / (st.S * red); k2 = L.alpha * (st.Lw / st.S) / (st.S * red); break;
+        case AMDKGE_LOSS_MULTICLASS_NLL: {
+            const float eP = fast_exp(fminf(fmaxf(P, -75.f), 75.f));
+            k1 = 1.f / ((st.Zs / red + eP) * red);
+        } break;
+        default: k1 = 1.f / red; break;
+    }
+}
+
+// Loss.__call__ for one positive on the single-pass path: same outputs as loss_and_dscore (per-sample loss, dL/dpos,
+// sn[j] <- dL/dneg_j) from the statistics the row loop already gathered (st = wave totals).
+__device__ __forceinline__ void onepass_finish(const amdkge_loss& L, float P, float* sn, int eta, int lane,
+                                               const OnePassState& st, float& per, float& dP) {
+    const float feta = (float)eta;
+    float red = L.reduction_mean ? feta : 1.f;
+    switch (L.kind) {
+        case AMDKGE_LOSS_NLL: {   // loss_functions.py:376-382
+            if (L.reduction_mean) red = 2.f * feta;
+            const bool inP = (P >= -75.f) && (P <= 75.f);
+            float sgP, lsP;
+            fast_sig_logsig(-fminf(fmaxf(P, -75.f), 75.f), sgP, lsP);   // sigma(-Pc), log sigma(Pc)
+            for (int j = lane; j < eta; j += KGE_WAVE) {
+                const float n = sn[j];
+                float sg, ls;
+                fast_sig_logsig(fminf(fmaxf(n, -75.f), 75.f), sg, ls);
+                sn[j] = ((n >= -75.f) && (n <= 75.f)) ? sg / red : 0.f;
+            }
+            per = (feta * -lsP + st.Lw) / red;   // log(1+exp(-Pc)) = -log sigma(Pc)
+            dP = inP ? -feta * sgP / red : 0.f;
+        } break;
+        case AMDKGE_LOSS_SELF_ADVERSARIAL: {   // :556-574
+            const float lbar = st.Lw / st.S;
+            for (int j = lane; j < eta; j += KGE_WAVE) {
+                const float n = sn[j];
+                const float w = fast_exp(L.alpha * n - st.m) / st.S;
+                float sg, ell;
+                fast_sig_logsig(n + L.margin, sg, ell);
+                sn[j] = (w * sg - L.alpha * w * (ell - lbar)) / red;
+            }
+            float sgP, lsP;
+            fast_sig_logsig(-(L.margin + P), sgP, lsP);   // sigma(-(gamma+P)), log sigma(gamma+P)
+            per = -lsP - lbar / red;
+            dP = -sgP;
+        } break;
+        default: {   // AMDKGE_LOSS_MULTICLASS_NLL :647-654
+            const bool inP = (P >= -75.f) && (P <= 75.f);
+            const float Pc = fminf(fmaxf(P, -75.f), 75.f);
+            const float eP = fast_exp(Pc);
+            const float Z = st.Zs / red + eP;
+            for (int j = lane; j < eta; j += KGE_WAVE) {
+                const float n = sn[j];
+                sn[j] = ((n >= -75.f) && (n <= 75.f)) ? fast_exp(fminf(fmaxf(n, -75.f), 75.f)) / Z / red : 0.f;
+            }
+            per = __builtin_amdgcn_logf(Z) * 0.6931471805599453f - Pc;   // -log(eP / Z)
+            dP = inP ? -1.f + eP / Z : 0.f;
+        } break;
+    }
+}
+
 __host__ __device__ inline size_t slot_lds_bytes(int eta, int W) {
-    // neg[eta+1], repl[eta+1], keep[eta+1], part[W][eta+1] (W>1), rounded to 8 bytes
-    const size_t b = (size_t)(eta + 1) * (3 + (W > 1 ? W : 0)) * 4;
+    // neg[eta+1], repl[eta+1], keep[eta+1], then part[W][eta+1] (W>1) or perm[eta+1] (W==1), rounded to 8 bytes
+    const size_t b = (size_t)(eta + 1) * (3 + (W > 1 ? W : 1)) * 4;
     return (b + 7) & ~(size_t)7;
 }
 
@@ -152,8 +293,11 @@ __device__ __forceinline__ void slot_sync() {
 
 // LDS layout per slot: float neg[eta+1] (index eta = the positive); int repl[eta]; int keep[eta];
 // float part[W][eta+1] (W>1 only).  Tail of the block: double blockloss[SLOTS].
+// The single-pass variants are bound by the latency of the random row gathers: ask for 4 workgroups (16 waves) per CU,
+// i.e. <= 128 VGPRs, where the row fits one quad per lane.
 template <int MODEL, int VEC, int W, int CH, bool STAGE = false>
-__global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
+__global__ __launch_bounds__(256, (STAGE && W == 1 && CH == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX)) ? 4 : 1)
+void train_fwdbwd_kernel(TrainArgs a) {
     using T = ModelTraits<MODEL>;
     constexpr int NC = T::NC;
     constexpr int SLOTS = 4 / W;          // positives per 256-thread block
@@ -274,7 +418,136 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     };
 
     // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
-    for (int j0 = -1; j0 < eta; j0 += PF) {
+    constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
+    float av1[2][CH][VEC][NC], av2[2][CH][VEC][NC];   // [0]: sum c_j e_j over object-replaced rows, [1]: subject-replaced
+    OnePassState ops{-INFINITY, 0.f, 0.f, 0.f};
+    if constexpr (ONEPASS) {
+        // Single pass (see OnePassState): scores as dot products with the side rows A = d/do(s,p), B = d/ds(p,o)
+        // (score(s,p,e) = <A, e>, score(e,p,o) = <B, e>: the query-vector form the reference itself uses for
+        // corruption scores, ComplEx.py:93-107,138-150), and sum_j c_j e_j accumulated while the rows stream by.
+        // s, p, o are dead inside the loop (reloaded afterwards): the loop lives on A, B, PF rows and 4 accumulators.
+        float qa[CH][VEC][NC], qb[CH][VEC][NC];
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                float ds[NC], dp[NC], dd[NC];
+                grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], 1.f, ds, dp, dd);
+#pragma unroll
+                for (int h = 0; h < NC; ++h) {
+                    qa[c][u][h] = dd[h]; qb[c][u][h] = ds[h];
+                    av1[0][c][u][h] = 0.f; av1[1][c][u][h] = 0.f; av2[0][c][u][h] = 0.f; av2[1][c][u][h] = 0.f;
+                }
+                acc += score_unit<MODEL>(s[c][u], p[c][u], o[c][u]);   // the positive keeps the reference's op order
+            }
+            part += qok[c] ? acc : 0.f;
+        }
+        const float P1 = sgn_scale * wave_sum(part);
+        if (lane == 0) sh_neg[eta] = P1;
+        // corruptions ordered by side (object-replaced first): each of the two row loops below then has a
+        // compile-time side, i.e. fixed accumulators and no per-row selects
+        int* sh_perm = reinterpret_cast<int*>(sh_part);
+        int nkeep = 0;
+        for (int jb = 0; jb < eta; jb += KGE_WAVE) {
+            const int j = jb + lane;
+            nkeep += __popcll(__ballot(j < eta && sh_keep[j] != 0));
+        }
+        {
+            int offk = 0, offn = nkeep;
+            for (int jb = 0; jb < eta; jb += KGE_WAVE) {
+                const int j = jb + lane;
+                const bool valid = j < eta;
+                const bool k = valid && sh_keep[j] != 0;
+                const unsigned long long mk = __ballot(k), mn = __ballot(valid && !k);
+                const unsigned long long mine = k ? mk : mn;
+                const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
+                if (valid) sh_perm[(k ? offk : offn) + before] = j;
+                offk += __popcll(mk); offn += __popcll(mn);
+            }
+        }
+        slot_sync<W>();
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int p_begin = d == 0 ? 0 : nkeep, p_end = d == 0 ? nkeep : eta;
+            for (int p0 = p_begin; p0 < p_end; p0 += PF) {
+                float e[PF][CH][VEC][NC];
+                int jv[PF];
+#pragma unroll
+                for (int f = 0; f < PF; ++f) {
+                    jv[f] = __builtin_amdgcn_readfirstlane(sh_perm[min(p0 + f, p_end - 1)]);   // past the end: reload the last row
+                    load_row(a.ent + (int64_t)__builtin_amdgcn_readfirstlane(sh_repl[jv[f]]) * a.K, e[f]);
+                }
+                float nv = 0.f;   // lane f: score of row p0 + f
+#pragma unroll
+                for (int f = 0; f < PF; ++f) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int u = 0; u < VEC; ++u)
+#pragma unroll
+                            for (int h = 0; h < NC; ++h) t = fmaf(d == 0 ? qa[c][u][h] : qb[c][u][h], e[f][c][u][h], t);
+                        acc += qok[c] ? t : 0.f;
+                    }
+                    const float n = sgn_scale * wave_sum(acc);
+                    if (lane == 0 && p0 + f < p_end) sh_neg[jv[f]] = n;
+                    nv = (lane == f) ? n : nv;
+                }
+                float c1l, c2l;
+                const float rs = onepass_coeff(a.loss, P1, nv, lane < min(PF, p_end - p0), ops, c1l, c2l);
+                if (rs != 1.f) {   // the running softmax maximum grew: rescale what has been accumulated
+#pragma unroll
+                    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+#pragma unroll
+                            for (int u = 0; u < VEC; ++u)
+#pragma unroll
+                                for (int h = 0; h < NC; ++h) { av1[dd][c][u][h] *= rs; av2[dd][c][u][h] *= rs; }
+                }
+                const bool two = a.loss.kind == AMDKGE_LOSS_SELF_ADVERSARIAL;   // only this loss has a second coefficient
+#pragma unroll
+                for (int f = 0; f < PF; ++f) {
+                    // rows past the end had invalid lanes: their coefficients are 0 and add nothing
+                    const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1l), f));
+                    const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2l), f));
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+#pragma unroll
+                        for (int u = 0; u < VEC; ++u)
+#pragma unroll
+                            for (int h = 0; h < NC; ++h) av1[d][c][u][h] = fmaf(c1, e[f][c][u][h], av1[d][c][u][h]);
+                    if (two) {
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+#pragma unroll
+                            for (int u = 0; u < VEC; ++u)
+#pragma unroll
+                                for (int h = 0; h < NC; ++h) av2[d][c][u][h] = fmaf(c2, e[f][c][u][h], av2[d][c][u][h]);
+                    }
+                }
+            }
+        }
+        ops.S = wave_sum(ops.S); ops.Lw = wave_sum(ops.Lw); ops.Zs = wave_sum(ops.Zs);
+        // s, p, o again for the gradient transform below (L2-hot)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int h = 0; h < NC; ++h) {
+                const fvec<VEC> vs = ldg<VEC>(rs + qoff[c] + h * a.k);
+                const fvec<VEC> vp = ldg<VEC>(rp + qoff[c] + h * a.k);
+                const fvec<VEC> vo = ldg<VEC>(ro + qoff[c] + h * a.k);
+#pragma unroll
+                for (int u = 0; u < VEC; ++u) { s[c][u][h] = vs.v[u]; p[c][u][h] = vp.v[u]; o[c][u][h] = vo.v[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) prep_rel<MODEL>(a.mc, p[c][u]);
+        }
+    }
+    for (int j0 = -1; j0 < (ONEPASS ? -1 : eta); j0 += PF) {
         float e[PF][CH][VEC][NC];
         int keepv[PF];
 #pragma unroll
@@ -326,7 +599,11 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 
     // ---- loss + dL/dscore (a12-a16): wave 0 of the slot, results through LDS -------------------
     float per = 0.f, dP = 0.f;
-    if (W == 1 || wv == 0) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP);
+    if constexpr (ONEPASS) {
+        // pairwise / absolute_margin have no transcendental and keep the generic evaluation
+        if (a.loss.kind == AMDKGE_LOSS_PAIRWISE || a.loss.kind == AMDKGE_LOSS_ABSOLUTE_MARGIN) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP);
+        else onepass_finish(a.loss, P, sh_neg, eta, lane, ops, per, dP);
+    } else if (W == 1 || wv == 0) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP);
     if constexpr (W > 1) {
         if (wv == 0 && lane == 0) sh_part[0] = dP;
         __syncthreads();
@@ -397,8 +674,32 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         }
     };
 
+    if constexpr (ONEPASS) {
+        // E_side = sum_j g_j e_j (g_j incl. score scale) from the two coefficient sums; the gradients of s, p, o are
+        // linear in it
+        float k1, k2;
+        onepass_kappa(a.loss, P, eta, ops, k1, k2);
+        k1 *= sgn_scale; k2 *= sgn_scale;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                float eo[NC], es[NC], ds[NC], dp[NC], dd[NC];
+#pragma unroll
+                for (int h = 0; h < NC; ++h) {
+                    eo[h] = k1 * av1[0][c][u][h] + k2 * av2[0][c][u][h];
+                    es[h] = k1 * av1[1][c][u][h] + k2 * av2[1][c][u][h];
+                }
+                grad_unit<MODEL>(s[c][u], p[c][u], eo, 1.f, ds, dp, dd);   // corruptions (s, p, e_j)
+#pragma unroll
+                for (int h = 0; h < NC; ++h) { gs[c][u][h] += ds[h]; gp[c][u][h] += dp[h]; }
+                grad_unit<MODEL>(es, p[c][u], o[c][u], 1.f, ds, dp, dd);   // corruptions (e_j, p, o)
+#pragma unroll
+                for (int h = 0; h < NC; ++h) { go[c][u][h] += dd[h]; gp[c][u][h] += dp[h]; }
+            }
+    }
     const bool do_neg_atomics = active && !(a.dbg & 1);
-    for (int j0 = 0; j0 < ((a.dbg & 4) ? 0 : eta); j0 += PF) {
+    for (int j0 = 0; j0 < ((ONEPASS || (a.dbg & 4)) ? 0 : eta); j0 += PF) {
         float e[PF][CH][VEC][NC];
         int keepv[PF];
         int64_t erv[PF];
