@@ -67,6 +67,7 @@ SIGNATURES = {
     "amdkge_stream_sync": (C.c_int, [P]),
     "amdkge_internal_k": (C.c_int, [C.c_int, C.c_int]),
     "amdkge_score": (C.c_int, [C.POINTER(Model), P, P, P, I64, P, P]),
+    "amdkge_platt_step": (C.c_int, [P, I64, P, I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, P, P]),
     "amdkge_sample_corruptions": (C.c_int, [P, I64, I32, I64, I64, U64, U64, I64, I64, P, P]),
     "amdkge_train_fwdbwd": (C.c_int, [C.POINTER(Model), C.POINTER(Loss), P, P, P, I64, I32, I64, I64, U64, U64,
                                       I64, I64, P, P, P, P, P, P, P]),

@@ -61,9 +61,53 @@ int score_dispatch(const amdkge_model* m, const float* d_ent, const float* d_rel
     }
 }
 
+// calibrate(): one evaluation of the Platt-scaling objective and its gradient for a batch of scores.
+// Replaces CalibrationLayer.call(training=1) (/root/reference/ampligraph/latent_features/layers/calibration/
+// calibrate.py:78-129) + the tape gradient of ScoringBasedEmbeddingModel.calibrate (:2108-2121):
+//   logit = -(w*s + b); loss = mean_i weight_i * (max(x,0) - x*z_i + log(1+exp(-|x|)))   (sigmoid_cross_entropy_with_logits)
+//   z = label_pos | label_neg, weight = weight_pos | weight_neg by the side the score came from.
+// out[0] += loss, out[1] += dloss/dw, out[2] += dloss/db   (fp64 accumulators)
+__global__ __launch_bounds__(256) void platt_kernel(const float* __restrict__ sp, int64_t np_, const float* __restrict__ sn,
+                                                    int64_t nn, float w, float b, float zp, float zn, float wp, float wn,
+                                                    double* out) {
+    const int64_t n = np_ + nn;
+    float l = 0.f, gw = 0.f, gb = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool pos = i < np_;
+        const float s = pos ? sp[i] : sn[i - np_];
+        const float z = pos ? zp : zn, wt = pos ? wp : wn;
+        const float x = -(w * s + b);
+        l += wt * (fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))));
+        const float d = wt * (1.f / (1.f + expf(-x)) - z);   // dloss_i/dx
+        gw += -s * d;
+        gb += -d;
+    }
+    const float inv = 1.f / (float)n;
+    l = wave_sum(l); gw = wave_sum(gw); gb = wave_sum(gb);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out + 0, (double)(l * inv));
+        atomicAdd(out + 1, (double)(gw * inv));
+        atomicAdd(out + 2, (double)(gb * inv));
+    }
+}
+
 }  // namespace kge
 
 using namespace kge;
+
+extern "C" int amdkge_platt_step(const float* d_scores_pos, int64_t n_pos, const float* d_scores_neg, int64_t n_neg, float w,
+                                 float b, float label_pos, float label_neg, float weight_pos, float weight_neg,
+                                 double* d_out3, void* stream) {
+    if (n_pos < 0 || n_neg < 0) return set_error(AMDKGE_EINVAL, "platt_step: negative size");
+    if (n_pos + n_neg == 0) return AMDKGE_OK;
+    if ((n_pos > 0 && !d_scores_pos) || (n_neg > 0 && !d_scores_neg) || !d_out3) return set_error(AMDKGE_EINVAL, "platt_step: NULL pointer");
+    const int64_t n = n_pos + n_neg;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(platt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_scores_pos, n_pos, d_scores_neg, n_neg, w, b,
+                       label_pos, label_neg, weight_pos, weight_neg, d_out3);
+    return check_launch("platt_step");
+}
 
 extern "C" int amdkge_score(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
                             int64_t n, float* d_scores, void* stream) {

@@ -183,6 +183,14 @@ class KgeEngine:
                                     _ptr(out), _stream()))
         return out
 
+    def platt_step(self, scores_pos, scores_neg, w, b, label_pos, label_neg, weight_pos, weight_neg):
+        """(loss, dloss/dw, dloss/db) of the Platt-scaling objective for one batch (amdkge_platt_step)."""
+        out = torch.zeros(3, dtype=torch.float64, device=self.device)
+        check(self.lib.amdkge_platt_step(_ptr(scores_pos), int(scores_pos.shape[0]), _ptr(scores_neg),
+                                         int(scores_neg.shape[0]), float(w), float(b), float(label_pos), float(label_neg),
+                                         float(weight_pos), float(weight_neg), _ptr(out), _stream()))
+        return [float(v) for v in out.tolist()]
+
     # ------------------------------------------------------------------ evaluate
     def _workspace(self, n):
         need = int(self.lib.amdkge_rank_workspace_bytes(C.byref(self.model), n))

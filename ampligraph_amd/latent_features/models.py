@@ -6,7 +6,7 @@ argument meaning and error behaviour; the Keras/TF machinery underneath is repla
 
 Intentional, documented differences: negatives come from a counter-based Philox stream
 keyed by (seed, step, row) instead of TF's stateful stream; tables are always HBM-resident, so
-`partitioning_k > 1` is rejected; FocusE / calibration are "next" rows and raise.
+`partitioning_k > 1` is rejected; FocusE is a "next" row and raises.
 """
 import json
 import os
@@ -420,13 +420,86 @@ class ScoringBasedEmbeddingModel:
         tab = self._entity_table() if embedding_type == "e" else self._engine.rel
         return tab[torch.as_tensor(idx).to(tab.device)].cpu().numpy()
 
-    # calibration is a "next" row; keep the reference's error for the uncalibrated case
-    def calibrate(self, *a, **kw):
-        raise NotImplementedError("calibrate(): Platt scaling is a 'next' row (SURVEY.md 8f)")
+    # ------------------------------------------------------------------------------------ calibration
+    def calibrate(self, X_pos, X_neg=None, positive_base_rate=None, batch_size=32, epochs=50, verbose=0):
+        """:1922-2122 -- Platt scaling of the scores (CalibrationLayer, layers/calibration/calibrate.py:11-129): two
+        scalars (w, b) fitted with Adam (Keras defaults) on sigmoid cross-entropy, one update per batch of positives.
+        With X_neg the negatives are iterated in lock step (their batch size adjusted so that both have the same
+        number of batches, :2033-2052); without, one corruption per positive is generated per step
+        (corruption_layer(inputs, num_ents, 1), :1886) -- here from the Philox stream keyed by (seed, step).
+        Scores, corruptions and the objective/gradient reduction are libamdkge kernels; the scalar Adam runs on host."""
+        import math
 
-    def predict_proba(self, *a, **kw):
+        import torch
+
+        assert self.is_fitted, "Model is not fit on the data yet!"
+        if self._spec is not None:
+            raise NotImplementedError("calibrate() with a row-sharded entity table")
+        self.is_calibrated = False
+        eng = self._engine
+        Xp = self._index_test(X_pos)
+        pos_size = int(Xp.shape[0])
+        neg_size = pos_size
+        batch_size = int(batch_size)
+        Xn = None
+        if X_neg is None:
+            assert positive_base_rate is not None, "Please provide the negatives or positive base rate!"
+        else:
+            Xn = self._index_test(X_neg)
+            neg_size = int(Xn.shape[0])
+            if positive_base_rate is None:
+                positive_base_rate = pos_size / (pos_size + neg_size)
+        if positive_base_rate is not None and (positive_base_rate <= 0 or positive_base_rate >= 1):
+            raise ValueError("positive_base_rate must be a value between 0 and 1.")
+        n_batches = max(1, -(-pos_size // batch_size))
+        bs_neg = batch_size
+        if Xn is not None and -(-neg_size // batch_size) != n_batches:
+            bs_neg = -(-neg_size // n_batches)
+        # CalibrationLayer.__init__ / call constants
+        w, b = 0.0, float(np.float32(math.log((neg_size + 1.0) / (pos_size + 1.0))))
+        label_pos, label_neg = (pos_size + 1.0) / (pos_size + 2.0), 1.0 / (neg_size + 2.0)
+        weight_neg = (1.0 - positive_base_rate) / positive_base_rate
+        dev = eng.device
+        Xpd = torch.as_tensor(Xp).to(dev)
+        sp_all = eng.score(Xpd) if pos_size else None          # the embeddings are frozen: score once
+        sn_all = eng.score(torch.as_tensor(Xn).to(dev)) if Xn is not None and neg_size else None
+        slots = [(0.0, 0.0), (0.0, 0.0)]
+        t = 0
+        for epoch in range(int(epochs)):
+            for bi in range(n_batches):
+                sp = sp_all[bi * batch_size:(bi + 1) * batch_size]
+                if sn_all is not None:
+                    sn = sn_all[bi * bs_neg:(bi + 1) * bs_neg]
+                else:
+                    neg = eng.sample_corruptions(Xpd[bi * batch_size:(bi + 1) * batch_size], 1, self.seed, t)
+                    sn = eng.score(neg)
+                if sp.shape[0] == 0:
+                    continue
+                t += 1
+                loss, gw, gb = eng.platt_step(sp, sn, w, b, label_pos, label_neg, sn.shape[0] / sp.shape[0], weight_neg)
+                alpha = 0.001 * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)   # tf.keras.optimizers.Adam() defaults
+                upd = []
+                for i, (p_, g_) in enumerate(((w, gw), (b, gb))):
+                    m, v = slots[i]
+                    m += (g_ - m) * (1.0 - 0.9)
+                    v += (g_ * g_ - v) * (1.0 - 0.999)
+                    slots[i] = (m, v)
+                    upd.append(p_ - m * alpha / (math.sqrt(v) + 1e-7))
+                w, b = upd
+            if verbose:
+                print(f"calibration epoch {epoch + 1}/{epochs} - loss: {loss:.6f}")
+        self.calibration_parameters = {"calib_w": float(w), "calib_b": float(b), "pos_size": pos_size,
+                                       "neg_size": neg_size, "positive_base_rate": float(positive_base_rate)}
+        self.is_calibrated = True
+
+    def predict_proba(self, x, batch_size=32, verbose=0, callbacks=None):
+        """:2124-2212: sigmoid(-(w * score + b)) of the calibrated model (CalibrationLayer.call(training=0))."""
         if not self.is_calibrated:
             raise RuntimeError("Model has not been calibrated. Please call `model.calibrate(...)` before predicting probabilities.")
+        s = self.predict(x, batch_size=batch_size).astype(np.float32)
+        w = np.float32(self.calibration_parameters["calib_w"])
+        b = np.float32(self.calibration_parameters["calib_b"])
+        return (1.0 / (1.0 + np.exp((w * s + b).astype(np.float64)))).astype(np.float32)
 
     # ------------------------------------------------------------------------------------ persistence
     def save_weights(self, filepath):
@@ -448,7 +521,8 @@ class ScoringBasedEmbeddingModel:
         meta = {"eta": self.eta, "k": self.k, "scoring_type": self.scoring_type, "seed": self.seed,
                 "optimizer": self.optimizer.get_config() if self.is_compiled else None,
                 "iterations": self.optimizer.iterations if self.is_compiled else 0,
-                "loss": {"name": self.loss.name, "params": self.loss._loss_parameters} if self.is_compiled else None}
+                "loss": {"name": self.loss.name, "params": self.loss._loss_parameters} if self.is_compiled else None,
+                "calibration": self.calibration_parameters if self.is_calibrated else None}
         with open(filepath + ".json", "w") as f:
             json.dump(meta, f)
 
@@ -467,4 +541,8 @@ class ScoringBasedEmbeddingModel:
                 self._engine.slots[kname].copy_(torch.as_tensor(v))
             if os.path.exists(filepath + ".json"):
                 self.optimizer.iterations = int(json.load(open(filepath + ".json")).get("iterations", 0))
+        if os.path.exists(filepath + ".json"):
+            cal = json.load(open(filepath + ".json")).get("calibration")
+            if cal:
+                self.calibration_parameters, self.is_calibrated = cal, True
         self.is_fitted = True

@@ -30,7 +30,7 @@ every score, loss, gradient and update is a libamdkge kernel.
 """
 import torch
 
-from .trainer import shard_bounds
+from .trainer import prefer_tiled, shard_bounds
 
 
 class ShardSpec:
@@ -113,7 +113,7 @@ class ShardedStepLoop:
         if self.capacity < 0:
             raise ValueError("engine table is smaller than the local shard")
         self.n_steps = 0
-        self.use_tiled = hasattr(engine, "train_step_tiled")
+        self.use_tiled = prefer_tiled(engine)
         self.kernel_hook = None   # bench.py: callable(phase) recording HIP events around the fused kernels
         engine.prepare_training(optimizer.name)
 

@@ -159,6 +159,14 @@ int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, cons
                             float* d_grad_ent, float* d_grad_rel, double* d_loss_sum, double* d_reg_loss,
                             float* d_pos_scores, float* d_neg_scores, void* d_work, void* stream);
 
+/* calibrate(): Platt-scaling objective + gradient for one batch of scores -- CalibrationLayer.call(training=1)
+ * (layers/calibration/calibrate.py:78-129) and the gradient of ScoringBasedEmbeddingModel.calibrate (:2108-2121).
+ *   logit_i = -(w*s_i + b); loss = mean_i weight_i * sigmoid_cross_entropy_with_logits(label_i, logit_i) over the
+ *   n_pos + n_neg scores (labels / weights by side).  d_out3 (3 doubles, device) += {loss, dloss/dw, dloss/db}. */
+int amdkge_platt_step(const float* d_scores_pos, int64_t n_pos, const float* d_scores_neg, int64_t n_neg,
+                      float w, float b, float label_pos, float label_neg, float weight_pos, float weight_neg,
+                      double* d_out3, void* stream);
+
 /* evaluate(): AbstractScoringLayer.get_ranks steps (1)+(2) (AbstractScoringLayer.py:156-258,
  * 309-366) for ONE side: quantised positive score vs the quantised score of every corruption.
  *   d_ent_ids : NULL = corruptions are table rows [ent_lo, ent_hi); else int32 [m] row ids

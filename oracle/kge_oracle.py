@@ -510,6 +510,56 @@ def train_step(state, model, pos, eta, loss_name, seed, step, n_ents=None, loss_
 
 
 # ----------------------------------------------------------------------------
+# calibration: CalibrationLayer (layers/calibration/calibrate.py:33-129)
+# ----------------------------------------------------------------------------
+def platt_init(pos_size, neg_size=0, positive_base_rate=None):
+    """w, b, (label_pos, label_neg), neg_size, base rate as CalibrationLayer.__init__ / call set them (:33-56,95-106)."""
+    neg_size = pos_size if neg_size == 0 else neg_size
+    if positive_base_rate is not None:
+        if positive_base_rate <= 0 or positive_base_rate >= 1:
+            raise ValueError("Positive_base_rate must be a value between 0 and 1.")
+    else:
+        assert pos_size > 0 and neg_size > 0, "Positive size must be > 0."
+        positive_base_rate = pos_size / (pos_size + neg_size)
+    b0 = float(F32(math.log((neg_size + 1.0) / (pos_size + 1.0))))
+    labels = (F32((pos_size + 1.0) / (pos_size + 2.0)), F32(1.0 / (neg_size + 2.0)))
+    return 0.0, b0, labels, neg_size, positive_base_rate
+
+
+def platt_proba(scores, w, b):
+    """CalibrationLayer.call(training=0) (:90,128-129): sigmoid(-(w*s + b))."""
+    x = -(F32(w) * np.asarray(scores, dtype=F32) + F32(b))
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(F32)
+
+
+def platt_loss_and_grads(scores_pos, scores_neg, w, b, labels, positive_base_rate):
+    """CalibrationLayer.call(training=1) (:84-127) and its gradient w.r.t. (w, b): weighted mean of
+    tf.nn.sigmoid_cross_entropy_with_logits(labels, logits) = max(x,0) - x*z + log(1+exp(-|x|))."""
+    sp, sn = np.asarray(scores_pos, dtype=np.float64), np.asarray(scores_neg, dtype=np.float64)
+    s = np.concatenate([sp, sn])
+    z = np.concatenate([np.full(sp.shape, float(labels[0])), np.full(sn.shape, float(labels[1]))])
+    wt = np.concatenate([np.full(sp.shape, sn.shape[0] / sp.shape[0]),
+                         np.full(sn.shape, (1.0 - positive_base_rate) / positive_base_rate)])
+    x = -(float(w) * s + float(b))
+    loss = np.mean(wt * (np.maximum(x, 0.0) - x * z + np.log1p(np.exp(-np.abs(x)))))
+    d = wt * (1.0 / (1.0 + np.exp(-x)) - z) / s.shape[0]
+    return float(loss), float(np.sum(-s * d)), float(np.sum(-d))
+
+
+def adam_scalar_step(params, grads, slots, t, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-7):
+    """tf.keras.optimizers.Adam() defaults (third-party, TF 2.15) on python floats: used by calibrate (:2062)."""
+    alpha = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    out = []
+    for i, (p, g) in enumerate(zip(params, grads)):
+        m, v = slots[i]
+        m += (g - m) * (1.0 - beta1)
+        v += (g * g - v) * (1.0 - beta2)
+        slots[i] = (m, v)
+        out.append(p - m * alpha / (math.sqrt(v) + eps))
+    return out
+
+
+# ----------------------------------------------------------------------------
 # a21/a22: host data semantics
 # ----------------------------------------------------------------------------
 def first_seen_index(triples):

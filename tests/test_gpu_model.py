@@ -333,3 +333,82 @@ def _reorder(emb_by_name, model, ents):
     tab = np.zeros_like(emb_by_name)
     tab[idx] = emb_by_name
     return tab
+
+
+# ------------------------------------------------------------------------------------ calibration (8f.3)
+def test_platt_kernel_parity(gpu_lib):
+    import torch
+
+    from ampligraph_amd.engine import KgeEngine
+
+    eng = KgeEngine("DistMult", 4, 5, 2)
+    rng = np.random.default_rng(3)
+    for npos, nneg in ((3, 3), (1000, 257), (5, 4000)):
+        sp = rng.normal(size=npos).astype(np.float32) * 3
+        sn = rng.normal(size=nneg).astype(np.float32) * 3 - 1
+        _, _, labels, neg_size, rate = O.platt_init(npos, nneg)
+        for w, b in ((0.0, 0.3), (-1.5, 0.2), (10.0, 10.0)):
+            got = eng.platt_step(torch.as_tensor(sp).cuda(), torch.as_tensor(sn).cuda(), w, b, labels[0], labels[1],
+                                 nneg / npos, (1 - rate) / rate)
+            ref = O.platt_loss_and_grads(sp, sn, w, b, labels, rate)
+            assert np.allclose(got, ref, rtol=2e-5, atol=1e-6), (npos, nneg, w, b, got, ref)
+    # the reference's own KAT through the kernel (test_calibrate.py:39-51)
+    got = eng.platt_step(torch.tensor([-2., 1., -1.]).cuda(), torch.tensor([10., 11., 12.]).cuda(), 10, 10, 6 / 7, 1 / 7, 1.0, 1.0)
+    assert np.around(np.float32(got[0]), 2) == np.float32(11.78)
+
+
+@pytest.mark.parametrize("with_negatives", [True, False])
+def test_calibrate_matches_oracle(gpu_lib, with_negatives):
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel
+
+    X = toy_graph(n=500, N=40, R=3)
+    m = ScoringBasedEmbeddingModel(eta=2, k=8, scoring_type="ComplEx", seed=1)
+    m.compile(optimizer="adam", loss="nll")
+    with pytest.raises(RuntimeError):
+        m.is_fitted = True
+        m.data_indexer = None
+        m.predict_proba(X[:3])
+    m.is_fitted = False
+    m.fit(X, batch_size=100, epochs=2, verbose=False)
+    Xp = X[:90]
+    rng = np.random.default_rng(5)
+    Xn = X[rng.permutation(len(X))[:140]].copy()
+    Xn[:, 2] = X[rng.integers(0, len(X), 140), 2]
+    bs, epochs = 32, 3
+    if with_negatives:
+        m.calibrate(Xp, Xn, batch_size=bs, epochs=epochs)
+    else:
+        with pytest.raises(AssertionError):
+            m.calibrate(Xp, batch_size=bs, epochs=epochs)
+        with pytest.raises(ValueError):
+            m.calibrate(Xp, positive_base_rate=1.5)
+        m.calibrate(Xp, positive_base_rate=0.3, batch_size=bs, epochs=epochs)
+    # oracle replay on the same scores
+    sp_all = m.predict(Xp)
+    npos = len(Xp)
+    if with_negatives:
+        sn_all, nneg = m.predict(Xn), len(Xn)
+        w, b, labels, _, rate = O.platt_init(npos, nneg)
+    else:
+        w, b, labels, _, rate = O.platt_init(npos, positive_base_rate=0.3)
+    nb = -(-npos // bs)
+    bsn = bs if not with_negatives or -(-len(Xn) // bs) == nb else -(-len(Xn) // nb)
+    e_all, r_all = m._engine.get_tables()
+    Xpi = m.data_indexer.get_indexes(Xp)
+    slots, t = [(0.0, 0.0), (0.0, 0.0)], 0
+    for ep in range(epochs):
+        for bi in range(nb):
+            sp = sp_all[bi * bs:(bi + 1) * bs]
+            if with_negatives:
+                sn = sn_all[bi * bsn:(bi + 1) * bsn]
+            else:
+                neg = O.generate_corruptions(Xpi[bi * bs:(bi + 1) * bs], e_all.shape[0], 1, 1, t)
+                sn = O.compute_scores("ComplEx", *O.lookup(e_all, r_all, neg), max_rel_size=r_all.shape[0])
+            t += 1
+            _, gw, gb = O.platt_loss_and_grads(sp, sn, w, b, labels, rate)
+            w, b = O.adam_scalar_step([w, b], [gw, gb], slots, t)
+    cp = m.calibration_parameters
+    assert abs(cp["calib_w"] - w) < 2e-5 and abs(cp["calib_b"] - b) < 2e-5, (cp, w, b)
+    pr = m.predict_proba(Xp)
+    assert np.allclose(pr, O.platt_proba(sp_all, cp["calib_w"], cp["calib_b"]), atol=1e-6)
+    assert pr.min() > 0 and pr.max() < 1

@@ -163,3 +163,29 @@ def test_metrics():
     assert abs(O.mrr_score(r) - (1 + 0.5 + 0.25 + 0.1) / 4) < 1e-12
     assert O.mr_score(r) == 17 / 4
     assert O.hits_at_n_score(r, 3) == 0.5
+
+
+def test_calibration_layer_kat():
+    """The reference's CalibrationLayer KATs (tests/ampligraph/latent_features/layers/calibrate/test_calibrate.py:16-61)."""
+    w, b, labels, neg_size, rate = O.platt_init(5, positive_base_rate=0.5)
+    assert neg_size == 5 and w == 0 and b == 0
+    w, b, labels, neg_size, rate = O.platt_init(5, 5)
+    assert rate == 0.5
+    with pytest.raises(ValueError):
+        O.platt_init(5, positive_base_rate=1.1)
+    with pytest.raises(AssertionError):
+        O.platt_init(0)
+    sp, sn = np.array([-2, 1, -1], np.float32), np.array([10, 11, 12], np.float32)
+    assert (np.around(O.platt_proba(sp, 10, 10), 2) == np.array([1, 0, 0.5], dtype=np.float32)).all()
+    for kw in (dict(neg_size=5), dict(positive_base_rate=0.5)):
+        _, _, labels, neg_size, rate = O.platt_init(5, **kw)
+        loss, gw, gb = O.platt_loss_and_grads(sp, sn, 10, 10, labels, rate)
+        assert np.around(np.float32(loss), 2) == np.float32(11.78)
+    # gradient of the restatement against finite differences
+    eps = 1e-6
+    l1 = O.platt_loss_and_grads(sp, sn, 10 + eps, 10, labels, rate)[0]
+    l0 = O.platt_loss_and_grads(sp, sn, 10 - eps, 10, labels, rate)[0]
+    assert abs((l1 - l0) / (2 * eps) - gw) < 1e-5 * max(1, abs(gw))
+    l1 = O.platt_loss_and_grads(sp, sn, 10, 10 + eps, labels, rate)[0]
+    l0 = O.platt_loss_and_grads(sp, sn, 10, 10 - eps, labels, rate)[0]
+    assert abs((l1 - l0) / (2 * eps) - gb) < 1e-5 * max(1, abs(gb))
