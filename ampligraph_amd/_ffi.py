@@ -22,6 +22,7 @@ LOSSES = {"pairwise": 0, "nll": 1, "absolute_margin": 2, "self_adversarial": 3, 
 OPTIMIZERS = {"sgd": 0, "adagrad": 1, "adam": 2}
 SIDE_S, SIDE_O = 1, 2
 RANK_STRATEGY = {"worst": 0, "best": 1, "middle": 2}
+FOCUS_NONLINEARITY = {"linear": 1, "tanh": 2, "sigmoid": 3, "softplus": 4}
 
 
 class AmdKgeLibraryError(RuntimeError):
@@ -40,7 +41,8 @@ class Model(C.Structure):
 
 
 class Loss(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("reduction_mean", C.c_int32), ("margin", C.c_float), ("alpha", C.c_float)]
+    _fields_ = [("kind", C.c_int32), ("reduction_mean", C.c_int32), ("margin", C.c_float), ("alpha", C.c_float),
+                ("focus_nonlinearity", C.c_int32), ("focus_beta", C.c_float), ("d_focus_w", C.c_void_p)]
 
 
 class Opt(C.Structure):

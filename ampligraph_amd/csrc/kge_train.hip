@@ -102,6 +102,8 @@ extern "C" int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* los
                                    void* stream) {
     if (int rc = validate_model(m)) return rc;
     if (!loss || loss->kind < 0 || loss->kind > AMDKGE_LOSS_MULTICLASS_NLL) return set_error(AMDKGE_EINVAL, "train: unknown loss kind");
+    if (loss->focus_nonlinearity < AMDKGE_FOCUS_OFF || loss->focus_nonlinearity > AMDKGE_FOCUS_SOFTPLUS || (loss->focus_nonlinearity && !loss->d_focus_w))
+        return set_error(AMDKGE_EINVAL, "train: bad FocusE settings (unknown non-linearity or NULL weights)");
     if (!d_ent || !d_rel || !d_grad_ent || !d_grad_rel || !d_loss_sum) return set_error(AMDKGE_EINVAL, "train: null table / gradient / loss pointer");
     if (B < 0 || eta < 1) return set_error(AMDKGE_EINVAL, "train: B must be >= 0 and eta >= 1");
     if (B == 0) return AMDKGE_OK;

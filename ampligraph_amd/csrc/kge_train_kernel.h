@@ -50,6 +50,20 @@ __device__ __forceinline__ float sigmoidf(float x) {
     return 1.f / (1.f + expf(-x));
 }
 
+// FocusE (ScoringBasedEmbeddingModel.py:396-406,492-513): y = f(x) * wgt, dfac = f'(x) * wgt.  The reference's
+// "softplus" is log(1 + 9999 e^x) with the custom gradient 1 - 1/(1 + 9999 e^x) (:499-510).
+__device__ __forceinline__ void focus_apply(int nl, float x, float wgt, float& y, float& dfac) {
+    float f, fp;
+    switch (nl) {
+        case AMDKGE_FOCUS_TANH: f = tanhf(x); fp = 1.f - f * f; break;
+        case AMDKGE_FOCUS_SIGMOID: f = sigmoidf(x); fp = f * (1.f - f); break;
+        case AMDKGE_FOCUS_SOFTPLUS: { const float e = 9999.f * expf(x); f = logf(1.f + e); fp = 1.f - 1.f / (1.f + e); } break;
+        default: f = x; fp = 1.f; break;
+    }
+    y = f * wgt;
+    dfac = fp * wgt;
+}
+
 // Loss.__call__ for one positive: neg scores in `sn[0..eta)` (LDS) are replaced by dL/dneg.
 // Returns per-sample loss and dL/dpos.  Executed by one whole wave (all lanes get the results).
 __device__ __forceinline__ void loss_and_dscore(const amdkge_loss& L, float P, float* sn, int eta, int lane,
@@ -275,8 +289,9 @@ __device__ __forceinline__ void onepass_finish(const amdkge_loss& L, float P, fl
 }
 
 __host__ __device__ inline size_t slot_lds_bytes(int eta, int W) {
-    // neg[eta+1], repl[eta+1], keep[eta+1], then part[W][eta+1] (W>1) or perm[eta+1] (W==1), rounded to 8 bytes
-    const size_t b = (size_t)(eta + 1) * (3 + (W > 1 ? W : 1)) * 4;
+    // neg[eta+1], repl[eta+1], keep[eta+1], then part[W][eta+1] (W>1) or perm[eta+1] (W==1), dfac[eta+1] (FocusE),
+    // rounded to 8 bytes
+    const size_t b = (size_t)(eta + 1) * (3 + (W > 1 ? W : 1) + 1) * 4;
     return (b + 7) & ~(size_t)7;
 }
 
@@ -321,6 +336,16 @@ void train_fwdbwd_kernel(TrainArgs a) {
     int* sh_repl = reinterpret_cast<int*>(base + (size_t)e1 * 4);
     int* sh_keep = reinterpret_cast<int*>(base + (size_t)e1 * 8);
     float* sh_part = reinterpret_cast<float*>(base + (size_t)e1 * 12);
+    float* sh_dfac = sh_part + (size_t)e1 * (W > 1 ? W : 1);
+    // FocusE weights of this positive (uniform per slot)
+    const int focus_nl = a.loss.focus_nonlinearity;
+    float focus_wp = 1.f, focus_wn = 1.f;
+    if (focus_nl) {
+        const float wi = a.loss.d_focus_w[i];
+        focus_wp = a.loss.focus_beta + (1.f - a.loss.focus_beta) * (1.f - wi);
+        focus_wn = a.loss.focus_beta + (1.f - a.loss.focus_beta) * wi;
+    }
+    float dPfac = 1.f;
     double* sh_loss = reinterpret_cast<double*>(smem + (size_t)SLOTS * per_slot);
 
     const int ps = a.triples[3 * i + 0], pp = a.triples[3 * i + 1], po = a.triples[3 * i + 2];
@@ -444,7 +469,8 @@ void train_fwdbwd_kernel(TrainArgs a) {
             }
             part += qok[c] ? acc : 0.f;
         }
-        const float P1 = sgn_scale * wave_sum(part);
+        float P1 = sgn_scale * wave_sum(part);
+        if (focus_nl) focus_apply(focus_nl, P1, focus_wp, P1, dPfac);
         if (lane == 0) sh_neg[eta] = P1;
         // corruptions ordered by side (object-replaced first): each of the two row loops below then has a
         // compile-time side, i.e. fixed accumulators and no per-row selects
@@ -480,6 +506,7 @@ void train_fwdbwd_kernel(TrainArgs a) {
                     load_row(a.ent + (int64_t)__builtin_amdgcn_readfirstlane(sh_repl[jv[f]]) * a.K, e[f]);
                 }
                 float nv = 0.f;   // lane f: score of row p0 + f
+                int jl = 0;       // lane f: its corruption index
 #pragma unroll
                 for (int f = 0; f < PF; ++f) {
                     float acc = 0.f;
@@ -493,11 +520,19 @@ void train_fwdbwd_kernel(TrainArgs a) {
                         acc += qok[c] ? t : 0.f;
                     }
                     const float n = sgn_scale * wave_sum(acc);
-                    if (lane == 0 && p0 + f < p_end) sh_neg[jv[f]] = n;
                     nv = (lane == f) ? n : nv;
+                    jl = (lane == f) ? jv[f] : jl;
+                }
+                const bool lane_valid = lane < min(PF, p_end - p0);
+                float dfl = 1.f;
+                if (focus_nl) focus_apply(focus_nl, nv, focus_wn, nv, dfl);
+                if (lane_valid) {
+                    sh_neg[jl] = nv;
+                    if (focus_nl) sh_dfac[jl] = dfl;
                 }
                 float c1l, c2l;
-                const float rs = onepass_coeff(a.loss, P1, nv, lane < min(PF, p_end - p0), ops, c1l, c2l);
+                const float rs = onepass_coeff(a.loss, P1, nv, lane_valid, ops, c1l, c2l);
+                c1l *= dfl; c2l *= dfl;   // d(neg')/d(neg) folded into the accumulation weights
                 if (rs != 1.f) {   // the running softmax maximum grew: rescale what has been accumulated
 #pragma unroll
                     for (int dd = 0; dd < 2; ++dd)
@@ -590,6 +625,20 @@ void train_fwdbwd_kernel(TrainArgs a) {
         }
     }
     slot_sync<W>();
+    if constexpr (!ONEPASS) {
+        if (focus_nl) {   // FocusE on the two-pass path: transform the scores in place, keep d(score')/d(score)
+            for (int j = ts; j < eta; j += TS) {
+                float y, dfc;
+                focus_apply(focus_nl, sh_neg[j], focus_wn, y, dfc);
+                sh_neg[j] = y; sh_dfac[j] = dfc;
+            }
+            float y;
+            focus_apply(focus_nl, sh_neg[eta], focus_wp, y, dPfac);
+            slot_sync<W>();
+            if (ts == 0) sh_neg[eta] = y;
+            slot_sync<W>();
+        }
+    }
     const float P = sh_neg[eta];
 
     if (active && a.neg_scores)
@@ -609,6 +658,11 @@ void train_fwdbwd_kernel(TrainArgs a) {
         __syncthreads();
         dP = sh_part[0];
     } else {
+        slot_sync<W>();
+    }
+    if (focus_nl) {   // chain rule through the FocusE transform
+        dP *= dPfac;
+        for (int j = ts; j < eta; j += TS) sh_neg[j] *= sh_dfac[j];
         slot_sync<W>();
     }
     if (ts == 0) sh_loss[slot] = active ? (double)per : 0.0;

@@ -355,6 +355,8 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     if (int rc = validate_model(m)) return rc;
     if (int rc = validate_opt(opt)) return rc;
     if (!loss || loss->kind < 0 || loss->kind > AMDKGE_LOSS_MULTICLASS_NLL) return set_error(AMDKGE_EINVAL, "train_step_tiled: unknown loss kind");
+    if (loss->focus_nonlinearity < AMDKGE_FOCUS_OFF || loss->focus_nonlinearity > AMDKGE_FOCUS_SOFTPLUS || (loss->focus_nonlinearity && !loss->d_focus_w))
+        return set_error(AMDKGE_EINVAL, "train_step_tiled: bad FocusE settings (unknown non-linearity or NULL weights)");
     if (!d_ent || !d_rel || !d_grad_rel || !d_loss_sum || !d_work) return set_error(AMDKGE_EINVAL, "train_step_tiled: NULL pointer");
     if (B < 0 || B >= (1ll << 30) || eta < 1) return set_error(AMDKGE_EINVAL, "train_step_tiled: B must be in [0, 2^30) and eta >= 1");
     TiledPlan p;

@@ -6,7 +6,8 @@ argument meaning and error behaviour; the Keras/TF machinery underneath is repla
 
 Intentional, documented differences: negatives come from a counter-based Philox stream
 keyed by (seed, step, row) instead of TF's stateful stream; tables are always HBM-resident, so
-`partitioning_k > 1` is rejected; FocusE is a "next" row and raises.
+`partitioning_k > 1` is rejected; FocusE's structural weight really decays per epoch (in the reference the
+tf.function captures the first epoch's value at trace time).
 """
 import json
 import os
@@ -215,11 +216,27 @@ class ScoringBasedEmbeddingModel:
         if partitioning_k != 1:
             raise NotImplementedError("partitioning_k > 1: tables are HBM-resident on MI355X, graph partitioning "
                                       "with disk swapping is out of scope (SURVEY.md section 2, rows 15-16)")
-        if focusE:
-            raise NotImplementedError("FocusE numeric-edge weighting is a 'next' row (SURVEY.md 8f)")
         if validation_split:
             raise NotImplementedError("validation_split: pass validation_data explicitly")
         X = _load_triples(x)
+        # FocusE (:714-790): active only when asked for AND the data carries numeric columns behind s, p, o
+        self.use_focusE = bool(focusE) and X.shape[1] > 3
+        focus_w = None
+        if self.use_focusE:
+            assert isinstance(focusE_params, dict), "focusE parameters need to be in a dict!"
+            nl = focusE_params.get("non_linearity", "linear")
+            if nl not in _ffi.FOCUS_NONLINEARITY:
+                raise ValueError("Invalid focusE non-linearity")
+            stop_epoch = focusE_params.get("stop_epoch", 251)
+            assert stop_epoch >= 0, "Invalid value for focusE stop_epoch: expected a value >=0 but got {}".format(stop_epoch)
+            structural_wt = focusE_params.get("structural_wt", 0.001)
+            assert 0 <= structural_wt <= 1, "Invalid focusE 'structural_wt' passed! It has to belong to [0,1]."
+            self.focusE_params = {"non_linearity": nl, "stop_epoch": stop_epoch, "structural_wt": structural_wt}
+            if self._sharding == "rows" and self._dist() is not None:
+                raise NotImplementedError("FocusE with a row-sharded entity table")
+            focus_w = np.ascontiguousarray(X[:, 3:].astype(np.float32).mean(axis=1), dtype=np.float32)   # :360
+        elif X.shape[1] > 3:
+            print("Data shape is {}: not only triples were given, but focusE is not active!".format(X.shape[1]))
         if self.data_indexer is None or not self.is_fitted:
             self.data_indexer = DataIndexer(X)
             Xi = self.data_indexer.get_indexes(X[:, :3])
@@ -233,6 +250,11 @@ class ScoringBasedEmbeddingModel:
         self._full_ent = None
         train = torch.as_tensor(np.ascontiguousarray(Xi, dtype=np.int32)).to(eng.device)
         n = int(train.shape[0])
+        focus_dev = None
+        if focus_w is not None:
+            if focus_w.shape[0] != n:
+                raise ValueError("FocusE: rows with unknown entities/relations were dropped; weights no longer align")
+            focus_dev = torch.as_tensor(focus_w).to(eng.device)
         batch_size = int(batch_size)
         steps = (n + batch_size - 1) // batch_size
         self.history = History()
@@ -248,9 +270,18 @@ class ScoringBasedEmbeddingModel:
         for epoch in range(int(initial_epoch), int(epochs)):
             self.current_epoch = epoch
             loop.reset_loss()
+            focus = None
+            if focus_dev is not None:   # update_focusE_params (:536-542): linear decay of the structural weight
+                fp = self.focusE_params
+                if fp["stop_epoch"] > 0:
+                    fp["structural_wt"] = max(1.0 - epoch / fp["stop_epoch"], 0.001)
             for step in range(steps):
                 b0 = step * batch_size
-                loop.step(train[b0:b0 + batch_size], epoch * steps + step)
+                if focus_dev is not None:
+                    focus = (focus_dev[b0:b0 + batch_size], self.focusE_params["structural_wt"], self.focusE_params["non_linearity"])
+                    loop.step(train[b0:b0 + batch_size], epoch * steps + step, focus)
+                else:
+                    loop.step(train[b0:b0 + batch_size], epoch * steps + step)
             logs = {"loss": loop.mean_batch_loss()}
             validate = (epoch >= (validation_burn_in - 1) and validation_data is not None
                         and (epoch + 1) % int(validation_freq) == 0)

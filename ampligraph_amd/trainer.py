@@ -53,12 +53,23 @@ class StepLoop:
         self.kernel_hook = None   # bench.py: callable(phase) recording HIP events around the fused kernel
         engine.prepare_training(optimizer.name)
 
-    def step(self, global_batch, rng_step):
+    def step(self, global_batch, rng_step, focus=None):
         """global_batch: (Bg,3) int32 device tensor holding the WHOLE batch (same on every rank);
-        rng_step: the step counter the negatives are keyed by."""
+        rng_step: the step counter the negatives are keyed by; focus: None or (w fp32 device tensor [Bg], beta,
+        non-linearity name) for FocusE (ScoringBasedEmbeddingModel.py:396-406)."""
         eng = self.engine
         bg = int(global_batch.shape[0])
         lo, hi = shard_bounds(bg, self.world, self.rank)
+        if focus is not None:
+            from . import _ffi
+
+            fw = focus[0][lo:hi].contiguous()   # kept alive until the launches below are enqueued
+            self.loss_ffi.focus_nonlinearity = _ffi.FOCUS_NONLINEARITY[focus[2]]
+            self.loss_ffi.focus_beta = float(focus[1])
+            self.loss_ffi.d_focus_w = fw.data_ptr()
+        else:
+            self.loss_ffi.focus_nonlinearity = 0
+            self.loss_ffi.d_focus_w = None
         self.optimizer.iterations += 1
         lam = self.reg.lam if self.reg is not None else 0.0
         opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2)

@@ -64,7 +64,15 @@ typedef struct amdkge_loss {
     int32_t reduction_mean; /* 0 = "sum" (default), 1 = "mean" over the corruptions */
     float margin;           /* pairwise / absolute_margin / self_adversarial */
     float alpha;            /* self_adversarial sampling temperature */
+    /* FocusE numeric-edge weighting (ScoringBasedEmbeddingModel.py:342-368,396-406,468-542): the scores entering the
+     * loss become  pos' = f(pos) * (beta + (1-beta)(1-w_i)),  neg'_ji = f(neg_ji) * (beta + (1-beta) w_i)  with
+     * w_i = d_focus_w[i] (mean of the numeric columns of positive i).  0 = off. */
+    int32_t focus_nonlinearity; /* AMDKGE_FOCUS_* */
+    float focus_beta;           /* structural weight beta in [0,1] */
+    const float* d_focus_w;     /* device fp32 [B] (this launch's positives); ignored when focus_nonlinearity == 0 */
 } amdkge_loss;
+
+enum { AMDKGE_FOCUS_OFF = 0, AMDKGE_FOCUS_LINEAR = 1, AMDKGE_FOCUS_TANH = 2, AMDKGE_FOCUS_SIGMOID = 3, AMDKGE_FOCUS_SOFTPLUS = 4 };
 
 /* Optimizer + regulariser for one table sweep: optimizers.py:136-168, regularizers.py:14-37 */
 typedef struct amdkge_opt {

@@ -436,8 +436,31 @@ class TrainState:
             self.slots = {}
 
 
+def focus_transform(x, weight, non_linearity):
+    """FocusE: y = f(x) * weight and dy/dx (ScoringBasedEmbeddingModel.py:396-406, non-linearities :492-513; the
+    reference's "softplus" is log(1 + 9999 e^x) with custom gradient 1 - 1/(1 + 9999 e^x))."""
+    x = np.asarray(x, dtype=F32).astype(np.float64)
+    if non_linearity == "linear":
+        f, fp = x, np.ones_like(x)
+    elif non_linearity == "tanh":
+        f = np.tanh(x); fp = 1.0 - f * f
+    elif non_linearity == "sigmoid":
+        f = 1.0 / (1.0 + np.exp(-x)); fp = f * (1.0 - f)
+    elif non_linearity == "softplus":
+        e = 9999.0 * np.exp(x); f = np.log(1.0 + e); fp = 1.0 - 1.0 / (1.0 + e)
+    else:
+        raise ValueError("Invalid focusE non-linearity")
+    return (f * weight).astype(F32), fp * weight
+
+
+def focus_weights(w_mean, beta, eta):
+    """compute_focusE_weights (:342-368): (weights_pos (B,), weights_neg (B*eta,) in corruption-row order j*B+i)."""
+    w = np.asarray(w_mean, dtype=np.float64)
+    return beta + (1.0 - beta) * (1.0 - w), np.tile(beta + (1.0 - beta) * w, eta)
+
+
 def dense_gradients(model, ent, rel, pos, negs, eta, loss_name, loss_params=None,
-                    reduction="sum", max_rel_size=None, reg=None):
+                    reduction="sum", max_rel_size=None, reg=None, focus=None):
     """Forward + backward of ScoringBasedEmbeddingModel.train_step (:370-429): returns
     (total loss fp32, G_ent fp64, G_rel fp64).  Duplicate row ids are summed (Keras
     IndexedSlices dedup).  reg = None or dict(p=..., lam_e=..., lam_r=...) following
@@ -448,7 +471,14 @@ def dense_gradients(model, ent, rel, pos, negs, eta, loss_name, loss_params=None
     ns, npred, no = lookup(ent, rel, negs)
     sp = compute_scores(model, s, p, o, max_rel_size=max_rel_size)
     sn = compute_scores(model, ns, npred, no, max_rel_size=max_rel_size)
+    fac_p = fac_n = None
+    if focus is not None:   # focus = (per-positive mean weight (B,), beta, non-linearity name)
+        wp, wn = focus_weights(focus[0], focus[1], eta)
+        sp, fac_p = focus_transform(sp, wp, focus[2])
+        sn, fac_n = focus_transform(sn, wn, focus[2])
     total, per, dP, dN = loss_and_grads(loss_name, sp, sn, eta, loss_params, reduction)
+    if focus is not None:
+        dP, dN = dP * fac_p, dN * fac_n
     Ge = np.zeros(ent.shape, dtype=np.float64)
     Gr = np.zeros(rel.shape, dtype=np.float64)
     for tri, (a, b, c), g in ((pos, (s, p, o), dP), (negs, (ns, npred, no), dN)):
@@ -498,13 +528,13 @@ def apply_optimizer(state, Ge, Gr, beta1=0.9, beta2=0.999, eps=1e-7):
 
 def train_step(state, model, pos, eta, loss_name, seed, step, n_ents=None, loss_params=None,
                reduction="sum", max_rel_size=None, reg=None, row_offset=0, b_global=None,
-               negs=None):
+               negs=None, focus=None):
     if n_ents is None:
         n_ents = state.ent.shape[0]
     if negs is None:
         negs = generate_corruptions(pos, n_ents, eta, seed, step, row_offset, b_global)
     loss, Ge, Gr, _ = dense_gradients(model, state.ent, state.rel, pos, negs, eta, loss_name,
-                                      loss_params, reduction, max_rel_size, reg)
+                                      loss_params, reduction, max_rel_size, reg, focus)
     apply_optimizer(state, Ge, Gr)
     return loss
 

@@ -493,3 +493,45 @@ def test_rank_mfma_kernel_bitwise_equals_valu_kernel(gpu_lib, model, k, N, n, mo
             assert (c_mfma == c_valu).all(), (model, side, np.abs(c_mfma - c_valu).max())
             m = N if ent_ids is None else int(ent_ids.shape[0])
             assert (c_mfma.sum(1) <= m).all() and c_mfma.min() >= 0
+
+
+# -------------------------------------------------------------------------------- FocusE (a23)
+@pytest.mark.parametrize("nl", ["linear", "tanh", "sigmoid", "softplus"])
+@pytest.mark.parametrize("model,k,path", [("ComplEx", 32, "tiled"), ("DistMult", 7, "atomic"), ("TransE", 32, "tiled"),
+                                          ("RotatE", 16, "atomic"), ("HolE", 16, "tiled")])
+def test_focuse_gradients_parity(gpu_lib, nl, model, k, path):
+    """FocusE score transform + chain rule inside the fused kernels (single-pass, two-pass staged, atomic) == oracle."""
+    from ampligraph_amd import _ffi
+
+    N, R, B, eta = 120, 4, 150, 5
+    # distance models: keep |score| ~ 1 so that tanh / sigmoid are not saturated (f' == 0 in fp32 otherwise)
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.5 if model in ("ComplEx", "DistMult", "HolE") else 0.03)
+    rng = np.random.default_rng(12)
+    X = rand_triples(rng, B, N, R)
+    wmean = rng.random(B).astype(np.float32)
+    beta = 0.37
+    wd = dev(wmean)
+    for loss in ("self_adversarial", "nll", "pairwise"):
+        ld = loss_desc(loss)
+        ld.focus_nonlinearity = _ffi.FOCUS_NONLINEARITY[nl]
+        ld.focus_beta = beta
+        ld.d_focus_w = wd.data_ptr()
+        eng.prepare_training("adam")
+        eng.loss_acc.zero_()
+        ps = torch.empty(B, dtype=torch.float32, device="cuda")
+        ns = torch.empty(B * eta, dtype=torch.float32, device="cuda")
+        if path == "tiled":
+            d = _ffi.Opt(_ffi.OPTIMIZERS["adam"], 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, 1)
+            eng.train_step_tiled(dev(X), eta, ld, d, 3, 7, grad_only=True, pos_scores=ps, neg_scores=ns)
+        else:
+            eng.train_fwdbwd(dev(X), eta, ld, 3, 7, pos_scores=ps, neg_scores=ns)
+        torch.cuda.synchronize()
+        negs = O.generate_corruptions(X, N, eta, 3, 7)
+        total, Te, Tr, (sp, sn, per) = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, "sum", R,
+                                                         focus=(wmean, beta, nl))
+        assert np.allclose(ps.cpu().numpy(), sp, rtol=2e-5, atol=2e-5 * np.abs(sp).max()), (loss, nl)
+        assert np.allclose(ns.cpu().numpy(), sn, rtol=2e-5, atol=2e-5 * np.abs(sn).max())
+        L = float(eng.loss_acc[0].item())
+        assert abs(L - float(per.astype(np.float64).sum())) <= 2e-5 * max(1.0, abs(L)), (loss, nl, L)
+        assert_grads_close(eng.g_ent.cpu().numpy(), Te, tol=4e-5)
+        assert_grads_close(eng.g_rel.cpu().numpy(), Tr, tol=4e-5)

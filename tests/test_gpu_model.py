@@ -412,3 +412,49 @@ def test_calibrate_matches_oracle(gpu_lib, with_negatives):
     pr = m.predict_proba(Xp)
     assert np.allclose(pr, O.platt_proba(sp_all, cp["calib_w"], cp["calib_b"]), atol=1e-6)
     assert pr.min() > 0 and pr.max() < 1
+
+
+# ------------------------------------------------------------------------------------ FocusE through fit()
+@pytest.mark.parametrize("model,nl,stop", [("ComplEx", "sigmoid", 4), ("TransE", "linear", 0), ("DistMult", "softplus", 251)])
+def test_fit_focuse_matches_oracle(gpu_lib, model, nl, stop):
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers
+
+    X = toy_graph(n=400, N=40, R=3)
+    rng = np.random.default_rng(8)
+    W = rng.random((len(X), 2)).astype(np.float32)
+    X4 = np.concatenate([X, W.astype(str)], 1)
+    k, eta, bs, epochs, lr = 8, 3, 128, 3, 1e-2
+    m = ScoringBasedEmbeddingModel(eta=eta, k=k, scoring_type=model, seed=6)
+    m.compile(optimizer=optimizers.get("adam", {"learning_rate": lr}), loss="nll")
+    fp = {"non_linearity": nl, "stop_epoch": stop, "structural_wt": 0.3}
+    h = m.fit(X4, batch_size=bs, epochs=epochs, verbose=False, focusE=True, focusE_params=fp)
+    with pytest.raises(ValueError):
+        m.fit(X4, batch_size=bs, epochs=1, verbose=False, focusE=True, focusE_params={"non_linearity": "relu"})
+    # oracle replay with the same schedule
+    from ampligraph_amd.latent_features.initializers import initialise
+
+    ents, rels = O.first_seen_index(X)
+    Xi = O.to_indexes(X, ents, rels)
+    N, R, K = len(ents), len(rels), O.internal_k(model, k)
+    rg = np.random.Generator(np.random.PCG64(6))
+    st = O.TrainState(initialise("glorot_uniform", (N, K), rg), initialise("glorot_uniform", (R, K), rg), "adam", lr)
+    wmean = W.astype(np.float32).mean(axis=1)
+    steps = -(-len(Xi) // bs)
+    hist = []
+    for ep in range(epochs):
+        beta = max(1.0 - ep / stop, 0.001) if stop > 0 else 0.3
+        tot = 0.0
+        for s_ in range(steps):
+            sl = slice(s_ * bs, (s_ + 1) * bs)
+            tot += float(O.train_step(st, model, Xi[sl], eta, "nll", 6, ep * steps + s_, max_rel_size=R,
+                                      focus=(wmean[sl], beta, nl)))
+        hist.append(tot / steps)
+    assert np.allclose(h.history["loss"], hist, rtol=3e-4), (h.history["loss"], hist)
+    e_all, _ = m._engine.get_tables()
+    close = np.abs(e_all - st.ent) <= 1e-4 + 1e-3 * np.abs(st.ent)
+    assert close.mean() > 0.99, close.mean()
+    # 3-column data with focusE=True: silently off, like the reference (:767-768)
+    m2 = ScoringBasedEmbeddingModel(eta=eta, k=k, scoring_type=model, seed=6)
+    m2.compile(optimizer="adam", loss="nll")
+    m2.fit(X, batch_size=bs, epochs=1, verbose=False, focusE=True)
+    assert m2.use_focusE is False
