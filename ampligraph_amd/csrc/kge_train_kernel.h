@@ -308,11 +308,10 @@ __device__ __forceinline__ void slot_sync() {
 
 // LDS layout per slot: float neg[eta+1] (index eta = the positive); int repl[eta]; int keep[eta];
 // float part[W][eta+1] (W>1 only).  Tail of the block: double blockloss[SLOTS].
-// The single-pass variants are bound by the latency of the random row gathers: ask for 4 workgroups (16 waves) per CU,
-// i.e. <= 128 VGPRs, where the row fits one quad per lane.
+// (Forcing 4 waves/SIMD with __launch_bounds__(256, 4) was measured: no gain over the natural 3 -- the row gather is
+// bound by fabric bandwidth, not by loads in flight -- and it costs spills.)
 template <int MODEL, int VEC, int W, int CH, bool STAGE = false>
-__global__ __launch_bounds__(256, (STAGE && W == 1 && CH == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX)) ? 4 : 1)
-void train_fwdbwd_kernel(TrainArgs a) {
+__global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     using T = ModelTraits<MODEL>;
     constexpr int NC = T::NC;
     constexpr int SLOTS = 4 / W;          // positives per 256-thread block
