@@ -1,0 +1,141 @@
+"""Parity at BASELINE.json's full sizes (the oracle is too slow there) through size-independent properties:
+independent kernels must agree with each other, invariants of the domain must hold.
+C1 TransE k=50 eta=5, C2 ComplEx k=200 eta=20, C3 DistMult k=400 eta=30 + 1-vs-all filtered eval (WN18RR shape),
+C4 ComplEx k=200 on 123 182 entities, C5 row width (RotatE k=1000, eta=64) on a cut-down entity count."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(model, k, N, R, seed=0):
+    from ampligraph_amd.engine import KgeEngine
+
+    eng = KgeEngine(model, k, N, R, max_rel_size=R)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    lim = float(np.sqrt(6.0 / (N + eng.K)))
+    eng.ent.copy_((torch.rand(N, eng.K, device="cuda", generator=g) * 2 - 1) * lim)
+    eng.rel.copy_((torch.rand(R, eng.K, device="cuda", generator=g) * 2 - 1) * float(np.sqrt(6.0 / (R + eng.K))))
+    return eng
+
+
+def _triples(n, N, R, seed=1):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.stack([torch.randint(0, N, (n,), device="cuda", generator=g), torch.randint(0, R, (n,), device="cuda", generator=g),
+                        torch.randint(0, N, (n,), device="cuda", generator=g)], 1).to(torch.int32).contiguous()
+
+
+def _loss(name, **kw):
+    from ampligraph_amd import _ffi
+
+    d = {"pairwise": (0, 1.0, 0.0), "nll": (1, 0.0, 0.0), "self_adversarial": (3, 3.0, 0.5), "multiclass_nll": (4, 0.0, 0.0)}[name]
+    return _ffi.Loss(d[0], 0, d[1], d[2])
+
+
+def _rows_close(a, b, tol):
+    scale = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-6 * float(b.abs().max()) + 1e-30)
+    return float(((a - b).abs() / scale).max()) < tol
+
+
+@pytest.mark.parametrize("model,k,eta,N,R,B,loss", [("ComplEx", 200, 20, 14505, 237, 10000, "self_adversarial"),    # C2
+                                                     ("DistMult", 400, 30, 40943, 11, 10000, "multiclass_nll"),      # C3
+                                                     ("TransE", 52, 5, 14505, 237, 10000, "pairwise"),               # C1 (k padded to 52)
+                                                     ("ComplEx", 200, 20, 123182, 37, 8192, "nll")])                 # C4
+def test_fullsize_train_paths_agree(gpu_lib, model, k, eta, N, R, B, loss):
+    """The owner-computes pair (gradient-only form) and the atomic-scatter kernel are independent implementations of the
+    same step: loss, scores and both dense gradients must agree at full size; then the in-place pair == gradient-only
+    pair + dense sweep."""
+    from ampligraph_amd import _ffi
+
+    eng = _engine(model, k, N, R)
+    X = _triples(B, N, R)
+    ld = _loss(loss)
+    opt = _ffi.Opt(_ffi.OPTIMIZERS["adam"], 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 1)
+    eng.prepare_training("adam")
+    ps1, ns1 = torch.empty(B, device="cuda"), torch.empty(B * eta, device="cuda")
+    eng.loss_acc.zero_()
+    eng.train_fwdbwd(X, eta, ld, 5, 9, pos_scores=ps1, neg_scores=ns1)
+    l1 = float(eng.loss_acc[0])
+    ge1, gr1 = eng.g_ent.clone(), eng.g_rel.clone()
+    eng.g_flat.zero_()
+    eng.loss_acc.zero_()
+    ps2, ns2 = torch.empty(B, device="cuda"), torch.empty(B * eta, device="cuda")
+    eng.train_step_tiled(X, eta, ld, opt, 5, 9, grad_only=True, pos_scores=ps2, neg_scores=ns2)
+    l2 = float(eng.loss_acc[0])
+    assert abs(l1 - l2) <= 2e-5 * abs(l1), (l1, l2)
+    assert torch.allclose(ps1, ps2, rtol=2e-5, atol=2e-5 * float(ps1.abs().max()))
+    assert torch.allclose(ns1, ns2, rtol=2e-5, atol=2e-5 * float(ns1.abs().max()))
+    assert _rows_close(eng.g_ent, ge1, 2e-4) and _rows_close(eng.g_rel, gr1, 2e-4)
+    if model == "TransE":   # translation invariance: d/ds + d/do = 0 for every triple => column sums of the entity gradient vanish
+        assert float(eng.g_ent.sum(0).abs().max()) < 1e-3 * float(eng.g_ent.abs().sum(0).max())
+    # in-place pair vs gradient-only pair + dense sweep (same gradient buffers as input)
+    ent0, rel0 = eng.ent.clone(), eng.rel.clone()
+    eng.opt_step(opt)
+    ent_a, rel_a = eng.ent.clone(), eng.rel.clone()
+    eng.ent.copy_(ent0); eng.rel.copy_(rel0)
+    for t in eng.slots.values():
+        t.zero_()
+    eng.train_step_tiled(X, eta, ld, opt, 5, 9)
+    assert float((eng.ent - ent_a).abs().max()) < 2.1e-3   # one Adam step moves at most lr (sign flips of ~0 gradients)
+    assert float(((eng.ent - ent_a).abs() < 2e-6).float().mean()) > 0.995
+    assert float(((eng.rel - rel_a).abs() < 2e-6).float().mean()) > 0.99
+    assert float(eng.g_rel.abs().max()) == 0.0
+
+
+def test_fullsize_c3_eval_invariants(gpu_lib, monkeypatch):
+    """C3: DistMult k=400, 40 943 entities, 2 924 test triples, both sides (MFMA path)."""
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.datasets import make_synthetic_kg
+    from ampligraph_amd.datasets.filters import FilterIndex
+
+    d = make_synthetic_kg("synth-wn18rr")
+    N, R = d["n_ents"], d["n_rels"]
+    eng = _engine("DistMult", 400, N, R)
+    test = d["test"]
+    Xd = torch.as_tensor(test).cuda()
+    fi = FilterIndex([d["train"], d["valid"], test], N, R)
+    res = {}
+    for side, nm, rng_fn, ids in ((_ffi.SIDE_S, "s", fi.subject_ranges, fi.s_ids), (_ffi.SIDE_O, "o", fi.object_ranges, fi.o_ids)):
+        lo, hi = rng_fn(test)
+        flt = (torch.as_tensor(lo).cuda(), torch.as_tensor(hi).cuda(), torch.as_tensor(ids).cuda())
+        monkeypatch.delenv("AMDKGE_RANK_PATH", raising=False)
+        r_w, c_mfma, sub = eng.rank_side(Xd, side, "worst", flt)
+        monkeypatch.setenv("AMDKGE_RANK_PATH", "valu")
+        c_valu = eng.rank_side(Xd, side, "worst")[1]
+        monkeypatch.delenv("AMDKGE_RANK_PATH", raising=False)
+        assert torch.equal(c_mfma, c_valu)                       # exact-fp32 MFMA == VALU chain, bit for bit
+        r_b = eng.rank_side(Xd, side, "best", flt)[0]
+        r_m = eng.rank_side(Xd, side, "middle", flt)[0]
+        r_u = eng.rank_side(Xd, side, "worst")[0]
+        assert bool((r_b <= r_m).all()) and bool((r_m <= r_w).all()) and bool((r_w <= r_u).all())
+        assert int(r_b.min()) >= 1 - int(sub.max()) and int(r_u.max()) <= N + 1
+        assert bool((c_mfma.sum(1) <= N).all())
+        # the test triple itself is in its own filter: its own corruption (score == positive) is always subtracted
+        assert bool((sub >= 1).all())
+        res[nm] = r_w
+
+
+def test_fullsize_c5_row_width_scores_agree(gpu_lib):
+    """C5 row width (RotatE k=1000 -> 8 000-byte rows, eta=64) on 200 000 entities: the fused kernel's scores ==
+    the stand-alone score kernel on the corruptions the stand-alone sampler materialises (three independent kernels)."""
+    from ampligraph_amd import _ffi
+
+    N, R, k, eta, B = 200_000, 100, 1000, 64, 2048
+    eng = _engine("RotatE", k, N, R)
+    X = _triples(B, N, R, seed=3)
+    eng.prepare_training("sgd")
+    ps, ns = torch.empty(B, device="cuda"), torch.empty(B * eta, device="cuda")
+    assert not eng.tiled_supported(B, eta)      # k > 512: atomic path (multi-wave slot geometry)
+    eng.train_fwdbwd(X, eta, _loss("self_adversarial"), 21, 4, pos_scores=ps, neg_scores=ns)
+    negs = eng.sample_corruptions(X, eta, 21, 4)
+    assert bool(((negs[:, 0] == X[:, 0].repeat(eta)) ^ (negs[:, 2] == X[:, 2].repeat(eta)) | (negs[:, 0] == X[:, 0].repeat(eta))).all())
+    ref_p, ref_n = eng.score(X), eng.score(negs)
+    assert torch.allclose(ps, ref_p, rtol=2e-5, atol=1e-5 * float(ref_p.abs().max()))
+    assert torch.allclose(ns, ref_n, rtol=2e-5, atol=1e-5 * float(ref_n.abs().max()))
+    assert bool(torch.isfinite(eng.g_ent).all()) and float(eng.g_ent.abs().max()) > 0
+    # only touched rows carry gradient: rows that are neither s/o of a positive nor a replacement stay exactly zero
+    touched = torch.zeros(N, dtype=torch.bool, device="cuda")
+    touched[X[:, 0].long()] = True; touched[X[:, 2].long()] = True
+    touched[negs[:, 0].long()] = True; touched[negs[:, 2].long()] = True
+    assert float(eng.g_ent[~touched].abs().max()) == 0.0
