@@ -34,7 +34,8 @@ struct TrainArgs {
     ModelConst mc;
     amdkge_loss loss;
     // owner-computes (STAGE) outputs: see kge_train_tiled.hip
-    float* stage_rows;       // [B][4][K]: grad rows of s and o, then the two side rows A, B
+    float* stage_rows;       // [B][4][K]: gradient rows of the positive's s and o (unless pos_atomic), then the side rows A, B
+    int pos_atomic;          // the positives' own s / o rows go through atomics into g_ent (skewed graphs)
     StageEntry* st_lists;    // [n_tiles][cap] buckets of row-gradient entries, by owning tile
     StageEntry* st_ovf;      // overflow of full buckets
     int* st_counters;        // [(n_tiles + 1) * 32] bucket fill counts (128-byte stride), last = overflow count
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     if constexpr (STAGE) {
         // one entry per row gradient that lands in the entity table, into the bucket of the owning tile
         if (active && !(a.dbg & 32))
-            for (int j = ts; j < eta + 2; j += TS) {
+            for (int j = ts; j < eta + (a.pos_atomic ? 0 : 2); j += TS) {
                 uint32_t dest, role;
                 float g;
                 if (j < eta) { dest = (uint32_t)sh_repl[j]; role = sh_keep[j] ? 0u : 1u; g = sh_neg[j] * sgn_scale; }
@@ -801,16 +802,26 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 
     // ---- resident rows: one atomic row-add each, or (STAGE) plain 16-byte stores for the owner kernel ----
     if constexpr (STAGE) {
+        // The positive's own s and o gradient rows.  Default: staged like the side rows and handed to the owning tiles
+        // as bucket entries (roles 2, 3).  On SKEWED graphs a hot entity is the s or o of thousands of positives of one
+        // batch, which piles thousands of entries onto one row of one tile and onto one bucket counter (measured 4x
+        // slower steps on a zipf graph); the host then sets pos_atomic and these 2 rows per positive take the atomic
+        // row-add into the dense gradient buffer instead (+15 us at C2), which the owner folds in when it flushes.
         if (active && !(a.dbg & 64)) {
-            float* ps_ = a.stage_rows + ((int64_t)i * 4 + 0) * a.K;
-            float* po_ = a.stage_rows + ((int64_t)i * 4 + 1) * a.K;
+            if (a.pos_atomic) {
+                emit_row(a.g_ent + (int64_t)ps * a.K, gs, a.K, 1.f);
+                emit_row(a.g_ent + (int64_t)po * a.K, go, a.K, 1.f);
+            } else {
+                float* ps_ = a.stage_rows + ((int64_t)i * 4 + 0) * a.K;
+                float* po_ = a.stage_rows + ((int64_t)i * 4 + 1) * a.K;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                if (!qok[c]) continue;
+                for (int c = 0; c < CH; ++c) {
+                    if (!qok[c]) continue;
 #pragma unroll
-                for (int h = 0; h < NC; ++h) {
-                    *reinterpret_cast<float4*>(ps_ + qoff[c] + h * a.k) = make_float4(gs[c][0][h], gs[c][1][h], gs[c][2][h], gs[c][3][h]);
-                    *reinterpret_cast<float4*>(po_ + qoff[c] + h * a.k) = make_float4(go[c][0][h], go[c][1][h], go[c][2][h], go[c][3][h]);
+                    for (int h = 0; h < NC; ++h) {
+                        *reinterpret_cast<float4*>(ps_ + qoff[c] + h * a.k) = make_float4(gs[c][0][h], gs[c][1][h], gs[c][2][h], gs[c][3][h]);
+                        *reinterpret_cast<float4*>(po_ + qoff[c] + h * a.k) = make_float4(go[c][0][h], go[c][1][h], go[c][2][h], go[c][3][h]);
+                    }
                 }
             }
         }

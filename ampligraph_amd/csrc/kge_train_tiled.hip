@@ -40,7 +40,9 @@ struct TileArgs {
     float* x;                 // entity table (updated in place when g_out == NULL)
     float* s0;                // optimizer slots
     float* s1;
-    float* g_out;             // NULL, or dense gradient buffer that RECEIVES (=) the tile sums
+    float* g_ent;             // dense entity gradient buffer
+    int apply_update;         // 1: optimizer applied from LDS; 0: g_ent receives the entity gradient (data parallel)
+    int pos_atomic;           // g_ent holds the s / o rows of the positives (forward kernel's atomics): fold them in
     const float* rel;         // live relation table (TransE / RotatE side of the gradient)
     const int32_t* triples;
     const float* stage_rows;  // [B][4][K]
@@ -222,8 +224,14 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             for (int h = 0; h < NC; ++h) {
                 float4 g = *reinterpret_cast<const float4*>(arow + qoff[c] + h * a.k);
                 const int64_t off = (t0 + r) * a.K + qoff[c] + h * a.k;
-                if (a.g_out) {
-                    *reinterpret_cast<float4*>(a.g_out + off) = g;
+                float4* gp4 = reinterpret_cast<float4*>(a.g_ent + off);
+                if (a.pos_atomic) {   // rows of the positives' own s / o
+                    const float4 gd = *gp4;
+                    g.x += gd.x; g.y += gd.y; g.z += gd.z; g.w += gd.w;
+                    if (a.apply_update) *gp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (!a.apply_update) {
+                    *gp4 = g;
                     continue;
                 }
                 float4* xp = reinterpret_cast<float4*>(a.x + off);
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             }
         }
     }
-    if (!a.g_out && a.reg_loss && a.opt.lam != 0.f) {
+    if (a.apply_update && a.reg_loss && a.opt.lam != 0.f) {
         const float w = wave_sum(reg_acc);
         if (lane == 0) atomicAdd(a.reg_loss, (double)a.opt.lam * (double)w);
     }
@@ -350,24 +358,25 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
                                        const int32_t* d_triples, int64_t B, int32_t eta, int64_t sample_base,
                                        int64_t sample_range, uint64_t seed, uint64_t step, int64_t row_offset,
                                        int64_t b_global, const int32_t* d_neg_override, float* d_grad_ent,
-                                       float* d_grad_rel, double* d_loss_sum, double* d_reg_loss, float* d_pos_scores,
-                                       float* d_neg_scores, void* d_work, void* stream) {
+                                       float* d_grad_rel, int32_t apply_update, int32_t flags, double* d_loss_sum, double* d_reg_loss,
+                                       float* d_pos_scores, float* d_neg_scores, void* d_work, void* stream) {
     if (int rc = validate_model(m)) return rc;
     if (int rc = validate_opt(opt)) return rc;
     if (!loss || loss->kind < 0 || loss->kind > AMDKGE_LOSS_MULTICLASS_NLL) return set_error(AMDKGE_EINVAL, "train_step_tiled: unknown loss kind");
     if (loss->focus_nonlinearity < AMDKGE_FOCUS_OFF || loss->focus_nonlinearity > AMDKGE_FOCUS_SOFTPLUS || (loss->focus_nonlinearity && !loss->d_focus_w))
         return set_error(AMDKGE_EINVAL, "train_step_tiled: bad FocusE settings (unknown non-linearity or NULL weights)");
     if (!d_ent || !d_rel || !d_grad_rel || !d_loss_sum || !d_work) return set_error(AMDKGE_EINVAL, "train_step_tiled: NULL pointer");
+    if (!d_grad_ent && (!apply_update || (flags & AMDKGE_TILED_POS_ATOMIC))) return set_error(AMDKGE_EINVAL, "train_step_tiled: d_grad_ent is required unless the step updates in place with staged positives");
     if (B < 0 || B >= (1ll << 30) || eta < 1) return set_error(AMDKGE_EINVAL, "train_step_tiled: B must be in [0, 2^30) and eta >= 1");
     TiledPlan p;
     if (!make_plan(m, B, eta, p))
         return set_error(AMDKGE_EUNSUPPORTED, "train_step_tiled: shape not supported (k % 4 != 0, k > 512 or eta too large); use amdkge_train_fwdbwd + amdkge_opt_step");
-    if (!d_grad_ent) {
+    if (apply_update) {
         if (opt->kind != AMDKGE_OPT_SGD && !d_ent_slot0) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 0 is NULL");
         if (opt->kind == AMDKGE_OPT_ADAM && !d_ent_slot1) return set_error(AMDKGE_EINVAL, "train_step_tiled: Adam slot 1 (v) is NULL");
     }
     const bool d_rel_slot_ok = (opt->kind == AMDKGE_OPT_SGD || d_rel_slot0) && (opt->kind != AMDKGE_OPT_ADAM || d_rel_slot1);
-    if (!d_grad_ent && !d_rel_slot_ok && (d_rel_slot0 || d_rel_slot1))
+    if (apply_update && !d_rel_slot_ok && (d_rel_slot0 || d_rel_slot1))
         return set_error(AMDKGE_EINVAL, "train_step_tiled: relation optimizer slots incomplete for this optimizer");
     if (B > 0 && !d_triples) return set_error(AMDKGE_EINVAL, "train_step_tiled: null triples");
     if (!d_neg_override && (sample_range <= 0 || sample_range > 0xFFFFFFFFll || sample_base < 0 || sample_base + sample_range > m->n_ents))
@@ -382,7 +391,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
 
     TrainArgs f{};
     f.ent = d_ent; f.rel = d_rel; f.triples = d_triples; f.neg_override = d_neg_override;
-    f.g_ent = nullptr; f.g_rel = d_grad_rel; f.loss_sum = d_loss_sum; f.pos_scores = d_pos_scores; f.neg_scores = d_neg_scores;
+    f.g_ent = d_grad_ent; f.g_rel = d_grad_rel; f.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; f.loss_sum = d_loss_sum; f.pos_scores = d_pos_scores; f.neg_scores = d_neg_scores;
     f.B = B; f.eta = eta; f.k = m->k; f.K = K; f.nq = m->k / 4;
     f.sc = SampleCfg{sample_base, (uint32_t)sample_range, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step,
                      (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
@@ -392,7 +401,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     { const char* e = getenv("AMDKGE_DEBUG"); f.dbg = e ? atoi(e) : 0; }
 
     TileArgs te{};
-    te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_out = d_grad_ent; te.rel = d_rel;
+    te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
     te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = m->k; te.K = K; te.nq = m->k / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;
@@ -400,7 +409,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     // Whole step in two launches when nothing in the tile pass reads the live relation table (trilinear models)
     // and the tables are updated in place: the relation sweep rides in extra workgroups of the tile kernel.
     // TransE / RotatE tiles read live relation rows, so their relation sweep stays a separate launch behind.
-    const bool rel_here = !d_grad_ent && d_rel_slot_ok;
+    const bool rel_here = apply_update && d_rel_slot_ok;
     const bool fuse_rel = rel_here && (m->scoring_type == AMDKGE_DISTMULT || m->scoring_type == AMDKGE_COMPLEX || m->scoring_type == AMDKGE_HOLE);
     te.rel_blocks = 0;
     if (rel_here) {

@@ -110,10 +110,11 @@ class KgeEngine:
 
     def train_step_tiled(self, triples, eta, loss, opt_desc, seed, step, reg_e=0.0, reg_r=0.0, sample_base=0,
                          sample_range=None, row_offset=0, b_global=0, neg_override=None, pos_scores=None,
-                         neg_scores=None, grad_only=False):
+                         neg_scores=None, grad_only=False, pos_atomic=False):
         """Owner-computes step (kge_train_tiled.hip).  grad_only=False: the COMPLETE step -- entity table
-        from the LDS tiles, relation table by the fused sweep.  grad_only=True (data-parallel): the entity
-        gradient is stored in g_ent and the relation gradient added to g_rel; nothing is updated."""
+        from the LDS tiles, relation table by the fused sweep; g_ent / g_rel (zero on entry) are left zero.
+        grad_only=True (data-parallel): g_ent / g_rel (zero on entry) receive the gradients; nothing is updated.
+        pos_atomic: skewed graphs, see AMDKGE_TILED_POS_ATOMIC in include/amdkge.h."""
         B = int(triples.shape[0])
         need = int(self.lib.amdkge_train_tiled_workspace_bytes(C.byref(self.model), B, int(eta)))
         if need <= 0:
@@ -131,7 +132,7 @@ class KgeEngine:
                 C.byref(self.model), C.byref(loss), C.byref(opt_desc), _ptr(self.ent), _ptr(self.rel), _ptr(s0), _ptr(s1),
                 _ptr(r0), _ptr(r1), float(reg_r), _ptr(triples), B, int(eta), int(sample_base), int(sample_range),
                 int(seed), int(step), int(row_offset), int(b_global), _ptr(neg_override),
-                _ptr(self.g_ent if grad_only else None), _ptr(self.g_rel),
+                _ptr(self.g_ent), _ptr(self.g_rel), 0 if grad_only else 1, 1 if pos_atomic else 0,
                 C.c_void_p(self.loss_acc.data_ptr()), C.c_void_p(self.loss_acc.data_ptr() + 8),
                 _ptr(pos_scores), _ptr(neg_scores), _ptr(self._twork), _stream()))
         except Exception:

@@ -248,6 +248,8 @@ class ScoringBasedEmbeddingModel:
             self._loop = self._make_loop()
         loop = self._loop
         self._full_ent = None
+        if hasattr(loop, "configure_for_data"):
+            loop.configure_for_data(Xi, batch_size)
         train = torch.as_tensor(np.ascontiguousarray(Xi, dtype=np.int32)).to(eng.device)
         n = int(train.shape[0])
         focus_dev = None

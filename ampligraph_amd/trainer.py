@@ -35,6 +35,21 @@ def prefer_tiled(engine):
     return getattr(engine, "scoring_type", "ComplEx") in ("DistMult", "ComplEx", "HolE")
 
 
+def hot_row_entries(triples, batch_size):
+    """Expected number of gradient rows ONE entity receives from the positives of one batch, for the most frequent
+    entity of `triples` (numpy (n,3) ids): (count as subject + count as object) / n * batch_size."""
+    import numpy as np
+
+    t = np.asarray(triples)
+    if t.shape[0] == 0:
+        return 0.0
+    cnt = np.bincount(np.concatenate([t[:, 0], t[:, 2]]).astype(np.int64))
+    return float(cnt.max()) / float(t.shape[0]) * float(batch_size)
+
+
+HOT_ROW_THRESHOLD = 256.0   # expected entries on one row per batch beyond which the positives' rows go atomic
+
+
 class StepLoop:
     def __init__(self, engine, eta, loss, optimizer, regularizer=None, seed=0, dist=None):
         """engine: KgeEngine-like backend; loss/optimizer: objects with .to_ffi(); dist: None or the
@@ -50,8 +65,15 @@ class StepLoop:
         self.rank = dist.get_rank() if dist is not None else 0
         self.n_steps = 0
         self.use_tiled = prefer_tiled(engine)
+        self.pos_atomic = False   # see configure_for_data
         self.kernel_hook = None   # bench.py: callable(phase) recording HIP events around the fused kernel
         engine.prepare_training(optimizer.name)
+
+    def configure_for_data(self, triples, batch_size):
+        """Pick the owner-computes variant for this training set (host-side, once per fit): skewed graphs route the
+        positives' own s / o gradient rows through atomics (AMDKGE_TILED_POS_ATOMIC)."""
+        self.pos_atomic = hot_row_entries(triples, -(-int(batch_size) // self.world)) > HOT_ROW_THRESHOLD
+        return self.pos_atomic
 
     def step(self, global_batch, rng_step, focus=None):
         """global_batch: (Bg,3) int32 device tensor holding the WHOLE batch (same on every rank);
@@ -80,7 +102,8 @@ class StepLoop:
             self.kernel_hook(0)
         if tiled:
             eng.train_step_tiled(global_batch[lo:hi], self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step,
-                                 reg_e=lam, reg_r=lam, row_offset=lo, b_global=bg, grad_only=self.world > 1)
+                                 reg_e=lam, reg_r=lam, row_offset=lo, b_global=bg, grad_only=self.world > 1,
+                                 pos_atomic=self.pos_atomic)
         elif hi > lo:
             eng.train_fwdbwd(global_batch[lo:hi], self.eta, self.loss_ffi, self.seed, rng_step,
                              row_offset=lo, b_global=bg)

@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--eta", type=int, default=20)
     ap.add_argument("--loss", default="self_adversarial")
     ap.add_argument("--dataset", default="synth-fb15k237")
+    ap.add_argument("--popularity", default="uniform", choices=["uniform", "zipf"],
+                    help="entity/relation popularity of the synthetic graph (SURVEY.md 8d: uniform primary, zipf secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -144,7 +146,7 @@ def main():
     from ampligraph_amd.latent_features import loss_functions, optimizers
     from ampligraph_amd.trainer import StepLoop
 
-    data = make_synthetic_kg(args.dataset, seed=0)
+    data = make_synthetic_kg(args.dataset, seed=0, popularity=args.popularity)
     N, R = data["n_ents"], data["n_rels"]
     sharded = args.parallelism != "replicated" and world > 1
     rng = np.random.Generator(np.random.PCG64(0))
@@ -170,6 +172,8 @@ def main():
         # the product's own step loop (what ScoringBasedEmbeddingModel.fit drives)
         loop = StepLoop(eng, args.eta, loss_functions.get(args.loss), optimizers.get("adam"), None, seed=0, dist=dist)
 
+    if hasattr(loop, "configure_for_data"):
+        loop.configure_for_data(data["train"], args.batch * world)
     # the training set lives in HBM; a global batch is a contiguous slice (reference order: sequential,
     # un-shuffled, graph_data_loader.py:472-523); each rank takes its share of it inside StepLoop
     B = args.batch
@@ -232,7 +236,7 @@ def main():
             "value": triples / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.dataset} (uniform, seed 0) {args.model} k={args.k} eta={args.eta} "
+            "config": {"workload": f"{args.dataset} ({args.popularity}, seed 0) {args.model} k={args.k} eta={args.eta} "
                                    f"{args.loss} adam lr=1e-3, {B} positives/GPU/step, tables resident in HBM, "
                                    f"dense (non-lazy) Keras-legacy Adam every step",
                        "global_batch": Bg, "n_ents": N, "n_rels": R, "row_floats": eng.K,

@@ -142,14 +142,20 @@ int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_s
  * of entity rows accumulates the staged row gradients in LDS and applies the optimizer + regulariser to its rows in
  * place.  Same reference code as amdkge_train_fwdbwd + amdkge_opt_step (ScoringBasedEmbeddingModel.py:370-429,
  * optimizers.py:136-168, regularizers.py:35-37) without global atomics or a dense gradient buffer for the entity
- * table.  Supported for all five models when k % 4 == 0 and k <= 512 (amdkge_train_tiled_workspace_bytes returns 0
+ * table (see `flags` for the skewed-graph variant).  Supported for all five models when k % 4 == 0 and k <= 512 (amdkge_train_tiled_workspace_bytes returns 0
  * otherwise and the call returns AMDKGE_EUNSUPPORTED).
- *   d_grad_ent : NULL  -> the entity table and its slots are updated in place (single GPU);
- *                !NULL -> the entity gradient is STORED there (every row overwritten), the relation gradient is
- *                         ADDED to d_grad_rel and nothing is updated (data-parallel: the caller all-reduces both
- *                         and calls amdkge_opt_step)
+ *   apply_update : 1 -> the entity table and its slots are updated in place (single GPU);
+ *                0 -> d_grad_ent receives the complete entity gradient (every row written), the relation gradient is ADDED
+ *                     to d_grad_rel and nothing is updated (data-parallel: the caller all-reduces both and calls
+ *                     amdkge_opt_step)
+ *   flags      : AMDKGE_TILED_POS_ATOMIC -> the gradient rows of the positives' own s / o entities bypass the tile buckets
+ *                and are added to d_grad_ent with 2 atomic row-adds per positive; the tiles fold d_grad_ent in when they
+ *                flush (and reset it when apply_update).  For SKEWED graphs: a hot entity that is the s / o of thousands
+ *                of positives of one batch would otherwise serialise one tile (measured 4x on a zipf graph); on uniform
+ *                graphs the staged default is ~15 us faster at C2.  Results are identical up to fp32 summation order.
+ *   d_grad_ent : dense entity gradient buffer; required unless apply_update && !POS_ATOMIC; zero on entry with POS_ATOMIC
  *   d_grad_rel : dense relation gradient buffer (+=), zero on entry
- *   d_rel_slot0/1, rel_reg_lambda : with d_grad_ent == NULL and the slots the optimizer needs given, the relation
+ *   d_rel_slot0/1, rel_reg_lambda : with apply_update and the slots the optimizer needs given, the relation
  *                table is swept as well (d_grad_rel is consumed and left zero): the call is the complete step.
  *                With NULL relation slots (and an optimizer that needs them) the caller sweeps the relation table.
  *   opt->reg_lambda : regulariser weight of the ENTITY table; d_reg_loss (double, may be NULL) += lambda*sum|x|^p of
@@ -157,6 +163,7 @@ int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_s
  *   d_work     : scratch of amdkge_train_tiled_workspace_bytes(m, B, eta) bytes.  It must be zero-filled before
  *                its FIRST use; the library leaves its bookkeeping region zeroed after every successful call, so
  *                one buffer (sized for the largest B) serves every later step of the same model. */
+#define AMDKGE_TILED_POS_ATOMIC 1
 int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta);
 int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, const amdkge_opt* opt,
                             float* d_ent, float* d_rel, float* d_ent_slot0, float* d_ent_slot1,
@@ -164,7 +171,8 @@ int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, cons
                             const int32_t* d_triples, int64_t B, int32_t eta,
                             int64_t sample_base, int64_t sample_range, uint64_t seed, uint64_t step,
                             int64_t row_offset, int64_t b_global, const int32_t* d_neg_override,
-                            float* d_grad_ent, float* d_grad_rel, double* d_loss_sum, double* d_reg_loss,
+                            float* d_grad_ent, float* d_grad_rel, int32_t apply_update, int32_t flags,
+                            double* d_loss_sum, double* d_reg_loss,
                             float* d_pos_scores, float* d_neg_scores, void* d_work, void* stream);
 
 /* calibrate(): Platt-scaling objective + gradient for one batch of scores -- CalibrationLayer.call(training=1)

@@ -7,7 +7,7 @@ sys.path.insert(0, %r)
 from ampligraph_amd import _ffi
 from ampligraph_amd.datasets import make_synthetic_kg
 from ampligraph_amd.engine import KgeEngine
-d = make_synthetic_kg(); N, R = d["n_ents"], d["n_rels"]
+d = make_synthetic_kg(popularity=os.environ.get("POP", "uniform")); N, R = d["n_ents"], d["n_rels"]
 model, k, eta, B = os.environ.get("M", "ComplEx"), int(os.environ.get("K", 200)), int(os.environ.get("ETA", 20)), 10000
 eng = KgeEngine(model, k, N, R, max_rel_size=R)
 rng = np.random.default_rng(0)

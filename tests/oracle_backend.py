@@ -90,7 +90,9 @@ class OracleEngine:
                           b_global=0, grad_only=False, **kw):
         """amdkge_train_step_tiled: grad_only stores the entity gradient (overwrite) and adds the relation
         gradient; otherwise it is the complete step (both tables updated, gradients left zero)."""
-        self.g_ent.zero_()
+        kw.pop("pos_atomic", None)
+        if grad_only:
+            self.g_ent.zero_()   # staged positives: the entity gradient is stored, not added
         self.train_fwdbwd(triples, eta, loss, seed, step, row_offset=row_offset, b_global=b_global, **kw)
         if not grad_only:
             self.opt_step(opt, reg_e, reg_r)

@@ -44,7 +44,7 @@ def test_abi_argument_validation_without_gpu():
     m4 = _ffi.Model(2, 200, 14505, 237, 0, 0)
     assert lib.amdkge_train_tiled_workspace_bytes(ctypes.byref(m4), 10000, 20) > 10000 * 4 * 400 * 4
     assert lib.amdkge_train_step_tiled(ctypes.byref(m4), None, ctypes.byref(o), *([None] * 6), 0.0, None, 1, 1, 0, 1,
-                                       0, 0, 0, 0, *([None] * 9)) == -1
+                                       0, 0, 0, 0, None, None, None, 1, 0, *([None] * 6)) == -1
     assert lib.amdkge_internal_k(7, 3) == -1
 
 

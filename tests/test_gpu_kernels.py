@@ -180,35 +180,38 @@ def test_train_neg_override_and_duplicates(gpu_lib):
 
 
 # -------------------------------------------------------------------------------- owner-computes step
-def run_tiled_grads(eng, X, eta, loss_name, reduction, seed, step, negs=None):
+def run_tiled_grads(eng, X, eta, loss_name, reduction, seed, step, negs=None, pos_atomic=False):
     """amdkge_train_step_tiled in its gradient-only form: g_ent is STORED, g_rel accumulated."""
     from ampligraph_amd import _ffi
 
     eng.prepare_training("adam")
     eng.loss_acc.zero_()
-    eng.g_ent.fill_(123.0)   # must be overwritten, every row
     B = X.shape[0]
     ps = torch.empty(B, dtype=torch.float32, device="cuda")
     ns = torch.empty(B * eta, dtype=torch.float32, device="cuda")
     d = _ffi.Opt(_ffi.OPTIMIZERS["adam"], 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, 1)
-    eng.train_step_tiled(dev(X), eta, loss_desc(loss_name, reduction), d, seed, step, grad_only=True,
+    if not pos_atomic:
+        eng.g_ent.fill_(123.0)   # staged positives: every row is overwritten
+    eng.train_step_tiled(dev(X), eta, loss_desc(loss_name, reduction), d, seed, step, grad_only=True, pos_atomic=pos_atomic,
                          neg_override=None if negs is None else dev(negs), pos_scores=ps, neg_scores=ns)
     torch.cuda.synchronize()
     return (float(eng.loss_acc[0].item()), eng.g_ent.cpu().numpy(), eng.g_rel.cpu().numpy(),
             ps.cpu().numpy(), ns.cpu().numpy())
 
 
+@pytest.mark.parametrize("pos_atomic", [False, True])
 @pytest.mark.parametrize("model", MODELS)
 @pytest.mark.parametrize("loss", LOSSES)
-def test_tiled_gradients_parity(gpu_lib, model, loss):
-    """Bucketed owner-computes backward == oracle dense gradients (all models x losses x reductions)."""
+def test_tiled_gradients_parity(gpu_lib, model, loss, pos_atomic):
+    """Bucketed owner-computes backward == oracle dense gradients (all models x losses x reductions; positives' own
+    rows staged or through atomics)."""
     N, R, k, B, eta = 300, 5, 32, 257, 6
     eng, ent, rel = make_engine(model, k, N, R, scale=0.6)
     assert eng.tiled_supported(B, eta)
     rng = np.random.default_rng(3)
     X = rand_triples(rng, B, N, R)
     for reduction in ("sum", "mean"):
-        L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, loss, reduction, seed=9, step=4)
+        L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, loss, reduction, seed=9, step=4, pos_atomic=pos_atomic)
         negs = O.generate_corruptions(X, N, eta, 9, 4)
         total, Te, Tr, (sp, sn, per) = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, reduction, R)
         assert np.allclose(ps, sp, rtol=1e-5, atol=1e-5 * np.abs(sp).max())
@@ -248,12 +251,13 @@ def test_tiled_unsupported_shapes(gpu_lib):
                 C.byref(eng.model), C.byref(loss_desc("nll")), C.byref(_ffi.Opt(0, 2, 1e-2, .9, .999, 1e-7, 0.0, 1)),
                 eng.ent.data_ptr(), eng.rel.data_ptr(), None, None, None, None, 0.0,
                 dev(np.zeros((10, 3), np.int32)).data_ptr(), 10, 2,
-                0, 50, 0, 0, 0, 0, None, None, eng.g_rel.data_ptr(), eng.loss_acc.data_ptr(), None, None, None,
+                0, 50, 0, 0, 0, 0, None, eng.g_ent.data_ptr(), eng.g_rel.data_ptr(), 1, 0, eng.loss_acc.data_ptr(), None, None, None,
                 eng._twork.data_ptr(), None))
 
 
+@pytest.mark.parametrize("pos_atomic", [False, True])
 @pytest.mark.parametrize("model", ["ComplEx", "TransE"])
-def test_tiled_overflow_buckets_and_duplicates(gpu_lib, model):
+def test_tiled_overflow_buckets_and_duplicates(gpu_lib, model, pos_atomic):
     """Every positive shares one subject (its tile's bucket overflows into the shared list), s == o triples,
     identity corruptions, inactive margins (g == 0 entries are skipped)."""
     N, R, k, eta, B = 300, 3, 16, 2, 3000
@@ -266,16 +270,17 @@ def test_tiled_overflow_buckets_and_duplicates(gpu_lib, model):
     negs[:B // 2] = X[:B // 2]
     negs[:B // 2, 2] = 11   # first half of the j = 0 corruptions: object replaced by one hot row
     for loss in ("pairwise", "nll"):
-        L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, loss, "sum", 5, 2, negs=negs)
+        L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, loss, "sum", 5, 2, negs=negs, pos_atomic=pos_atomic)
         total, Te, Tr, _ = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, "sum", R)
         assert abs(L - float(total)) <= 2e-5 * max(1.0, abs(L))
         assert_grads_close(Ge, Te, tol=1e-4)   # thousands of fp32 terms per hot row, unordered
         assert_grads_close(Gr, Tr, tol=1e-4)
 
 
+@pytest.mark.parametrize("pos_atomic", [False, True])
 @pytest.mark.parametrize("opt", ["adam", "adagrad", "sgd"])
 @pytest.mark.parametrize("model,reg", [("ComplEx", None), ("DistMult", (2, 1e-3)), ("RotatE", (3, 1e-2)), ("TransE", None)])
-def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg):
+def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg, pos_atomic):
     """Whole owner-computes steps (tables + slots updated from LDS) == oracle train_step, 3 steps."""
     from ampligraph_amd import _ffi
 
@@ -290,8 +295,9 @@ def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg):
         X = rand_triples(rng, B, N, R)
         eng.loss_acc.zero_()
         d = _ffi.Opt(_ffi.OPTIMIZERS[opt], reg[0] if reg else 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, t)
-        eng.train_step_tiled(dev(X), eta, loss_desc("self_adversarial"), d, 77, t, reg_e=lam, reg_r=lam)
+        eng.train_step_tiled(dev(X), eta, loss_desc("self_adversarial"), d, 77, t, reg_e=lam, reg_r=lam, pos_atomic=pos_atomic)
         assert float(eng.g_rel.abs().max()) == 0.0   # relation gradient consumed by the fused / trailing sweep
+        assert float(eng.g_ent.abs().max()) == 0.0   # the positives' own rows were folded in and reset by the tiles
         ref_loss = float(O.train_step(st, model, X, eta, "self_adversarial", 77, t, max_rel_size=R, reg=oreg))
         torch.cuda.synchronize()
         got_loss = float(eng.loss_acc[0].item()) + float(eng.loss_acc[1].item())
