@@ -430,7 +430,10 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     // Rows in flight per slot: the replacement rows of PF corruptions are requested together (the row loads are
     // dependent on nothing but LDS-resident ids), then reduced one by one.  One row at a time left the kernel
     // latency-bound (21 serial L2/MALL round trips per pass per positive).
-    constexpr int PF = (CH * NC * VEC <= 8) ? 4 : 2;
+#ifndef KGE_PF
+#define KGE_PF 6
+#endif
+    constexpr int PF = (CH * NC * VEC <= 8) ? KGE_PF : 2;
     auto load_row = [&](const float* re, float (&e)[CH][VEC][NC]) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
