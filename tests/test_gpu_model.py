@@ -458,3 +458,59 @@ def test_fit_focuse_matches_oracle(gpu_lib, model, nl, stop):
     m2.compile(optimizer="adam", loss="nll")
     m2.fit(X, batch_size=bs, epochs=1, verbose=False, focusE=True)
     assert m2.use_focusE is False
+
+
+# ------------------------------------------------------------------------------------ discovery helpers, callbacks (8f)
+def test_query_topn_and_neighbours(gpu_lib):
+    """The reference's own test_query_topn (tests/ampligraph/discovery/test_discovery.py:238-313) + parity with predict."""
+    from ampligraph_amd.discovery import find_nearest_neighbours, query_topn
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel
+
+    X = np.array([['a', 'y', 'b'], ['b', 'y', 'a'], ['a', 'y', 'c'], ['c', 'y', 'a'], ['a', 'y', 'd'], ['c', 'x', 'd'],
+                  ['b', 'y', 'c'], ['f', 'y', 'e'], ['a', 'z', 'f'], ['c', 'z', 'f'], ['b', 'z', 'f']])
+    model = ScoringBasedEmbeddingModel(eta=5, k=10, scoring_type='ComplEx')
+    model.compile(optimizer='adam', loss='multiclass_nll')
+    with pytest.raises(ValueError):   # model not fitted
+        query_topn(model, top_n=2)
+    model.fit(X, batch_size=2, epochs=10, verbose=False)
+    bad = [dict(), dict(head='a'), dict(relation='y'), dict(tail='e'), dict(head='a', relation='y', tail='e'),
+           dict(head='xx', relation='y'), dict(head='a', relation='yakkety'), dict(head='a', tail='sax'),
+           dict(head='a', relation='x', rels_to_consider=['y', 'z']), dict(head='a', tail='f', rels_to_consider=['y', 'z', 'error']),
+           dict(head='a', tail='e', rels_to_consider='y'), dict(head='a', relation='x', ents_to_consider=['zz', 'top']),
+           dict(head='a', tail='e', ents_to_consider=['a', 'b'])]
+    for kw in bad:
+        with pytest.raises(ValueError):
+            query_topn(model, top_n=2, **kw)
+    subj, pred, obj, top_n = 'a', 'x', 'e', 3
+    Y, S = query_topn(model, top_n=top_n, head=subj, relation=pred)
+    assert len(Y) == len(S) == top_n and np.all(Y[:, 0] == subj) and np.all(Y[:, 1] == pred)
+    Y, S = query_topn(model, top_n=top_n, relation=pred, tail=obj)
+    assert np.all(Y[:, 1] == pred) and np.all(Y[:, 2] == obj)
+    ents_to_con = ['a', 'b', 'c', 'd']
+    Y, S = query_topn(model, top_n=top_n, relation=pred, tail=obj, ents_to_consider=ents_to_con)
+    assert np.all([x in ents_to_con for x in Y[:, 0]])
+    Y, S = query_topn(model, top_n=100, head=subj, tail=obj, rels_to_consider=['y', 'x'])
+    assert np.all([x in ['y', 'x'] for x in Y[:, 1]])
+    Y, S = query_topn(model, top_n=100, relation=pred, tail=obj)
+    assert all(S[i] >= S[i + 1] for i in range(len(S) - 1))
+    assert np.allclose(S, model.predict(Y), rtol=1e-6)          # same scores as the predict path on the returned triples
+    nb, dist = find_nearest_neighbours(model, ['b'], n_neighbors=3, entities_subset=['a', 'c', 'd', 'e', 'f'])
+    emb = model.get_embeddings(['a', 'c', 'd', 'e', 'f']).astype(np.float64)
+    d_ref = np.sort(np.linalg.norm(emb - model.get_embeddings(['b']).astype(np.float64), axis=1))[:3]
+    assert nb.shape == (1, 3) and np.allclose(dist[0], d_ref, rtol=1e-5)
+
+
+def test_early_stopping_callback(gpu_lib):
+    from ampligraph_amd.callbacks import EarlyStopping
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel
+
+    X = toy_graph(n=400, N=40, R=3)
+    m = ScoringBasedEmbeddingModel(eta=2, k=8, scoring_type="DistMult", seed=2)
+    m.compile(optimizer="adam", loss="nll")
+    es = EarlyStopping(monitor="val_mrr", patience=1, restore_best_weights=True)
+    h = m.fit(X[:300], batch_size=100, epochs=50, verbose=False, validation_data=X[300:], validation_freq=2,
+              validation_batch_size=100, callbacks=[es])
+    assert len(h.history["loss"]) < 50 and m.stop_training and "val_mrr" in h.history
+    es2 = EarlyStopping(monitor="loss", patience=3, min_delta=1e9)   # nothing ever improves by 1e9: stops after `patience` epochs
+    h2 = m.fit(X[:300], batch_size=100, epochs=50, verbose=False, callbacks=[es2])
+    assert len(h2.history["loss"]) <= 5
