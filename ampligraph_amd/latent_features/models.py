@@ -53,6 +53,13 @@ def _load_triples(x):
     return x
 
 
+class _NoDist:
+    """Stand-in that makes _dist() report a single rank (used while a rank evaluates its own share)."""
+
+    def get_world_size(self):
+        return 1
+
+
 class ScoringBasedEmbeddingModel:
     def __init__(self, eta, k, scoring_type="DistMult", seed=0, max_ent_size=None, max_rel_size=None):
         if scoring_type not in SCORING_LAYER_REGISTRY:
@@ -348,6 +355,11 @@ class ScoringBasedEmbeddingModel:
             return np.zeros((0, 1 if corrupt_side in ("s", "o", "s+o") else 2), dtype=np.int32)
         if self._spec is not None:
             return self._evaluate_sharded(Xi, sides, use_filter, corrupt_side, entities_subset, ranking_strategy)
+        d = self._dist()
+        if d is not None and n >= d.get_world_size():
+            # replicated tables, several ranks: every rank ranks its contiguous share of the test triples (all filters
+            # are built from the full data, so the ranks are those of the single-GPU run) and the shares are gathered
+            return self._evaluate_split_queries(d, x, Xi, use_filter, corrupt_side, entities_subset, ranking_strategy)
         # filters (graph_data_loader.py:184-190,652-653): True -> the evaluated data filters itself;
         # dict -> union of the given datasets, all indexed with the training id map
         fi = None
@@ -383,6 +395,33 @@ class ScoringBasedEmbeddingModel:
         if corrupt_side == "s+o":  # :1459-1463 sums the two 0-based sides, then +1 (:1684)
             r = (r.sum(1, keepdims=True) - 1).astype(np.int32)
         return r
+
+    def _evaluate_split_queries(self, d, x, Xi, use_filter, corrupt_side, entities_subset, ranking_strategy):
+        import torch
+
+        from ..trainer import shard_bounds
+
+        W, r = d.get_world_size(), d.get_rank()
+        n = Xi.shape[0]
+        lo, hi = shard_bounds(n, W, r)
+        flt = use_filter
+        if use_filter is True:   # "the evaluated data filters itself": keep filtering with the WHOLE evaluated set
+            flt = {"self": self.data_indexer.get_indexes(Xi, "t", "ind2raw")}
+        override, self._dist_override = self._dist_override, _NoDist()
+        try:
+            mine = self.evaluate(self.data_indexer.get_indexes(Xi[lo:hi], "t", "ind2raw"), use_filter=flt,
+                                 corrupt_side=corrupt_side, entities_subset=entities_subset,
+                                 ranking_strategy=ranking_strategy, verbose=False)
+        finally:
+            self._dist_override = override
+        cols = mine.shape[1]
+        width = -(-n // W)
+        buf = torch.zeros(width, cols, dtype=torch.int32, device=self._engine.device)
+        buf[:hi - lo] = torch.as_tensor(mine).to(buf.device)
+        parts = [torch.empty_like(buf) for _ in range(W)]
+        d.all_gather(parts, buf)
+        out = [parts[q][:shard_bounds(n, W, q)[1] - shard_bounds(n, W, q)[0]] for q in range(W)]
+        return torch.cat(out).cpu().numpy()
 
     def _evaluate_sharded(self, Xi, sides, use_filter, corrupt_side, entities_subset, ranking_strategy):
         """Row-sharded evaluate(): every rank counts against ITS rows, counts are summed over ranks

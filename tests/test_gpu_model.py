@@ -514,3 +514,39 @@ def test_early_stopping_callback(gpu_lib):
     es2 = EarlyStopping(monitor="loss", patience=3, min_delta=1e9)   # nothing ever improves by 1e9: stops after `patience` epochs
     h2 = m.fit(X[:300], batch_size=100, epochs=50, verbose=False, callbacks=[es2])
     assert len(h2.history["loss"]) <= 5
+
+
+def test_replicated_evaluate_splits_queries_over_ranks(gpu_lib):
+    """Replicated tables, 2 ranks (in-process rendezvous): evaluate() splits the test triples over the ranks and
+    gathers; every rank returns exactly the single-GPU ranks (incl. use_filter=True, which must keep filtering with the
+    whole evaluated set)."""
+    from threaded_dist import ThreadedWorld
+
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel
+
+    X = toy_graph(n=500, N=50, R=3)
+    Xt = X[:77]
+
+    def make(dist=None):
+        m = ScoringBasedEmbeddingModel(eta=2, k=8, scoring_type="DistMult", seed=3)
+        m._dist_override = dist
+        m.compile(optimizer="adam", loss="nll")
+        m.fit(X, batch_size=128, epochs=2, verbose=False)
+        return m
+
+    m1 = make()
+    ref = [m1.evaluate(Xt, use_filter=True, corrupt_side="s,o", verbose=False),
+           m1.evaluate(Xt, use_filter={"train": X}, corrupt_side="s+o", ranking_strategy="middle", verbose=False),
+           m1.evaluate(Xt, corrupt_side="o", verbose=False)]
+    e1, r1 = m1._engine.get_tables()
+
+    def body(dist):
+        m = make(dist)
+        m._engine.set_tables(e1, r1)   # identical tables: DP training differs only by fp32 summation order
+        return [m.evaluate(Xt, use_filter=True, corrupt_side="s,o", verbose=False),
+                m.evaluate(Xt, use_filter={"train": X}, corrupt_side="s+o", ranking_strategy="middle", verbose=False),
+                m.evaluate(Xt, corrupt_side="o", verbose=False)]
+
+    for got in ThreadedWorld(2).run(body):
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape and np.array_equal(a, b)
