@@ -22,9 +22,10 @@ def shard_bounds(n, world, rank):
 
 def prefer_tiled(engine):
     """Which fused train path a loop should use when the shape allows both.  Owner-computes (kge_train_tiled.hip)
-    wins 2.2x for the trilinear models (single pass over the rows, no global atomics); for TransE / RotatE it
-    reads the rows twice AND re-reads side rows in the tile pass and measures equal (RotatE k=200) or slower
-    (TransE k=52) than the atomic path, so those default to kge_train.hip.  AMDKGE_TRAIN_PATH=atomic|tiled forces."""
+    wins 2.2x for the trilinear models (single pass over the rows, no global atomics).  TransE / RotatE read the rows
+    twice AND re-read side + own rows in the tile pass; measured at the C2 shape (ms/step, atomic vs tiled): TransE
+    k=52 0.059 vs 0.089, TransE k=200 0.214 vs 0.161, RotatE k=200 0.358 vs 0.402 -- so TransE switches at k >= 128
+    and RotatE stays on kge_train.hip.  AMDKGE_TRAIN_PATH=atomic|tiled forces."""
     if not hasattr(engine, "train_step_tiled"):
         return False
     force = os.environ.get("AMDKGE_TRAIN_PATH", "")
@@ -32,7 +33,10 @@ def prefer_tiled(engine):
         return False
     if force == "tiled":
         return True
-    return getattr(engine, "scoring_type", "ComplEx") in ("DistMult", "ComplEx", "HolE")
+    model = getattr(engine, "scoring_type", "ComplEx")
+    if model == "TransE":
+        return getattr(engine, "k", 0) >= 128
+    return model in ("DistMult", "ComplEx", "HolE")
 
 
 def hot_row_entries(triples, batch_size):
