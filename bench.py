@@ -132,13 +132,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    # AMDKGE_BENCH_BACKEND=gloo (development): several ranks on ONE GPU, collectives through the host -- exercises the
+    # multi-rank code path of this script on a single-GPU box; the driver's runs use nccl (= RCCL over xGMI)
+    backend = os.environ.get("AMDKGE_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ampligraph_amd import _ffi
     from ampligraph_amd.datasets import make_synthetic_kg
