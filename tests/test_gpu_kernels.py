@@ -541,3 +541,45 @@ def test_focuse_gradients_parity(gpu_lib, nl, model, k, path):
         assert abs(L - float(per.astype(np.float64).sum())) <= 2e-5 * max(1.0, abs(L)), (loss, nl, L)
         assert_grads_close(eng.g_ent.cpu().numpy(), Te, tol=4e-5)
         assert_grads_close(eng.g_rel.cpu().numpy(), Tr, tol=4e-5)
+
+
+@pytest.mark.parametrize("model", ["ComplEx", "TransE"])
+@pytest.mark.parametrize("B,eta", [(1, 1), (3, 64), (5, 100), (2, 7)])
+def test_train_edge_shapes(gpu_lib, model, B, eta):
+    """One positive, one corruption, eta at and beyond the wave width (lane loops, side-sorted permutation over several
+    ballots), batches smaller than a workgroup -- both fused paths against the oracle."""
+    N, R, k = 40, 3, 16
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.4)
+    rng = np.random.default_rng(B * 1000 + eta)
+    X = rand_triples(rng, B, N, R)
+    negs = O.generate_corruptions(X, N, eta, 2, 3)
+    for loss in ("self_adversarial", "multiclass_nll", "pairwise"):
+        total, Te, Tr, (sp, sn, per) = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, "mean", R)
+        for path in ("atomic", "tiled"):
+            if path == "atomic":
+                L, Ge, Gr, ps, ns = run_fwdbwd(eng, X, eta, loss, "mean", 2, 3)
+            else:
+                L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, loss, "mean", 2, 3)
+            assert np.allclose(ns, sn, rtol=1e-5, atol=1e-5 * max(np.abs(sn).max(), 1e-6)), (path, loss)
+            assert abs(L - float(per.astype(np.float64).sum())) <= 2e-5 * max(1.0, abs(L)), (path, loss)
+            assert_grads_close(Ge, Te, tol=4e-5)
+            assert_grads_close(Gr, Tr, tol=4e-5)
+
+
+def test_empty_inputs(gpu_lib):
+    """Empty batches / test sets are no-ops with well-formed outputs (the reference's loaders can yield them)."""
+    from ampligraph_amd import _ffi
+
+    eng, ent, rel = make_engine("DistMult", 8, 20, 2, scale=0.3)
+    empty = torch.empty(0, 3, dtype=torch.int32, device="cuda")
+    assert eng.score(empty).shape[0] == 0
+    r, c, s = eng.rank_side(empty, _ffi.SIDE_S, "worst")
+    assert r.shape[0] == 0 and c.shape == (0, 2)
+    eng.prepare_training("adam")
+    eng.train_fwdbwd(empty, 3, loss_desc("nll"), 0, 0)
+    assert float(eng.g_ent.abs().max()) == 0.0 and float(eng.loss_acc[0]) == 0.0
+    before = eng.ent.clone()
+    d = _ffi.Opt(_ffi.OPTIMIZERS["adam"], 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, 1)
+    eng.train_step_tiled(empty, 3, loss_desc("nll"), d, 0, 0)          # a zero-gradient Adam step: tables unchanged
+    torch.cuda.synchronize()
+    assert torch.equal(eng.ent, before)
