@@ -714,8 +714,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
                 for (int h = 0; h < NC; ++h)
                     if (qok[c] && qoff[c] + h * a.k < nfloats) atomic_add_f32(grow + qoff[c] + h * a.k, gr[c][0][h] * mul);
-        } else {
-            static_assert(VEC == 1 || W == 1, "LDS-transposed emit is per wave");
+        } else if constexpr (W == 1) {
 #pragma unroll
             for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -728,6 +727,21 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
             for (int idx = lane; idx < nfloats; idx += KGE_WAVE) atomic_add_f32(grow + idx, stage[idx]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        } else {
+            // one positive per workgroup (W == 4): the row is transposed through ONE LDS row shared by the four waves.
+            // Called by every thread of the workgroup (SLOTS == 1, so `active` is workgroup-uniform).
+            static_assert(VEC == 1 || W == 1 || W == 4, "multi-wave LDS-transposed emit needs one slot per workgroup");
+            float* srow = reinterpret_cast<float*>(smem + (size_t)SLOTS * per_slot + SLOTS * sizeof(double));
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int h = 0; h < NC; ++h)
+                    if (qok[c])
+                        *reinterpret_cast<float4*>(srow + qoff[c] + h * a.k) =
+                            make_float4(gr[c][0][h] * mul, gr[c][1][h] * mul, gr[c][2][h] * mul, gr[c][3][h] * mul);
+            __syncthreads();
+            for (int idx = ts; idx < nfloats; idx += TS) atomic_add_f32(grow + idx, srow[idx]);
+            __syncthreads();
         }
     };
 

@@ -44,6 +44,7 @@ struct TileArgs {
     int apply_update;         // 1: optimizer applied from LDS; 0: g_ent receives the entity gradient (data parallel)
     int pos_atomic;           // g_ent holds the s / o rows of the positives (forward kernel's atomics): fold them in
     const float* rel;         // live relation table (TransE / RotatE side of the gradient)
+    const float* rel_cs;      // RotatE: [R][cos(phase) || sin(phase)] of this step's relation table (rel_phase_kernel)
     const int32_t* triples;
     const float* stage_rows;  // [B][4][K]
     const StageEntry* lists;  // [n_tiles][cap]
@@ -135,7 +136,9 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             // TransE / RotatE: the gradient w.r.t. the replaced row depends on that row -> same grad_unit
             // arithmetic as the atomic path, on (side row copy, live relation row, own live row)
             const int pp = a.triples[3 * (int64_t)pos + 1];
-            const float* rp = a.rel + (int64_t)pp * a.K;
+            // RotatE: cos / sin of the relation phases come from a per-step table (one sincos per relation unit instead
+            // of one per bucket entry: at k = 1000, eta = 64 that is 1e6 instead of 4.3e9 evaluations)
+            const float* rp = (MODEL == AMDKGE_ROTATE ? a.rel_cs : a.rel) + (int64_t)pp * a.K;
             const float* re = a.x + (t0 + lr) * a.K;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                     for (int h = 0; h < NC; ++h) {
                         p[h] = (&pv[h].x)[u]; e[h] = (&ev[h].x)[u]; sd[h] = (&v[c][h].x)[u];
                     }
-                    prep_rel<MODEL>(a.mc, p);
+                    if constexpr (MODEL != AMDKGE_ROTATE) prep_rel<MODEL>(a.mc, p);
                     if (role == 0) grad_unit<MODEL>(sd, p, e, g, ds, dp, dd);
                     else grad_unit<MODEL>(e, p, sd, g, ds, dp, dd);
 #pragma unroll
@@ -272,10 +275,24 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     }
 }
 
+// RotatE: cos / sin of every relation phase, once per step (same cosf / sinf as prep_rel, so the tile pass sees the
+// very values the forward kernel used)
+__global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict__ rel, int64_t n_rels, int k, int K, ModelConst mc,
+                                                        float* __restrict__ cs) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rels * k) return;
+    const int64_t r = idx / k;
+    const int c = (int)(idx - r * k);
+    float p[2] = {rel[r * K + c], 0.f};
+    prep_rel<AMDKGE_ROTATE>(mc, p);
+    cs[r * K + c] = p[0];
+    cs[r * K + k + c] = p[1];
+}
+
 // ---- plan: tile size, bucket capacity and workspace layout (shared by the two entry points) ------------------
 struct TiledPlan {
     int tile_rows, n_tiles, cap, ovf_cap;
-    size_t off_cnt, off_lists, off_ovf, off_rows, total;
+    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, total;
 };
 
 // rows per tile: as many as fit the LDS budget, then shrunk so that the tiles fill whole waves of 256 CUs evenly
@@ -292,14 +309,17 @@ static int pick_tile_rows(int64_t n_rows, int K) {
 
 static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p) {
     const int K = internal_k_of(m->scoring_type, m->k);
-    if (m->k % 4 != 0 || m->k > 512) return false;   // 16-byte layout, one wave per positive, <= 2 quads per lane
-    if ((size_t)4 * slot_lds_bytes(eta, 1) + 32 + 16 * (size_t)K > 64 * 1024) return false;
+    if (m->k % 4 != 0 || m->k > 2048) return false;   // 16-byte layout; one wave (k <= 512) or one workgroup (k <= 2048) per positive
+    if ((m->k <= 512 ? (size_t)4 * slot_lds_bytes(eta, 1) + 32 + 16 * (size_t)K : slot_lds_bytes(eta, 4) + 8 + 4 * (size_t)K) > 150 * 1024) return false;
     p.tile_rows = pick_tile_rows(m->n_ents, K);
     if (p.tile_rows < 1) return false;
     p.n_tiles = (int)((m->n_ents + p.tile_rows - 1) / p.tile_rows);
     const int64_t entries = B * (eta + 2);
     if (entries >= (1ll << 31)) return false;
-    p.cap = (int)(2 * ((entries + p.n_tiles - 1) / p.n_tiles) + 256);
+    {   // bucket capacity: twice the mean + slack (Poisson tail; anything beyond goes to the overflow list)
+        const int64_t mean = (entries + p.n_tiles - 1) / p.n_tiles;
+        p.cap = (int)(2 * mean + (mean >= 224 ? 256 : 32 + mean));
+    }
     p.ovf_cap = (int)(entries > 0 ? entries : 1);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
@@ -307,6 +327,7 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     p.off_lists = o; o += up((size_t)p.n_tiles * p.cap * sizeof(StageEntry));
     p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
     p.off_rows = o; o += up((size_t)B * 4 * K * 4);
+    p.off_cs = o; o += up(m->scoring_type == AMDKGE_ROTATE ? (size_t)m->n_rels * K * 4 : 0);
     p.total = o + 256;
     return true;
 }
@@ -323,22 +344,42 @@ static int launch_tile(const TileArgs& a, size_t shmem, hipStream_t st) {
     return check_launch("tile_backward");
 }
 
+template <int MODEL, int W, int CHF>
+static int launch_forward(const TrainArgs& f, hipStream_t st) {
+    constexpr int slots = 4 / W;
+    // LDS: per-slot score / id arrays, per-slot loss, and the transpose rows of emit_row (one per wave, or one per
+    // workgroup when a positive spans the whole workgroup)
+    const size_t shmem = (size_t)slots * slot_lds_bytes(f.eta, W) + slots * sizeof(double) + (W == 1 ? 4 : 1) * (size_t)f.K * 4;
+    if (shmem > 64 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            if (hipError_t e = hipFuncSetAttribute((const void*)train_fwdbwd_kernel<MODEL, 4, W, CHF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+                return set_error_hip(e, "hipFuncSetAttribute(train_forward_stage)");
+            attr = true;
+        }
+    }
+    const unsigned grid = (unsigned)((f.B + slots - 1) / slots);
+    if (grid) hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, 4, W, CHF, true>), dim3(grid), dim3(256), shmem, st, f);
+    return check_launch("train_forward_stage");
+}
+
 template <int MODEL>
 static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     constexpr bool TRILINEAR = (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
-    constexpr int U = TRILINEAR ? 8 : 4;   // entries in flight per wave
-    const int CH = f.nq <= 64 ? 1 : 2;
-    // F: forward + staging
-    const size_t shmem_f = 4 * slot_lds_bytes(f.eta, 1) + 4 * sizeof(double) + 4 * (size_t)f.K * 4;
-    const unsigned grid_f = (unsigned)((f.B + 3) / 4);
-    if (grid_f == 0) {}
-    else if (CH == 1) hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, 4, 1, 1, true>), dim3(grid_f), dim3(256), shmem_f, st, f);
-    else hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, 4, 1, 2, true>), dim3(grid_f), dim3(256), shmem_f, st, f);
-    if (int rc = check_launch("train_forward_stage")) return rc;
-    // T: entity tiles (the owner applies the optimizer)
+    // F: forward + staging.  Rows of up to 128 quads: one wave per positive (1 or 2 quads per lane); longer rows
+    // (k <= 2048): the four waves of a workgroup share one positive.
+    int rc;
+    if (f.nq <= 64) rc = launch_forward<MODEL, 1, 1>(f, st);
+    else if (f.nq <= 128) rc = launch_forward<MODEL, 1, 2>(f, st);
+    else if (f.nq <= 256) rc = launch_forward<MODEL, 4, 1>(f, st);
+    else rc = launch_forward<MODEL, 4, 2>(f, st);
+    if (rc) return rc;
+    // T: entity tiles (the owner applies the optimizer); quads per lane = ceil(nq / 64), entries in flight shrink with it
     const size_t shmem_t = (size_t)te.tile_rows * te.K * 4;
-    if (CH == 1) return launch_tile<MODEL, 1, U>(te, shmem_t, st);
-    return launch_tile<MODEL, 2, (TRILINEAR ? 4 : 2)>(te, shmem_t, st);
+    if (f.nq <= 64) return launch_tile<MODEL, 1, (TRILINEAR ? 8 : 4)>(te, shmem_t, st);
+    if (f.nq <= 128) return launch_tile<MODEL, 2, (TRILINEAR ? 4 : 2)>(te, shmem_t, st);
+    if (f.nq <= 256) return launch_tile<MODEL, 4, (TRILINEAR ? 2 : 1)>(te, shmem_t, st);
+    return launch_tile<MODEL, 8, 1>(te, shmem_t, st);
 }
 
 }  // namespace kge
@@ -370,7 +411,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     if (B < 0 || B >= (1ll << 30) || eta < 1) return set_error(AMDKGE_EINVAL, "train_step_tiled: B must be in [0, 2^30) and eta >= 1");
     TiledPlan p;
     if (!make_plan(m, B, eta, p))
-        return set_error(AMDKGE_EUNSUPPORTED, "train_step_tiled: shape not supported (k % 4 != 0, k > 512 or eta too large); use amdkge_train_fwdbwd + amdkge_opt_step");
+        return set_error(AMDKGE_EUNSUPPORTED, "train_step_tiled: shape not supported (k % 4 != 0, k > 2048 or eta too large); use amdkge_train_fwdbwd + amdkge_opt_step");
     if (apply_update) {
         if (opt->kind != AMDKGE_OPT_SGD && !d_ent_slot0) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 0 is NULL");
         if (opt->kind == AMDKGE_OPT_ADAM && !d_ent_slot1) return set_error(AMDKGE_EINVAL, "train_step_tiled: Adam slot 1 (v) is NULL");
@@ -388,6 +429,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     StageEntry* lists = (StageEntry*)(w + p.off_lists);
     StageEntry* ovf = (StageEntry*)(w + p.off_ovf);
     float* stage_rows = (float*)(w + p.off_rows);
+    float* rel_cs = (float*)(w + p.off_cs);
 
     TrainArgs f{};
     f.ent = d_ent; f.rel = d_rel; f.triples = d_triples; f.neg_override = d_neg_override;
@@ -402,6 +444,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
 
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
+    te.rel_cs = rel_cs;
     te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = m->k; te.K = K; te.nq = m->k / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;
@@ -424,6 +467,11 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     // B == 0 still runs the tiles: with no gradient the optimizer sweep must decay the slots / apply the
     // regulariser exactly like the dense path does
     int rc;
+    if (m->scoring_type == AMDKGE_ROTATE && B > 0) {
+        const int64_t nel = (int64_t)m->n_rels * m->k;
+        hipLaunchKernelGGL(rel_phase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, d_rel, (int64_t)m->n_rels, m->k, K, f.mc, rel_cs);
+        if ((rc = check_launch("rel_phase"))) return rc;
+    }
     switch (m->scoring_type) {
         case AMDKGE_TRANSE: rc = run_tiled<AMDKGE_TRANSE>(f, te, st); break;
         case AMDKGE_DISTMULT: rc = run_tiled<AMDKGE_DISTMULT>(f, te, st); break;

@@ -24,8 +24,8 @@ def prefer_tiled(engine):
     """Which fused train path a loop should use when the shape allows both.  Owner-computes (kge_train_tiled.hip)
     wins 2.2x for the trilinear models (single pass over the rows, no global atomics).  TransE / RotatE read the rows
     twice AND re-read side + own rows in the tile pass; measured at the C2 shape (ms/step, atomic vs tiled): TransE
-    k=52 0.059 vs 0.089, TransE k=200 0.214 vs 0.161, RotatE k=200 0.358 vs 0.402 -- so TransE switches at k >= 128
-    and RotatE stays on kge_train.hip.  AMDKGE_TRAIN_PATH=atomic|tiled forces."""
+    k=52 0.059 vs 0.089, TransE k=200 0.214 vs 0.161, RotatE k=200 0.358 vs 0.340, RotatE k=1000 eta=64 B=65536
+    52.0 vs 37.1 -- so only narrow TransE rows (k < 128) stay on kge_train.hip.  AMDKGE_TRAIN_PATH=atomic|tiled forces."""
     if not hasattr(engine, "train_step_tiled"):
         return False
     force = os.environ.get("AMDKGE_TRAIN_PATH", "")
@@ -36,7 +36,7 @@ def prefer_tiled(engine):
     model = getattr(engine, "scoring_type", "ComplEx")
     if model == "TransE":
         return getattr(engine, "k", 0) >= 128
-    return model in ("DistMult", "ComplEx", "HolE")
+    return True
 
 
 def hot_row_entries(triples, batch_size):

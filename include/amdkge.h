@@ -142,7 +142,7 @@ int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_s
  * of entity rows accumulates the staged row gradients in LDS and applies the optimizer + regulariser to its rows in
  * place.  Same reference code as amdkge_train_fwdbwd + amdkge_opt_step (ScoringBasedEmbeddingModel.py:370-429,
  * optimizers.py:136-168, regularizers.py:35-37) without global atomics or a dense gradient buffer for the entity
- * table (see `flags` for the skewed-graph variant).  Supported for all five models when k % 4 == 0 and k <= 512 (amdkge_train_tiled_workspace_bytes returns 0
+ * table (see `flags` for the skewed-graph variant).  Supported for all five models when k % 4 == 0 and k <= 2048 (amdkge_train_tiled_workspace_bytes returns 0
  * otherwise and the call returns AMDKGE_EUNSUPPORTED).
  *   apply_update : 1 -> the entity table and its slots are updated in place (single GPU);
  *                0 -> d_grad_ent receives the complete entity gradient (every row written), the relation gradient is ADDED

@@ -126,7 +126,6 @@ def test_fullsize_c5_row_width_scores_agree(gpu_lib):
     X = _triples(B, N, R, seed=3)
     eng.prepare_training("sgd")
     ps, ns = torch.empty(B, device="cuda"), torch.empty(B * eta, device="cuda")
-    assert not eng.tiled_supported(B, eta)      # k > 512: atomic path (multi-wave slot geometry)
     eng.train_fwdbwd(X, eta, _loss("self_adversarial"), 21, 4, pos_scores=ps, neg_scores=ns)
     negs = eng.sample_corruptions(X, eta, 21, 4)
     assert bool(((negs[:, 0] == X[:, 0].repeat(eta)) ^ (negs[:, 2] == X[:, 2].repeat(eta)) | (negs[:, 0] == X[:, 0].repeat(eta))).all())
@@ -139,3 +138,13 @@ def test_fullsize_c5_row_width_scores_agree(gpu_lib):
     touched[X[:, 0].long()] = True; touched[X[:, 2].long()] = True
     touched[negs[:, 0].long()] = True; touched[negs[:, 2].long()] = True
     assert float(eng.g_ent[~touched].abs().max()) == 0.0
+    # the owner-computes pair at this row width (one positive per workgroup) agrees with the atomic path
+    assert eng.tiled_supported(B, eta)
+    ge, gr, l1 = eng.g_ent.clone(), eng.g_rel.clone(), float(eng.loss_acc[0])
+    eng.g_flat.zero_(); eng.loss_acc.zero_()
+    ns2 = torch.empty(B * eta, device="cuda")
+    eng.train_step_tiled(X, eta, _loss("self_adversarial"), _ffi.Opt(0, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 1), 21, 4,
+                         grad_only=True, neg_scores=ns2)
+    assert abs(float(eng.loss_acc[0]) - l1) <= 2e-5 * abs(l1)
+    assert torch.allclose(ns2, ns, rtol=2e-5, atol=1e-5 * float(ns.abs().max()))
+    assert _rows_close(eng.g_ent, ge, 3e-4) and _rows_close(eng.g_rel, gr, 3e-4)

@@ -223,7 +223,10 @@ def test_tiled_gradients_parity(gpu_lib, model, loss, pos_atomic):
 
 @pytest.mark.parametrize("model,k,N", [("ComplEx", 200, 700), ("DistMult", 400, 5000), ("ComplEx", 352, 300),
                                          ("TransE", 52, 40000), ("RotatE", 260, 200), ("HolE", 100, 64),
-                                         ("DistMult", 4, 3), ("TransE", 512, 1000)])
+                                         ("DistMult", 4, 3), ("TransE", 512, 1000),
+                                         # one positive per workgroup (k > 512): 1 and 2 quads per lane, ragged rows
+                                         ("RotatE", 1000, 300), ("ComplEx", 1024, 150), ("DistMult", 2048, 90),
+                                         ("TransE", 600, 200), ("HolE", 516, 64), ("TransE", 2044, 50)])
 def test_tiled_geometries(gpu_lib, model, k, N):
     """1 and 2 quads per lane, one-row tiles, tiles larger than the table, ragged last tile."""
     R, B, eta = 4, 37, 5
@@ -241,7 +244,7 @@ def test_tiled_geometries(gpu_lib, model, k, N):
 def test_tiled_unsupported_shapes(gpu_lib):
     from ampligraph_amd import _ffi
 
-    for model, k in (("DistMult", 6), ("ComplEx", 1024), ("TransE", 7)):
+    for model, k in (("DistMult", 6), ("ComplEx", 2052), ("TransE", 7)):
         eng, _, _ = make_engine(model, k, 50, 3, scale=0.1)
         assert not eng.tiled_supported(10, 2)
         eng.prepare_training("sgd")
