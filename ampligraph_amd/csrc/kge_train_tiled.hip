@@ -56,6 +56,8 @@ struct TileArgs {
     int64_t n_rows;
     int k, K, nq;
     int tile_rows, n_tiles, cap, ovf_cap;
+    int gw;                   // waves that share one row (1: a wave covers the row; 4 / 8: long rows are split over a group of
+                              // waves, each lane one quad), rows are owned by wave GROUPS: TILE_WAVES / gw owners per tile
     ModelConst mc;
     OptArgs opt;
 };
@@ -96,16 +98,20 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     const int64_t t1 = min(a.n_rows, t0 + a.tile_rows);
     const int nrow = (int)(t1 - t0);
 
-    // a wave zeroes the rows it owns: no workgroup barrier is needed anywhere in this kernel
+    // Row ownership.  Short rows: wave wv owns local rows r with r % 16 == wv and covers the whole row (CH quads per lane).
+    // Long rows (gw > 1): a GROUP of gw waves owns the row and each wave covers its 64-quad slice, so that the few entries
+    // of a tile with few, long rows (C5: 18 rows of 8 KB) are spread over all lanes instead of over at most 16 owners.
+    const int gw = a.gw, grp = wv / gw, wg = wv % gw, G = TILE_WAVES / gw;
+    // an owner zeroes the rows it owns: no workgroup barrier is needed anywhere in this kernel
     bool qok[CH];
     int qoff[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        const int q = lane + 64 * c;
+        const int q = lane + 64 * c + 64 * CH * wg;
         qok[c] = q < a.nq;
         qoff[c] = (qok[c] ? q : 0) * 4;
     }
-    for (int r = wv; r < nrow; r += TILE_WAVES)
+    for (int r = grp; r < nrow; r += G)
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -206,19 +212,19 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         StageEntry mine{0u, 0u, 0.f, 0u};
         const bool in = base + lane < cnt;
         if (in) mine = list[base + lane];
-        process(mine, __ballot(in && (int)((mine.meta >> 2) % TILE_WAVES) == wv));
+        process(mine, __ballot(in && (int)((mine.meta >> 2) % G) == grp));
     }
     // ---- overflow list (entries of buckets that were full): every tile filters all of it ----
     for (int base = 0; base < on; base += 64) {
         StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
         if (base + lane < on) mine = a.ovf[base + lane];
         const bool hit = (int64_t)mine.dest >= t0 && (int64_t)mine.dest < t1;
-        process(mine, __ballot(hit && (int)((mine.meta >> 2) % TILE_WAVES) == wv));
+        process(mine, __ballot(hit && (int)((mine.meta >> 2) % G) == grp));
     }
 
     // ---- flush: the tile's rows leave LDS exactly once ------------------------------------------------
     float reg_acc = 0.f;
-    for (int r = wv; r < nrow; r += TILE_WAVES) {
+    for (int r = grp; r < nrow; r += G) {
         const float* arow = acc + (size_t)r * a.K;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -374,12 +380,11 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     else if (f.nq <= 256) rc = launch_forward<MODEL, 4, 1>(f, st);
     else rc = launch_forward<MODEL, 4, 2>(f, st);
     if (rc) return rc;
-    // T: entity tiles (the owner applies the optimizer); quads per lane = ceil(nq / 64), entries in flight shrink with it
+    // T: entity tiles (the owner applies the optimizer)
     const size_t shmem_t = (size_t)te.tile_rows * te.K * 4;
-    if (f.nq <= 64) return launch_tile<MODEL, 1, (TRILINEAR ? 8 : 4)>(te, shmem_t, st);
-    if (f.nq <= 128) return launch_tile<MODEL, 2, (TRILINEAR ? 4 : 2)>(te, shmem_t, st);
-    if (f.nq <= 256) return launch_tile<MODEL, 4, (TRILINEAR ? 2 : 1)>(te, shmem_t, st);
-    return launch_tile<MODEL, 8, 1>(te, shmem_t, st);
+    te.gw = f.nq <= 128 ? 1 : (f.nq <= 256 ? 4 : 8);
+    if (f.nq <= 64 || f.nq > 128) return launch_tile<MODEL, 1, (TRILINEAR ? 8 : 4)>(te, shmem_t, st);
+    return launch_tile<MODEL, 2, (TRILINEAR ? 4 : 2)>(te, shmem_t, st);
 }
 
 }  // namespace kge
