@@ -119,7 +119,11 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                 if (qok[c]) *reinterpret_cast<float4*>(acc + (size_t)r * a.K + qoff[c] + h * a.k) = make_float4(0, 0, 0, 0);
 
     // side-row loads of one staged entry.  All arguments are wave-uniform.
-    auto load_side = [&](uint32_t pos, uint32_t meta, float4 (&v)[CH][NC]) {
+    // Operand loads of one staged entry (all arguments wave-uniform): the staged side row and, for TransE / RotatE
+    // corruption entries, the relation row (RotatE: its cos / sin from the per-step table) and the tile's own live row.
+    // Kept apart from the arithmetic so that the loads of UNROLL entries are in flight together.
+    constexpr int NX = TRILINEAR ? 1 : NC;   // trilinear models need no relation / own-row operands
+    auto load_ops = [&](uint32_t pos, uint32_t meta, int pp, float4 (&v)[CH][NC], float4 (&pv)[CH][NX], float4 (&ev)[CH][NX]) {
         const int role = meta & 3;   // 0: corruption, object replaced; 1: corruption, subject replaced; 2: own s row; 3: own o row
         const int which = (role == 0) ? 2 : (role == 1) ? 3 : (role == 2) ? 0 : 1;
         const float* src = a.stage_rows + ((int64_t)pos * 4 + which) * a.K;
@@ -127,8 +131,23 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int h = 0; h < NC; ++h) v[c][h] = *reinterpret_cast<const float4*>(src + qoff[c] + h * a.k);
+        if constexpr (!TRILINEAR) {
+            if (role < 2) {
+                // RotatE: cos / sin of the relation phases come from a per-step table (one sincos per relation unit
+                // instead of one per bucket entry: at k = 1000, eta = 64 that is 1e6 instead of 4.3e9 evaluations)
+                const float* rp = (MODEL == AMDKGE_ROTATE ? a.rel_cs : a.rel) + (int64_t)pp * a.K;
+                const float* re = a.x + (t0 + (int)(meta >> 2)) * a.K;
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) {
+                        pv[c][h] = *reinterpret_cast<const float4*>(rp + qoff[c] + h * a.k);
+                        ev[c][h] = *reinterpret_cast<const float4*>(re + qoff[c] + h * a.k);
+                    }
+            }
+        }
     };
-    auto add_entry = [&](uint32_t pos, uint32_t meta, float g, const float4 (&v)[CH][NC]) {
+    auto add_entry = [&](uint32_t meta, float g, const float4 (&v)[CH][NC], const float4 (&pv)[CH][NX], const float4 (&ev)[CH][NX]) {
         const int role = meta & 3;
         const int lr = (int)(meta >> 2);
         float* arow = acc + (size_t)lr * a.K;
@@ -141,25 +160,14 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         } else {
             // TransE / RotatE: the gradient w.r.t. the replaced row depends on that row -> same grad_unit
             // arithmetic as the atomic path, on (side row copy, live relation row, own live row)
-            const int pp = a.triples[3 * (int64_t)pos + 1];
-            // RotatE: cos / sin of the relation phases come from a per-step table (one sincos per relation unit instead
-            // of one per bucket entry: at k = 1000, eta = 64 that is 1e6 instead of 4.3e9 evaluations)
-            const float* rp = (MODEL == AMDKGE_ROTATE ? a.rel_cs : a.rel) + (int64_t)pp * a.K;
-            const float* re = a.x + (t0 + lr) * a.K;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                float4 pv[NC], ev[NC];
-#pragma unroll
-                for (int h = 0; h < NC; ++h) {
-                    pv[h] = *reinterpret_cast<const float4*>(rp + qoff[c] + h * a.k);
-                    ev[h] = *reinterpret_cast<const float4*>(re + qoff[c] + h * a.k);
-                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float p[NC], e[NC], sd[NC], ds[NC], dp[NC], dd[NC];
 #pragma unroll
                     for (int h = 0; h < NC; ++h) {
-                        p[h] = (&pv[h].x)[u]; e[h] = (&ev[h].x)[u]; sd[h] = (&v[c][h].x)[u];
+                        p[h] = (&pv[c][h < NX ? h : 0].x)[u]; e[h] = (&ev[c][h < NX ? h : 0].x)[u]; sd[h] = (&v[c][h].x)[u];
                     }
                     if constexpr (MODEL != AMDKGE_ROTATE) prep_rel<MODEL>(a.mc, p);
                     if (role == 0) grad_unit<MODEL>(sd, p, e, g, ds, dp, dd);
@@ -181,28 +189,32 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             }
         }
     };
-    // entries of `mine` selected by `mask`, UNROLL at a time so that the side-row loads of several entries are in flight
+    // entries of `mine` selected by `mask`, UNROLL at a time so that the operand loads of several entries are in flight
     auto process = [&](const StageEntry& mine, unsigned long long mask) {
+        int mine_pp = 0;   // relation id of the lane's entry (TransE / RotatE): one gather per 64 entries, not one per entry
+        if constexpr (!TRILINEAR) {
+            if (mask) mine_pp = a.triples[3 * (int64_t)mine.pos + 1];   // mine.pos is a valid positive index (0 for padding lanes)
+        }
         while (mask) {
-            uint32_t pos[UNROLL], meta[UNROLL];
+            uint32_t meta[UNROLL];
             float g[UNROLL];
-            float4 v[UNROLL][CH][NC];
+            float4 v[UNROLL][CH][NC], pv[UNROLL][CH][NX], ev[UNROLL][CH][NX];
             int m = 0;
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 if (mask) {
                     const int tt = __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    pos[u] = __builtin_amdgcn_readlane(mine.pos, tt);
+                    const uint32_t pos = __builtin_amdgcn_readlane(mine.pos, tt);
                     meta[u] = __builtin_amdgcn_readlane(mine.meta, tt);
                     g[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.g), tt));
-                    load_side(pos[u], meta[u], v[u]);
+                    load_ops(pos, meta[u], __builtin_amdgcn_readlane(mine_pp, tt), v[u], pv[u], ev[u]);
                     m = u + 1;
                 }
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                if (u < m) add_entry(pos[u], meta[u], g[u], v[u]);
+                if (u < m) add_entry(meta[u], g[u], v[u], pv[u], ev[u]);
         }
     };
 
@@ -383,8 +395,12 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     // T: entity tiles (the owner applies the optimizer)
     const size_t shmem_t = (size_t)te.tile_rows * te.K * 4;
     te.gw = f.nq <= 128 ? 1 : (f.nq <= 256 ? 4 : 8);
-    if (f.nq <= 64 || f.nq > 128) return launch_tile<MODEL, 1, (TRILINEAR ? 8 : 4)>(te, shmem_t, st);
-    return launch_tile<MODEL, 2, (TRILINEAR ? 4 : 2)>(te, shmem_t, st);
+    // entries in flight per wave: bounded by the 128 VGPRs a 1024-thread workgroup leaves per lane (RotatE holds three
+    // complex operand rows per entry)
+    constexpr int U1 = TRILINEAR ? 8 : (MODEL == AMDKGE_ROTATE ? 2 : 4);
+    constexpr int U2 = TRILINEAR ? 4 : (MODEL == AMDKGE_ROTATE ? 1 : 2);
+    if (f.nq <= 64 || f.nq > 128) return launch_tile<MODEL, 1, U1>(te, shmem_t, st);
+    return launch_tile<MODEL, 2, U2>(te, shmem_t, st);
 }
 
 }  // namespace kge
