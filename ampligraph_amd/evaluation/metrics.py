@@ -21,3 +21,11 @@ def mr_score(ranks):
 def hits_at_n_score(ranks, n):
     r = _flat(ranks)
     return float(np.sum(r <= n) / len(r))
+
+
+def rank_score(y_true, y_pred, pos_lab=1):
+    """Rank of the positive element among the scores (metrics.py:155-193): 1 + number of elements before it when sorting
+    by decreasing score."""
+    y_true, y_pred = np.asarray(y_true), np.asarray(y_pred)
+    idx = np.argsort(y_pred)[::-1]
+    return int(np.where(y_true[idx] == pos_lab)[0][0] + 1)

@@ -35,3 +35,40 @@ def test_filter_index_reference_kat():
     fi0 = FilterIndex([], 8, 2)
     fs, fo = fi0.as_lists(np.array([[1, 1, 2]]))
     assert len(fs[0]) == 0 and len(fo[0]) == 0
+
+
+def test_evaluation_protocol_helpers():
+    """rank_score docstring KAT (metrics.py:181-185) and the invariants of train_test_split_no_unseen (protocol.py:27-198)."""
+    import numpy as np
+    import pytest
+
+    from ampligraph_amd.evaluation import filter_unseen_entities, rank_score, train_test_split_no_unseen
+
+    assert rank_score(np.array([0, 0, 1, 0]), np.array([.434, .65, .21, .84])) == 4
+    rng = np.random.default_rng(0)
+    X = np.stack([rng.integers(0, 30, 400).astype(str), rng.integers(0, 4, 400).astype(str), rng.integers(0, 30, 400).astype(str)], 1)
+    state = np.random.get_state()[1][:5].copy()
+    tr, te = train_test_split_no_unseen(X, test_size=50, seed=3)
+    assert (np.random.get_state()[1][:5] == state).all()        # the caller's numpy stream is left alone
+    assert len(te) == 50 and len(tr) == 350
+    assert set(te[:, 0]) | set(te[:, 2]) <= set(tr[:, 0]) | set(tr[:, 2]) and set(te[:, 1]) <= set(tr[:, 1])
+    both = np.concatenate([tr, te])
+    assert sorted(map(tuple, both)) == sorted(map(tuple, X))    # a partition of the input
+    tr2, te2 = train_test_split_no_unseen(X, test_size=50, seed=3)
+    assert np.array_equal(te, te2) and np.array_equal(tr, tr2)  # seeded
+    tr3, te3 = train_test_split_no_unseen(X, test_size=0.1, seed=1, filtered_test_predicates=["1", "2"])
+    assert len(te3) == int(0.1 * np.isin(X[:, 1], ["1", "2"]).sum()) and set(te3[:, 1]) <= {"1", "2"}
+    chain = np.array([["a", "r", "b"], ["b", "r", "c"], ["c", "r", "d"]])   # every triple carries an entity seen once
+    with pytest.raises(Exception):
+        train_test_split_no_unseen(chain, test_size=2)
+
+    class M:
+        pass
+
+    from ampligraph_amd.datasets.indexer import DataIndexer
+
+    m = M()
+    m.data_indexer = DataIndexer(X)
+    Y = np.array([["1", "0", "2"], ["zz", "0", "2"], ["1", "0", "qq"]])
+    assert filter_unseen_entities(Y, m).tolist() == [["1", "0", "2"]]
+    assert filter_unseen_entities(Y[:1], m) is not None and len(filter_unseen_entities(Y[:1], m)) == 1
