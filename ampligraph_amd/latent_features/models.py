@@ -167,14 +167,16 @@ class ScoringBasedEmbeddingModel:
 
     def _make_loop(self):
         reg = self._regularizers[0]
-        if reg is not None and self._regularizers[1].lam != reg.lam:
-            raise NotImplementedError("different lambdas for entity / relation tables")
         if self._spec is not None:
             from ..sharded import ShardedStepLoop
 
-            return ShardedStepLoop(self._engine, self._spec, self.eta, self.loss, self.optimizer, reg, self.seed,
+            loop = ShardedStepLoop(self._engine, self._spec, self.eta, self.loss, self.optimizer, reg, self.seed,
                                    self._dist(), negatives=self._sharded_negatives)
-        return StepLoop(self._engine, self.eta, self.loss, self.optimizer, reg, self.seed, self._dist())
+        else:
+            loop = StepLoop(self._engine, self.eta, self.loss, self.optimizer, reg, self.seed, self._dist())
+        if reg is not None and self._regularizers[1].lam != reg.lam:
+            loop.lam_rel = self._regularizers[1].lam   # [entity_reg, relation_reg] pair with different lambdas
+        return loop
 
     def _entity_table(self):
         """(N, K) entity table as a device tensor (row-sharded mode: gathered once and cached until the next fit)."""
@@ -223,9 +225,13 @@ class ScoringBasedEmbeddingModel:
         if partitioning_k != 1:
             raise NotImplementedError("partitioning_k > 1: tables are HBM-resident on MI355X, graph partitioning "
                                       "with disk swapping is out of scope (SURVEY.md section 2, rows 15-16)")
-        if validation_split:
-            raise NotImplementedError("validation_split: pass validation_data explicitly")
         X = _load_triples(x)
+        if validation_split:   # :719-728: carve the validation set out of x without creating unseen entities
+            assert isinstance(x, np.ndarray), "Validation split supported for numpy arrays only!"
+            from ..evaluation.protocol import train_test_split_no_unseen
+
+            X, validation_data = train_test_split_no_unseen(X, test_size=validation_split, seed=self.seed,
+                                                            allow_duplication=False)
         # FocusE (:714-790): active only when asked for AND the data carries numeric columns behind s, p, o
         self.use_focusE = bool(focusE) and X.shape[1] > 3
         focus_w = None

@@ -106,6 +106,7 @@ class ShardedStepLoop:
         self.loss_ffi = loss.to_ffi()
         self.optimizer = optimizer
         self.reg = regularizer
+        self.lam_rel = None   # relation-table lambda when it differs from the entity table's (same p)
         self.seed = int(seed)
         self.negatives = negatives
         self.world, self.rank = spec.world, spec.rank
@@ -173,7 +174,7 @@ class ShardedStepLoop:
             eng.g_ent[sp.n_local:sp.n_local + ex.n].zero_()
         self.dist.all_reduce(eng.g_rel)
         # ---- 4. every rank sweeps its rows and the replicated relation table -------------------------------
-        eng.opt_step(opt_ffi, lam, lam, rows_e=sp.n_local, reg_slots=(1, 2))
+        eng.opt_step(opt_ffi, lam, lam if self.lam_rel is None else self.lam_rel, rows_e=sp.n_local, reg_slots=(1, 2))
         self.n_steps += 1
 
     def reset_loss(self):

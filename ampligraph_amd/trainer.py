@@ -63,6 +63,7 @@ class StepLoop:
         self.loss_ffi = loss.to_ffi()
         self.optimizer = optimizer
         self.reg = regularizer
+        self.lam_rel = None   # relation-table lambda when it differs from the entity table's (same p)
         self.seed = int(seed)
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
@@ -98,6 +99,7 @@ class StepLoop:
             self.loss_ffi.d_focus_w = None
         self.optimizer.iterations += 1
         lam = self.reg.lam if self.reg is not None else 0.0
+        lam_r = lam if self.lam_rel is None else self.lam_rel
         opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2)
         # owner-computes path (kge_train_tiled.hip) whenever the shape allows it: no global atomics, no dense
         # entity gradient; data-parallel runs take its gradient-only form and keep the dense sweep
@@ -106,7 +108,7 @@ class StepLoop:
             self.kernel_hook(0)
         if tiled:
             eng.train_step_tiled(global_batch[lo:hi], self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step,
-                                 reg_e=lam, reg_r=lam, row_offset=lo, b_global=bg, grad_only=self.world > 1,
+                                 reg_e=lam, reg_r=lam_r, row_offset=lo, b_global=bg, grad_only=self.world > 1,
                                  pos_atomic=self.pos_atomic)
         elif hi > lo:
             eng.train_fwdbwd(global_batch[lo:hi], self.eta, self.loss_ffi, self.seed, rng_step,
@@ -117,7 +119,7 @@ class StepLoop:
             for g in eng.grad_tensors():
                 self.dist.all_reduce(g)
         if not (tiled and self.world == 1):   # the single-GPU owner-computes call is the complete step
-            eng.opt_step(opt_ffi, lam, lam)
+            eng.opt_step(opt_ffi, lam, lam_r)
         self.n_steps += 1
 
     def reset_loss(self):

@@ -550,3 +550,41 @@ def test_replicated_evaluate_splits_queries_over_ranks(gpu_lib):
     for got in ThreadedWorld(2).run(body):
         for a, b in zip(got, ref):
             assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_fit_validation_split_and_separate_lambdas(gpu_lib):
+    """validation_split (train_test_split_no_unseen inside fit, :719-728) and an [entity, relation] regulariser pair with
+    different lambdas, against the oracle replay on the same split."""
+    from ampligraph_amd.evaluation import train_test_split_no_unseen
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers, regularizers
+
+    X = toy_graph(n=500, N=40, R=3)
+    k, eta, bs, epochs, lr = 8, 3, 128, 2, 1e-2
+    m = ScoringBasedEmbeddingModel(eta=eta, k=k, scoring_type="ComplEx", seed=9)
+    regs = [regularizers.get("LP", {"p": 2, "lambda": 1e-3}), regularizers.get("LP", {"p": 2, "lambda": 5e-2})]
+    m.compile(optimizer=optimizers.get("adam", {"learning_rate": lr}), loss="nll", entity_relation_regularizer=regs)
+    h = m.fit(X, batch_size=bs, epochs=epochs, verbose=False, validation_split=0.1, validation_freq=1, validation_batch_size=64)
+    assert "val_mrr" in h.history and len(h.history["val_mrr"]) == epochs
+    Xtr, Xva = train_test_split_no_unseen(X, test_size=0.1, seed=9)
+    assert m.get_count("e") == len(set(Xtr[:, 0]) | set(Xtr[:, 2]))
+    st, Xi, hist = oracle_replay_reg("ComplEx", Xtr, k, eta, "nll", "adam", lr, bs, epochs, 9, dict(p=2, lam_e=1e-3, lam_r=5e-2))
+    assert np.allclose(h.history["loss"], hist, rtol=3e-4), (h.history["loss"], hist)
+
+
+def oracle_replay_reg(model, X, k, eta, loss, opt, lr, batch_size, epochs, seed, reg):
+    from ampligraph_amd.latent_features.initializers import initialise
+
+    ents, rels = O.first_seen_index(X)
+    Xi = O.to_indexes(X, ents, rels)
+    N, R, K = len(ents), len(rels), O.internal_k(model, k)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    st = O.TrainState(initialise("glorot_uniform", (N, K), rng), initialise("glorot_uniform", (R, K), rng), opt, lr)
+    steps = -(-len(Xi) // batch_size)
+    hist = []
+    for ep in range(epochs):
+        tot = 0.0
+        for s_ in range(steps):
+            tot += float(O.train_step(st, model, Xi[s_ * batch_size:(s_ + 1) * batch_size], eta, loss, seed, ep * steps + s_,
+                                      max_rel_size=R, reg=reg))
+        hist.append(tot / steps)
+    return st, Xi, hist
