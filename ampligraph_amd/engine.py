@@ -36,9 +36,17 @@ class KgeEngine:
         self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], self.k))
         self.model = _ffi.Model(_ffi.SCORING_TYPES[scoring_type], self.k, self.n_ents, self.n_rels,
                                 int(max_rel_size) if max_rel_size else 0, 0)
-        f32 = dict(dtype=torch.float32, device=self.device)
-        self.ent = torch.zeros(self.n_ents, self.K, **f32)
-        self.rel = torch.zeros(self.n_rels, self.K, **f32)
+        # Both tables live in ONE flat allocation (entity rows first, relation rows on a 256-byte boundary behind them),
+        # and so do their gradients and every optimizer slot: the multi-GPU step can then treat "all parameters" as one
+        # vector (single all-reduce, or slice-wise reduce-scatter / sharded sweep / all-gather).
+        ne, nr = self.n_ents * self.K, self.n_rels * self.K
+        self._ne, self._nr = ne, nr
+        self._off = (ne + 63) // 64 * 64
+        self.p_flat = self._flat()
+        self.ent = self.p_flat[:ne].view(self.n_ents, self.K)
+        self.rel = self.p_flat[self._off:self._off + nr].view(self.n_rels, self.K)
+        self.g_flat = None
+        self.slot_flat = {}
         self.g_ent = None
         self.g_rel = None
         self.slots = {}
@@ -47,6 +55,12 @@ class KgeEngine:
         self.loss_acc = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._work = None
         self._twork = None
+
+    def _flat(self, pad_to=64 * 16, fill=0.0):
+        """Flat fp32 buffer [entity part | pad | relation part | pad]; total length a multiple of `pad_to` floats so that
+        it splits evenly over up to 16 ranks in 256-byte-aligned slices."""
+        n = (self._off + self._nr + pad_to - 1) // pad_to * pad_to
+        return torch.full((n,), float(fill), dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ tables
     def set_tables(self, ent, rel):
@@ -65,22 +79,17 @@ class KgeEngine:
         if optimizer not in _ffi.OPTIMIZERS:
             raise ValueError(f"unknown optimizer {optimizer!r}")
         self.opt_kind = optimizer
-        # one flat allocation (entity part first, 16-byte aligned parts) so that the data-parallel merge is a
-        # SINGLE all-reduce over xGMI instead of one per table
-        ne, nr = self.ent.numel(), self.rel.numel()
-        off = (ne + 63) // 64 * 64   # relation part starts on a 256-byte boundary
-        self.g_flat = torch.zeros(off + nr, dtype=torch.float32, device=self.device)
+        ne, nr, off = self._ne, self._nr, self._off
+        self.g_flat = self._flat()
         self.g_ent = self.g_flat[:ne].view_as(self.ent)
         self.g_rel = self.g_flat[off:off + nr].view_as(self.rel)
-        self.slots = {}
-        if optimizer == "adam":
-            for n in ("m_e", "v_e"):
-                self.slots[n] = torch.zeros_like(self.ent)
-            for n in ("m_r", "v_r"):
-                self.slots[n] = torch.zeros_like(self.rel)
-        elif optimizer == "adagrad":  # Keras legacy Adagrad initial_accumulator_value = 0.1
-            self.slots["a_e"] = torch.full_like(self.ent, 0.1)
-            self.slots["a_r"] = torch.full_like(self.rel, 0.1)
+        self.slots, self.slot_flat = {}, {}
+        names = {"adam": ("m", "v"), "adagrad": ("a",), "sgd": ()}[optimizer]
+        for nme in names:   # Keras legacy Adagrad initial_accumulator_value = 0.1
+            fl = self._flat(fill=0.1 if nme == "a" else 0.0)
+            self.slot_flat[nme] = fl
+            self.slots[nme + "_e"] = fl[:ne].view_as(self.ent)
+            self.slots[nme + "_r"] = fl[off:off + nr].view_as(self.rel)
 
     def grad_tensors(self):
         return [self.g_flat]
@@ -156,6 +165,25 @@ class KgeEngine:
                 s0 = s1 = None
             check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(x), _ptr(g), _ptr(s0), _ptr(s1),
                                            n_el, reg_ptr, _stream()))
+
+    def opt_step_flat(self, opt_desc, lo, hi, reg_e=0.0, reg_r=0.0, reg_slot=1):
+        """Dense sweep over elements [lo, hi) of the flat parameter vector (sharded-optimizer data parallelism: a rank
+        sweeps only its slice).  The slice may straddle the entity / relation boundary; the regulariser lambda follows."""
+        segs = []
+        a, b = max(lo, 0), min(hi, self._ne)
+        if b > a:
+            segs.append((a, b, reg_e))
+        # (the padding between / behind the tables holds zero parameters and zero gradients: nothing to sweep)
+        a, b = max(lo, self._off), min(hi, self._off + self._nr)
+        if b > a:
+            segs.append((a, b, reg_r))
+        reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(reg_slot))
+        names = {"adam": ("m", "v"), "adagrad": ("a",), "sgd": ()}[self.opt_kind]
+        for a, b, lam in segs:
+            opt_desc.reg_lambda = float(lam)
+            sl = [self.slot_flat[n][a:b] for n in names] + [None, None]
+            check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(self.p_flat[a:b]), _ptr(self.g_flat[a:b]), _ptr(sl[0]),
+                                           _ptr(sl[1]), b - a, reg_ptr, _stream()))
 
     def sample_corruptions(self, triples, eta, seed, step, sample_base=0, sample_range=None,
                            row_offset=0, b_global=0):

@@ -55,9 +55,16 @@ HOT_ROW_THRESHOLD = 256.0   # expected entries on one row per batch beyond which
 
 
 class StepLoop:
-    def __init__(self, engine, eta, loss, optimizer, regularizer=None, seed=0, dist=None):
+    def __init__(self, engine, eta, loss, optimizer, regularizer=None, seed=0, dist=None, merge=None):
         """engine: KgeEngine-like backend; loss/optimizer: objects with .to_ffi(); dist: None or the
-        torch.distributed module (already initialised)."""
+        torch.distributed module (already initialised); merge: how N > 1 ranks merge gradients --
+          "sharded"   (default when the backend has flat parameter buffers): reduce-scatter by all_to_all (every rank
+                      receives the W partial sums of ITS 1/W slice of the flat gradient over all xGMI links at once and
+                      adds them), sharded optimizer sweep (each rank sweeps only its slice: 1/W of the optimizer traffic,
+                      m / v effectively sharded), all_to_all of the updated parameter slices (every rank's slice to every
+                      peer).  Same bytes on the wire as an all-reduce, but point-to-point on every link at once instead of
+                      a ring that is bound by one link.
+          "allreduce": one all-reduce of the flat gradient, every rank sweeps everything (AMDKGE_DP_MERGE=allreduce)."""
         self.engine = engine
         self.eta = int(eta)
         self.loss_ffi = loss.to_ffi()
@@ -68,11 +75,18 @@ class StepLoop:
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
+        if merge is None:
+            merge = os.environ.get("AMDKGE_DP_MERGE", "sharded")
+        if merge not in ("sharded", "allreduce"):
+            raise ValueError("merge must be 'sharded' or 'allreduce'")
+        self.merge = merge if hasattr(engine, "opt_step_flat") else "allreduce"
         self.n_steps = 0
         self.use_tiled = prefer_tiled(engine)
         self.pos_atomic = False   # see configure_for_data
         self.kernel_hook = None   # bench.py: callable(phase) recording HIP events around the fused kernel
         engine.prepare_training(optimizer.name)
+        if self.merge == "sharded" and self.world > 1 and int(engine.g_flat.numel()) % self.world != 0:
+            self.merge = "allreduce"   # the flat buffers split evenly over 1, 2, 4, 8, 16 ranks; other counts all-reduce
 
     def configure_for_data(self, triples, batch_size):
         """Pick the owner-computes variant for this training set (host-side, once per fit): skewed graphs route the
@@ -115,12 +129,36 @@ class StepLoop:
                              row_offset=lo, b_global=bg)
         if self.kernel_hook is not None:
             self.kernel_hook(1)
-        if self.world > 1:
-            for g in eng.grad_tensors():
-                self.dist.all_reduce(g)
-        if not (tiled and self.world == 1):   # the single-GPU owner-computes call is the complete step
-            eng.opt_step(opt_ffi, lam, lam_r)
+        if self.world > 1 and self.merge == "sharded":
+            self._merge_sharded(opt_ffi, lam, lam_r)
+        else:
+            if self.world > 1:
+                for g in eng.grad_tensors():
+                    self.dist.all_reduce(g)
+            if not (tiled and self.world == 1):   # the single-GPU owner-computes call is the complete step
+                eng.opt_step(opt_ffi, lam, lam_r)
         self.n_steps += 1
+
+    def _merge_sharded(self, opt_ffi, lam, lam_r):
+        """Reduce-scatter (all_to_all + local sum), sharded sweep, all_gather of the parameters."""
+        import torch
+
+        eng, W, r = self.engine, self.world, self.rank
+        g, p = eng.g_flat, eng.p_flat
+        chunk = g.numel() // W                      # the flat buffers are padded to a multiple of 16 * 64 floats
+        recv = torch.empty_like(g)
+        self.dist.all_to_all_single(recv, g)        # recv[q*chunk:(q+1)*chunk] = rank q's partial sums of MY slice
+        g.zero_()                                   # gradients of the other slices are spent
+        mine = g[r * chunk:(r + 1) * chunk]
+        torch.sum(recv.view(W, chunk), dim=0, out=mine)
+        eng.opt_step_flat(opt_ffi, r * chunk, (r + 1) * chunk, lam, lam_r, reg_slot=1)   # leaves my gradient slice zero
+        # parameters back to everyone.  Also as an all_to_all (the same slice to every peer, one link each) rather than a
+        # ring all-gather, which would push W - 1 hops through a single xGMI link.  AMDKGE_DP_GATHER=allgather switches.
+        mine_p = p[r * chunk:(r + 1) * chunk]
+        if os.environ.get("AMDKGE_DP_GATHER", "alltoall") == "allgather":
+            self.dist.all_gather_into_tensor(p, mine_p.clone())
+        else:
+            self.dist.all_to_all_single(p, mine_p.expand(W, chunk).contiguous().view(-1))
 
     def reset_loss(self):
         self.engine.loss_acc.zero_()
@@ -129,9 +167,14 @@ class StepLoop:
     def mean_batch_loss(self):
         """Keras Mean('loss') of the per-batch total loss (loss_functions.py:224): (sum over batches of
         data loss + regulariser loss) / #batches.  The data loss is summed over ranks; the regulariser
-        term is identical on every rank (replicated tables) and counted once."""
+        term is identical on every rank (replicated tables, all-reduce merge: counted once) or split over the
+        ranks' slices (sharded merge: summed)."""
         acc = self.engine.loss_acc.clone()
-        if self.world > 1:
+        if self.world > 1 and self.merge == "sharded":
+            both = acc[0:2].clone()
+            self.dist.all_reduce(both)
+            acc[0], acc[1] = both[0], both[1]
+        elif self.world > 1:
             data = acc[0:1].clone()
             self.dist.all_reduce(data)
             acc[0] = data[0]

@@ -257,7 +257,7 @@ def main():
                        "global_batch": Bg, "n_ents": N, "n_rels": R, "row_floats": eng.K,
                        "parallelism": (f"rows{world} (row-sharded entity table, {args.parallelism.split('-')[1]} negatives, "
                                        "all_to_all row/gradient exchange)" if sharded else
-                                       f"dp{world} (replicated tables, gradient all-reduce)" if world > 1 else "single GPU")},
+                                       f"dp{world} (replicated tables, gradient merge: {getattr(loop, 'merge', 'allreduce')})" if world > 1 else "single GPU")},
             "mean_batch_loss": loss_mean,
             "roofline": {"bound": "hbm", "kernel": " + ".join(kernel_names), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -11,8 +11,12 @@ OPT_BY_ID = {0: "sgd", 1: "adagrad", 2: "adam"}
 
 
 class OracleEngine:
-    def __init__(self, model, k, ent, rel, tiled=False):
+    def __init__(self, model, k, ent, rel, tiled=False, flat=False):
         self.model, self.k = model, k
+        self.flat = flat   # flat parameter / gradient / slot buffers like KgeEngine (sharded-optimizer merge)
+        self.flat_sweeps = 0
+        if flat:
+            self.opt_step_flat = self._opt_step_flat
         if tiled:   # expose the owner-computes entry points of KgeEngine (same calling convention)
             self.train_step_tiled = self._train_step_tiled
             self.tiled_supported = lambda B, eta: True
@@ -62,9 +66,52 @@ class OracleEngine:
     def prepare_training(self, optimizer):
         self.state = O.TrainState(self.ent0, self.rel0, optimizer, 0.0)
         ne, nr = self.ent0.size, self.rel0.size
-        self.g_flat = torch.zeros(ne + nr, dtype=torch.float32)
+        if not self.flat:
+            self.g_flat = torch.zeros(ne + nr, dtype=torch.float32)
+            self.g_ent = self.g_flat[:ne].view(self.ent0.shape)
+            self.g_rel = self.g_flat[ne:].view(self.rel0.shape)
+            return
+        # KgeEngine layout: [entity | pad to 64 | relation | pad to 1024]
+        self._ne, self._nr, self._off = ne, nr, (ne + 63) // 64 * 64
+        n = (self._off + nr + 1023) // 1024 * 1024
+
+        def flat_of(a_e, a_r, fill=0.0):
+            f = np.full(n, fill, dtype=np.float32)
+            f[:ne] = a_e.reshape(-1)
+            f[self._off:self._off + nr] = a_r.reshape(-1)
+            return f
+
+        self._p = flat_of(self.state.ent, self.state.rel)
+        self.state.ent = self._p[:ne].reshape(self.ent0.shape)          # numpy views: the oracle updates in place
+        self.state.rel = self._p[self._off:self._off + nr].reshape(self.rel0.shape)
+        self._slot_flat = {}
+        for key in sorted({k[0] for k in self.state.slots}):
+            f = flat_of(self.state.slots[key + "_e"], self.state.slots[key + "_r"], fill=0.1 if key == "a" else 0.0)
+            self._slot_flat[key] = f
+            self.state.slots[key + "_e"] = f[:ne].reshape(self.ent0.shape)
+            self.state.slots[key + "_r"] = f[self._off:self._off + nr].reshape(self.rel0.shape)
+        self.p_flat = torch.from_numpy(self._p)
+        self.g_flat = torch.zeros(n, dtype=torch.float32)
         self.g_ent = self.g_flat[:ne].view(self.ent0.shape)
-        self.g_rel = self.g_flat[ne:].view(self.rel0.shape)
+        self.g_rel = self.g_flat[self._off:self._off + nr].view(self.rel0.shape)
+
+    def _opt_step_flat(self, opt, lo, hi, reg_e=0.0, reg_r=0.0, reg_slot=1):
+        """Sweep elements [lo, hi) of the flat vector only: run the whole-table oracle sweep, then put everything outside
+        the slice back."""
+        self.flat_sweeps += 1
+        keep_p = self._p.copy()
+        keep_s = {k: v.copy() for k, v in self._slot_flat.items()}
+        reg_before = self.loss_acc.clone()
+        self._sweep(opt, reg_e, reg_r, (reg_slot, reg_slot), None)
+        self.loss_acc.copy_(reg_before)
+        for lam, a, b in ((reg_e, max(lo, 0), min(hi, self._ne)), (reg_r, max(lo, self._off), min(hi, self._off + self._nr))):
+            if lam and b > a:
+                self.loss_acc[reg_slot] += lam * float((np.abs(keep_p[a:b].astype(np.float64)) ** opt.reg_p).sum())
+        mask = np.ones(self._p.shape, dtype=bool)
+        mask[lo:hi] = False
+        self._p[mask] = keep_p[mask]
+        for k, v in self._slot_flat.items():
+            v[mask] = keep_s[k][mask]
 
     def grad_tensors(self):
         return [self.g_flat]

@@ -31,7 +31,7 @@ def _problem():
     return ent, rel, X, k
 
 
-def _run(world, rank, port, out, tiled=False):
+def _run(world, rank, port, out, tiled=False, flat=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_backend import OracleEngine
@@ -44,7 +44,7 @@ def _run(world, rank, port, out, tiled=False):
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         d = dist
     ent, rel, X, k = _problem()
-    eng = OracleEngine("ComplEx", k, ent, rel, tiled=tiled)
+    eng = OracleEngine("ComplEx", k, ent, rel, tiled=tiled, flat=flat)
     loop = StepLoop(eng, 3, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}),
                     regularizers.get("LP", {"p": 2, "lambda": 1e-3}), seed=5, dist=d)
     Xt = torch.as_tensor(X)
@@ -56,6 +56,8 @@ def _run(world, rank, port, out, tiled=False):
             loop.step(Xt[b0:b0 + bs], step)
             step += 1
     loss = loop.mean_batch_loss()
+    if world > 1:
+        assert loop.merge == ("sharded" if flat else "allreduce") and (eng.flat_sweeps > 0) == flat
     if rank == 0:
         np.savez(out, ent=eng.state.ent, rel=eng.state.rel, loss=loss, calls=np.array(eng.calls))
     if world > 1:
@@ -75,10 +77,12 @@ def test_shard_bounds():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.parametrize("tiled", [False, True])
-def test_two_ranks_equal_one_rank(tmp_path, tiled):
+@pytest.mark.parametrize("tiled,flat", [(False, False), (True, False), (True, True), (False, True)])
+def test_two_ranks_equal_one_rank(tmp_path, tiled, flat):
     """tiled=True drives StepLoop through the owner-computes entry points: in-place entity update +
-    relation-only sweep on one rank, gradient-only form + all-reduce + dense sweep on two."""
+    relation-only sweep on one rank, gradient-only form + merge on two.  flat=True gives the engine KgeEngine's flat
+    parameter buffers, which selects the sharded merge (all_to_all reduce-scatter, sharded sweep, all_gather); flat=False
+    keeps the all-reduce merge."""
     single = str(tmp_path / "single.npz")
     _run(1, 0, 0, single, tiled)
     if tiled:   # the two single-rank paths agree with each other as well
@@ -89,7 +93,7 @@ def test_two_ranks_equal_one_rank(tmp_path, tiled):
         assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5 * abs(float(a["loss"]))
     port = _free_port()
     multi = str(tmp_path / "multi.npz")
-    mp.spawn(_run_spawn, args=(2, port, multi, tiled), nprocs=2, join=True)
+    mp.spawn(_run_spawn, args=(2, port, multi, tiled, flat), nprocs=2, join=True)
     a, b = np.load(single), np.load(multi)
     assert np.abs(a["ent"] - b["ent"]).max() < 5e-6
     assert np.abs(a["rel"] - b["rel"]).max() < 5e-6
@@ -99,5 +103,5 @@ def test_two_ranks_equal_one_rank(tmp_path, tiled):
     assert (calls[:, 1] == 0).all() and set(calls[:, 2]) == {37, 27} and set(calls[:, 0]) == {18, 13}
 
 
-def _run_spawn(rank, world, port, out, tiled=False):
-    _run(world, rank, port, out, tiled)
+def _run_spawn(rank, world, port, out, tiled=False, flat=False):
+    _run(world, rank, port, out, tiled, flat)

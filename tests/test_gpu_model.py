@@ -534,6 +534,7 @@ def test_replicated_evaluate_splits_queries_over_ranks(gpu_lib):
         m.fit(X, batch_size=128, epochs=2, verbose=False)
         return m
 
+    sums = []
     m1 = make()
     ref = [m1.evaluate(Xt, use_filter=True, corrupt_side="s,o", verbose=False),
            m1.evaluate(Xt, use_filter={"train": X}, corrupt_side="s+o", ranking_strategy="middle", verbose=False),
@@ -542,6 +543,13 @@ def test_replicated_evaluate_splits_queries_over_ranks(gpu_lib):
 
     def body(dist):
         m = make(dist)
+        # data-parallel fit of two replicas (sharded merge: all_to_all reduce-scatter, sharded Adam sweep, all_gather of
+        # the parameters) == the single-GPU fit up to fp32 summation order, and the replicas hold identical tables
+        assert m._loop.merge == "sharded" and m._loop.world == 2
+        ed, rd = m._engine.get_tables()
+        assert np.allclose(m.history.history["loss"], m1.history.history["loss"], rtol=2e-4)
+        assert np.mean(np.abs(ed - e1) <= 1e-5 + 1e-3 * np.abs(e1)) > 0.995 and np.abs(rd - r1).max() < 2.5e-2
+        sums.append((float(np.abs(ed).sum()), float(np.abs(rd).sum())))
         m._engine.set_tables(e1, r1)   # identical tables: DP training differs only by fp32 summation order
         return [m.evaluate(Xt, use_filter=True, corrupt_side="s,o", verbose=False),
                 m.evaluate(Xt, use_filter={"train": X}, corrupt_side="s+o", ranking_strategy="middle", verbose=False),
@@ -550,6 +558,7 @@ def test_replicated_evaluate_splits_queries_over_ranks(gpu_lib):
     for got in ThreadedWorld(2).run(body):
         for a, b in zip(got, ref):
             assert a.shape == b.shape and np.array_equal(a, b)
+    assert len(sums) == 2 and sums[0] == sums[1]
 
 
 def test_fit_validation_split_and_separate_lambdas(gpu_lib):

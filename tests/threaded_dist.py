@@ -72,6 +72,11 @@ class ThreadedDist:
             o.copy_(p)
         self.barrier()
 
+    def all_gather_into_tensor(self, out, t):
+        parts = self._exchange(t.clone())
+        out.copy_(torch.cat([p.reshape(-1) for p in parts]).view_as(out))
+        self.barrier()
+
     def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
         W = self.w.world
         if in_splits is None:
