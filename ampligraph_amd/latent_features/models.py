@@ -589,6 +589,8 @@ class ScoringBasedEmbeddingModel:
             # not part of this file -- sharded checkpoints are a "next" row)
             arrays = {"ent": self._entity_table().cpu().numpy(), "rel": self._engine.rel.cpu().numpy()}
         else:
+            if self._loop is not None and hasattr(self._loop, "sync_optimizer_slots"):
+                self._loop.sync_optimizer_slots()   # data-parallel sharded merge: collective, call on every rank
             ent, rel = self._engine.get_tables()
             arrays = {"ent": ent, "rel": rel}
             for kname, t in self._engine.slots.items():

@@ -160,6 +160,16 @@ class StepLoop:
         else:
             self.dist.all_to_all_single(p, mine_p.expand(W, chunk).contiguous().view(-1))
 
+    def sync_optimizer_slots(self):
+        """Sharded merge: every rank only maintains ITS slice of the optimizer slots.  Before a checkpoint is written
+        the slices are exchanged so that any rank holds the complete m / v / accumulator tables."""
+        if self.world == 1 or self.merge != "sharded":
+            return
+        W, r = self.world, self.rank
+        for fl in self.engine.slot_flat.values():
+            chunk = fl.numel() // W
+            self.dist.all_to_all_single(fl, fl[r * chunk:(r + 1) * chunk].expand(W, chunk).contiguous().view(-1))
+
     def reset_loss(self):
         self.engine.loss_acc.zero_()
         self.n_steps = 0

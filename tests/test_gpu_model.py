@@ -550,6 +550,12 @@ def test_replicated_evaluate_splits_queries_over_ranks(gpu_lib):
         assert np.allclose(m.history.history["loss"], m1.history.history["loss"], rtol=2e-4)
         assert np.mean(np.abs(ed - e1) <= 1e-5 + 1e-3 * np.abs(e1)) > 0.995 and np.abs(rd - r1).max() < 2.5e-2
         sums.append((float(np.abs(ed).sum()), float(np.abs(rd).sum())))
+        # checkpoint from a data-parallel run: the sharded optimizer slots are exchanged first, so every rank writes the
+        # same complete Adam state as the single-GPU run holds
+        m._loop.sync_optimizer_slots()
+        for nme in ("m_e", "v_e", "m_r", "v_r"):
+            a_, b_ = m._engine.slots[nme].cpu().numpy(), m1._engine.slots[nme].cpu().numpy()
+            assert np.allclose(a_, b_, rtol=2e-3, atol=1e-7), nme
         m._engine.set_tables(e1, r1)   # identical tables: DP training differs only by fp32 summation order
         return [m.evaluate(Xt, use_filter=True, corrupt_side="s,o", verbose=False),
                 m.evaluate(Xt, use_filter={"train": X}, corrupt_side="s+o", ranking_strategy="middle", verbose=False),
