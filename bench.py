@@ -7,7 +7,8 @@ positives per GPU per step (the reference docstring's batch, ScoringBasedEmbeddi
 One "step" = one pass of the hot path over one batch = the product's StepLoop.step: at N=1 the
 owner-computes pair (kge_train_tiled.hip: fused lookup/sampling/score/loss/backward + staging kernel,
 then the per-tile LDS accumulation kernel that also applies Adam to both tables); at N>1 the same pair
-in its gradient-only form + gradient all-reduce over RCCL + dense optimizer sweep.
+in its gradient-only form + the data-parallel merge over RCCL/xGMI (reduce-scatter by all_to_all, sharded
+optimizer sweep, all_to_all of the updated parameter slices; AMDKGE_DP_MERGE=allreduce for one all-reduce).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run
 (one rank per GPU).  Rank 0 prints ONE JSON line.  Extra objects: `roofline` (the train-step kernel pair,
