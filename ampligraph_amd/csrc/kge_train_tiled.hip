@@ -319,7 +319,9 @@ static int pick_tile_rows(int64_t n_rows, int K) {
     int fit = (int)(budget / ((size_t)K * 4));
     if (fit < 1) return 0;
     if (fit > 4096) fit = 4096;
-    for (int64_t m = 1;; ++m) {   // smallest number of block waves m whose tile size fits
+    int64_t m0 = 1;
+    if (const char* e = getenv("AMDKGE_TILE_M")) m0 = atoi(e) > 0 ? atoi(e) : 1;   // development: more, smaller tiles
+    for (int64_t m = m0;; ++m) {   // smallest number of block waves m whose tile size fits
         const int64_t r = (n_rows + 256 * m - 1) / (256 * m);
         if (r <= fit) return (int)(r < 1 ? 1 : r);
     }
