@@ -147,6 +147,14 @@ __device__ __forceinline__ void prep_rel(const ModelConst& mc, float (&p)[ModelT
     }
 }
 
+#ifdef KGE_FAST_ROTATE
+#define KGE_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define KGE_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#else
+#define KGE_SQRT(x) sqrtf(x)
+#define KGE_DIV(a, b) ((a) / (b))
+#endif
+
 // un-negated, un-scaled contribution of one unit to the score
 template <int MODEL>
 __device__ __forceinline__ float score_unit(const float (&s)[ModelTraits<MODEL>::NC], const float (&p)[ModelTraits<MODEL>::NC],
@@ -162,7 +170,7 @@ __device__ __forceinline__ float score_unit(const float (&s)[ModelTraits<MODEL>:
         // RotatE.py:100-104 ; p = (cos, sin)
         const float re = s[0] * p[0] - s[1] * p[1] - o[0];
         const float im = s[0] * p[1] + s[1] * p[0] - o[1];
-        return sqrtf(re * re + im * im);
+        return KGE_SQRT(re * re + im * im);
     }
 }
 
@@ -187,8 +195,8 @@ __device__ __forceinline__ void grad_unit(const float (&s)[ModelTraits<MODEL>::N
         const float c = p[0], sn = p[1];
         const float re = s[0] * c - s[1] * sn - o[0];
         const float im = s[0] * sn + s[1] * c - o[1];
-        const float m = sqrtf(re * re + im * im);
-        const float gm = g / m;  // no epsilon: m == 0 -> NaN exactly like the reference (RotatE.py:102-104)
+        const float m = KGE_SQRT(re * re + im * im);
+        const float gm = KGE_DIV(g, m);  // no epsilon: m == 0 -> NaN exactly like the reference (RotatE.py:102-104)
         ds[0] = gm * (re * c + im * sn);
         ds[1] = gm * (-re * sn + im * c);
         dp[0] = gm * (re * (-s[0] * sn - s[1] * c) + im * (s[0] * c - s[1] * sn));
