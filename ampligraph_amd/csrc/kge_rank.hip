@@ -28,6 +28,11 @@ template <> struct ModeTraits<MODE_L1_SUB> { static constexpr int NQF = 1, NEF =
 template <> struct ModeTraits<MODE_ROT_O> { static constexpr int NQF = 2, NEF = 2; };
 template <> struct ModeTraits<MODE_ROT_S> { static constexpr int NQF = 4, NEF = 2; };
 
+// RotatE's per-unit modulus: the hardware v_sqrt_f32 (1 ulp).  One sqrt per (query, entity, unit) is what bounds RotatE's
+// evaluation; its 1-ulp error is below the fp32 summation-order noise the ranks already tolerate (oracle.fragile_rank_mask),
+// and the tile and the filter kernel share this function, so they still agree bit for bit.
+__device__ __forceinline__ float rank_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 // One unit of the corruption score, accumulated in unit order.  Shared by the tile kernel and the
 // filter kernel so that both produce bitwise identical scores (compiled with -ffp-contract=off).
 template <int MODE>
@@ -42,12 +47,12 @@ __device__ __forceinline__ float rank_op(float acc, const float (&q)[ModeTraits<
                                            // parameter, not a multiply: 2 VALU instructions per unit instead of 3
     } else if constexpr (MODE == MODE_ROT_O) {
         const float re = q[0] - e[0], im = q[1] - e[1];   // RotatE.py:209-214
-        return acc + sqrtf(re * re + im * im);
+        return acc + rank_sqrt(re * re + im * im);
     } else {
         // q = (cos, sin, o_re, o_im) ; RotatE.py:151-160
         const float re = e[0] * q[0] - e[1] * q[1] - q[2];
         const float im = e[0] * q[1] + e[1] * q[0] - q[3];
-        return acc + sqrtf(re * re + im * im);
+        return acc + rank_sqrt(re * re + im * im);
     }
 }
 

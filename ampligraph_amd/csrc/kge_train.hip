@@ -15,8 +15,8 @@
 
 // RotatE's modulus and its reciprocal in the TRAINING kernels use the hardware v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the
 // correctly rounded libm sequences: the fused kernels are bound by exactly these on RotatE (measured 1.26x on the step);
-// loss and gradients stay far inside the 1e-5 relative tolerance of the parity tests.  predict() and the rank kernels
-// (kge_score.hip, kge_rank.hip) keep the exact forms.  Device functions are inlined per kernel, so the two variants of
+// loss and gradients stay far inside the 1e-5 relative tolerance of the parity tests.  predict() (kge_score.hip) keeps the
+// exact forms; the rank kernels have their own rank_sqrt.  Device functions are inlined per kernel, so the two variants of
 // score_unit / grad_unit never meet at link time.
 #define KGE_FAST_ROTATE 1
 
