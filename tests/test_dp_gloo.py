@@ -105,3 +105,48 @@ def test_two_ranks_equal_one_rank(tmp_path, tiled, flat):
 
 def _run_spawn(rank, world, port, out, tiled=False, flat=False):
     _run(world, rank, port, out, tiled, flat)
+
+
+def test_three_ranks_fall_back_to_allreduce(tmp_path):
+    """The flat buffers split evenly over 1, 2, 4, 8, 16 ranks; any other count keeps the all-reduce merge and must
+    still reproduce the single-rank run."""
+    single = str(tmp_path / "single.npz")
+    _run(1, 0, 0, single, True, True)
+    port = _free_port()
+    multi = str(tmp_path / "multi.npz")
+    mp.spawn(_run_spawn3, args=(3, port, multi), nprocs=3, join=True)
+    a, b = np.load(single), np.load(multi)
+    assert np.abs(a["ent"] - b["ent"]).max() < 5e-6 and np.abs(a["rel"] - b["rel"]).max() < 5e-6
+    assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5 * abs(float(a["loss"]))
+
+
+def _run_spawn3(rank, world, port, out):
+    _run3(world, rank, port, out)
+
+
+def _run3(world, rank, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleEngine
+
+    from ampligraph_amd.latent_features import loss_functions, optimizers, regularizers
+    from ampligraph_amd.trainer import StepLoop
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ent, rel, X, k = _problem()
+    eng = OracleEngine("ComplEx", k, ent, rel, tiled=True, flat=True)
+    loop = StepLoop(eng, 3, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}),
+                    regularizers.get("LP", {"p": 2, "lambda": 1e-3}), seed=5, dist=dist)
+    assert loop.merge == "allreduce"   # 1024-float padding does not split over 3 ranks
+    Xt = torch.as_tensor(X)
+    loop.reset_loss()
+    step = 0
+    for ep in range(2):
+        for b0 in range(0, X.shape[0], 37):
+            loop.step(Xt[b0:b0 + 37], step)
+            step += 1
+    loss = loop.mean_batch_loss()
+    if rank == 0:
+        np.savez(out, ent=eng.state.ent, rel=eng.state.rel, loss=loss)
+    dist.barrier()
+    dist.destroy_process_group()
