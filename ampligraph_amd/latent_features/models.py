@@ -133,6 +133,7 @@ class ScoringBasedEmbeddingModel:
 
         self.max_ent_size, self.max_rel_size = int(n_ents), int(n_rels)
         self._n_ents, self._n_rels = int(n_ents), int(n_rels)
+        self._filter_cache = (None, None)   # a new id map invalidates cached filter indexes
         if tables is None:
             rng = np.random.Generator(np.random.PCG64(self.seed))
             ent = initialise(self._initializers[0], (n_ents, self.internal_k), rng)
@@ -323,6 +324,34 @@ class ScoringBasedEmbeddingModel:
         self.is_fitted = True
         return self.history
 
+    # ------------------------------------------------------------------------------------ filters
+    def _filter_index(self, use_filter, Xi):
+        """FilterIndex for evaluate(): the union of the given datasets (dict) or the evaluated data itself (True), all
+        indexed with the training id map (graph_data_loader.py:184-190,652-653).  Building it costs host time comparable
+        to tens of evaluations on the device (string -> id mapping + sort of the union), so the last one is cached by
+        content checksum: validation during fit() and repeated evaluate() calls reuse it."""
+        import zlib
+
+        if isinstance(use_filter, dict):
+            arrays = [_load_triples(v)[:, :3] for v in use_filter.values()]
+            key = []
+            for a in arrays:
+                a = np.ascontiguousarray(a)
+                if a.dtype == object:
+                    key = None
+                    break
+                key.append((a.shape, str(a.dtype), zlib.crc32(a.view(np.uint8).reshape(-1))))
+            key = None if key is None else ("dict", tuple(key), self._n_ents, self._n_rels)
+            if key is not None and getattr(self, "_filter_cache", (None, None))[0] == key:
+                return self._filter_cache[1]
+            fi = FilterIndex([self.data_indexer.get_indexes(a) for a in arrays], self._n_ents, self._n_rels)
+            if key is not None:
+                self._filter_cache = (key, fi)
+            return fi
+        if use_filter:
+            return FilterIndex([Xi], self._n_ents, self._n_rels)
+        return None
+
     # ------------------------------------------------------------------------------------ predict
     def _index_test(self, x):
         assert self.is_fitted, "Model is not fit on the data yet!"
@@ -368,12 +397,7 @@ class ScoringBasedEmbeddingModel:
             return self._evaluate_split_queries(d, x, Xi, use_filter, corrupt_side, entities_subset, ranking_strategy)
         # filters (graph_data_loader.py:184-190,652-653): True -> the evaluated data filters itself;
         # dict -> union of the given datasets, all indexed with the training id map
-        fi = None
-        if isinstance(use_filter, dict):
-            fi = FilterIndex([self.data_indexer.get_indexes(_load_triples(v)[:, :3]) for v in use_filter.values()],
-                             self._n_ents, self._n_rels)
-        elif use_filter:
-            fi = FilterIndex([Xi], self._n_ents, self._n_rels)
+        fi = self._filter_index(use_filter, Xi)
         dev = eng.device
         ent_ids = subset_pos = None
         if entities_subset is not None and len(entities_subset) > 0:
@@ -439,12 +463,7 @@ class ScoringBasedEmbeddingModel:
         if entities_subset is not None and len(entities_subset) > 0:
             raise NotImplementedError("entities_subset with a row-sharded entity table")
         eng, d = self._engine, self._dist()
-        fi = None
-        if isinstance(use_filter, dict):
-            fi = FilterIndex([self.data_indexer.get_indexes(_load_triples(v)[:, :3]) for v in use_filter.values()],
-                             self._n_ents, self._n_rels)
-        elif use_filter:
-            fi = FilterIndex([Xi], self._n_ents, self._n_rels)
+        fi = self._filter_index(use_filter, Xi)
         dev = eng.device
         n = Xi.shape[0]
         ranks = torch.empty(n, len(sides), dtype=torch.int32, device=dev)
