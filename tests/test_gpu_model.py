@@ -603,3 +603,28 @@ def oracle_replay_reg(model, X, k, eta, loss, opt, lr, batch_size, epochs, seed,
                                       max_rel_size=R, reg=reg))
         hist.append(tot / steps)
     return st, Xi, hist
+
+
+def test_filter_index_cache(gpu_lib):
+    """evaluate() caches the filter index by content: same datasets -> same object and same ranks; changed content or a
+    new fit (new id map) -> rebuilt."""
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel
+
+    X = toy_graph(n=400, N=40, R=3)
+    m = ScoringBasedEmbeddingModel(eta=2, k=8, scoring_type="DistMult", seed=1)
+    m.compile(optimizer="adam", loss="nll")
+    m.fit(X[:300], batch_size=100, epochs=1, verbose=False)
+    flt = {"train": X[:300], "test": X[300:]}
+    r1 = m.evaluate(X[300:], use_filter=flt, verbose=False)
+    fi1 = m._filter_cache[1]
+    r2 = m.evaluate(X[300:], use_filter={"a": X[:300].copy(), "b": X[300:].copy()}, verbose=False)   # equal content, new arrays
+    assert m._filter_cache[1] is fi1 and np.array_equal(r1, r2)
+    X2 = X.copy()
+    X2[0, 2] = X2[1, 2]
+    m.evaluate(X[300:], use_filter={"train": X2[:300], "test": X[300:]}, verbose=False)
+    assert m._filter_cache[1] is not fi1
+    m.fit(X[:300], batch_size=100, epochs=1, verbose=False)   # continue training keeps the id map ...
+    m2 = ScoringBasedEmbeddingModel(eta=2, k=8, scoring_type="DistMult", seed=1)
+    m2.compile(optimizer="adam", loss="nll")
+    m2.fit(X[:200], batch_size=100, epochs=1, verbose=False)
+    assert m2._filter_cache == (None, None)                   # ... a new model starts empty
