@@ -1,0 +1,179 @@
+"""AmpliGraph-1.x style API on top of the engine: the adapter classes of /root/reference/ampligraph/compat/models.py
+(`TransE`, `DistMult`, `ComplEx`, `HolE`, base :29-632) and `evaluate_performance` (compat/evaluate.py:17-179).
+
+Pure argument mapping onto ampligraph_amd.latent_features.ScoringBasedEmbeddingModel -- what
+experiments/predictive_performance.py:153-217 and 1.x user code call:
+    model = ComplEx(batches_count=10, epochs=20, k=200, eta=20, loss="self_adversarial", optimizer="adam",
+                    optimizer_params={"lr": 1e-3}, regularizer="LP", regularizer_params={"p": 3, "lambda": 1e-5})
+    model.fit(X_train); ranks = evaluate_performance(X_test, model, filter_triples=X_all)
+"""
+import math
+
+import numpy as np
+
+from .callbacks import EarlyStopping
+from .latent_features import ScoringBasedEmbeddingModel, loss_functions, optimizers, regularizers
+
+_DEFAULT_EMB_PARAMS = {"corrupt_sides": ["s,o"], "negative_corruption_entities": "all", "norm": 1, "normalize_ent_emb": False}
+
+
+class ScoringModelBase:
+    model_name = None
+
+    def __init__(self, k=100, eta=2, epochs=100, batches_count=100, seed=0, embedding_model_params=None, optimizer="adam",
+                 optimizer_params=None, loss="nll", loss_params=None, regularizer=None, regularizer_params=None,
+                 initializer="xavier", initializer_params=None, verbose=False, model=None):
+        if model is not None:
+            self.model_name = model.scoring_type
+        self.k, self.eta, self.seed, self.batches_count, self.epochs = k, eta, seed, batches_count, epochs
+        self.embedding_model_params = dict(_DEFAULT_EMB_PARAMS if embedding_model_params is None else embedding_model_params)
+        self.optimizer, self.optimizer_params = optimizer, dict({"lr": 0.0005} if optimizer_params is None else optimizer_params)
+        self.loss, self.loss_params = loss, dict(loss_params or {})
+        self.regularizer, self.regularizer_params = regularizer, dict(regularizer_params or {})
+        self.initializer = initializer
+        self.initializer_params = dict({"uniform": False} if initializer_params is None else initializer_params)
+        self.verbose = verbose
+        self.model = model
+        self.is_backward = True
+
+    # -- argument mapping ------------------------------------------------------------------------------------------
+    def _get_initializer(self):
+        """compat/models.py:184-217 (Keras initialisers by the 1.x names)."""
+        ini, prm = self.initializer, self.initializer_params
+        if ini is None:
+            return "glorot_uniform"
+        if ini == "xavier":
+            return "glorot_uniform" if prm.get("uniform", False) else "glorot_normal"
+        if ini == "uniform":
+            lo, hi = prm.get("low", -0.05), prm.get("high", 0.05)
+            return lambda shape, rng: rng.uniform(lo, hi, size=shape)
+        if ini == "normal":
+            mu, sd = prm.get("mean", 0.0), prm.get("std", 0.05)
+            return lambda shape, rng: rng.normal(mu, sd, size=shape)
+        if ini == "constant":
+            e, r = prm.get("entity", None), prm.get("relation", None)
+            assert e is not None, "Please pass the `entity` initializer value"
+            assert r is not None, "Please pass the `relation` initializer value"
+            return [lambda shape, rng: np.broadcast_to(np.asarray(e, dtype=np.float32), shape).copy(),
+                    lambda shape, rng: np.broadcast_to(np.asarray(r, dtype=np.float32), shape).copy()]
+        return ini
+
+    def _get_optimizer(self):
+        prm = dict(self.optimizer_params)
+        lr = prm.pop("lr", 0.001)
+        return optimizers.get(self.optimizer, dict(prm, learning_rate=lr))
+
+    # -- 1.x surface -----------------------------------------------------------------------------------------------
+    def is_fit(self):
+        return self.model is not None and self.model.is_fit()
+
+    def fit(self, X, early_stopping=False, early_stopping_params=None, focusE_numeric_edge_values=None,
+            tensorboard_logs_path=None, callbacks=None, verbose=False):
+        """compat/models.py:219-395: batches_count -> batch_size = ceil(n / batches_count); early stopping = validation +
+        EarlyStopping(monitor=val_<criteria>, patience=stop_interval, restore_best_weights)."""
+        esp = dict(early_stopping_params or {})
+        self.model = ScoringBasedEmbeddingModel(self.eta, self.k, scoring_type=self.model_name, seed=self.seed)
+        reg = self.regularizer
+        if reg is not None:
+            reg = regularizers.get(reg, self.regularizer_params)
+        self.model.compile(optimizer=self._get_optimizer(), loss=loss_functions.get(self.loss, self.loss_params),
+                           entity_relation_initializer=self._get_initializer(), entity_relation_regularizer=reg)
+        cbs = list(callbacks or [])
+        if len(esp) != 0:
+            cbs.append(EarlyStopping(monitor="val_{}".format(esp.get("criteria", "mrr")), min_delta=0,
+                                     patience=esp.get("stop_interval", 10), verbose=self.verbose, mode="max",
+                                     restore_best_weights=True))
+        x_filter = esp.get("x_filter", None)
+        if isinstance(x_filter, (np.ndarray, list)):
+            x_filter = {"test": x_filter}
+        elif x_filter is None or (not isinstance(x_filter, dict) and not x_filter):
+            x_filter = False
+        elif not isinstance(x_filter, dict):
+            raise ValueError("Incorrect type for x_filter")
+        focusE, params_focusE = False, {}
+        if focusE_numeric_edge_values is not None:
+            if not (isinstance(focusE_numeric_edge_values, np.ndarray) and isinstance(X, np.ndarray)):
+                raise ValueError("Either X or focusE_numeric_edge_values are not np.array, so focusE is not supported.")
+            focusE = True
+            X = np.concatenate([X, focusE_numeric_edge_values], axis=1)
+            emp = self.embedding_model_params
+            params_focusE = {"non_linearity": emp.get("non_linearity", "linear"), "stop_epoch": emp.get("stop_epoch", 251),
+                             "structural_wt": emp.get("structural_wt", 0.001)}
+        X = np.asarray(X)
+        self.model.fit(X, batch_size=int(math.ceil(X.shape[0] / self.batches_count)), epochs=self.epochs,
+                       validation_freq=esp.get("check_interval", 10), validation_burn_in=esp.get("burn_in", 25),
+                       validation_batch_size=esp.get("batch_size", 100), validation_data=esp.get("x_valid", None),
+                       validation_filter=x_filter, validation_entities_subset=esp.get("corruption_entities", None),
+                       callbacks=cbs, verbose=verbose, focusE=focusE, focusE_params=params_focusE)
+        self.data_indexer = self.model.data_indexer
+        self.is_fitted = True
+        return self
+
+    def get_indexes(self, X, type_of="t", order="raw2ind"):
+        return self.model.get_indexes(X, type_of, order)
+
+    def get_count(self, concept_type="e"):
+        if concept_type == "entity" or concept_type == "e":
+            return self.model.get_count("e")
+        if concept_type == "relation" or concept_type == "r":
+            return self.model.get_count("r")
+        raise ValueError("Invalid value for concept_type!")
+
+    def get_embeddings(self, entities, embedding_type="entity"):
+        if embedding_type in ("entity", "e"):
+            return self.model.get_embeddings(entities, "e")
+        if embedding_type in ("relation", "r"):
+            return self.model.get_embeddings(entities, "r")
+        raise ValueError("Invalid value for embedding_type!")
+
+    def get_hyperparameter_dict(self):
+        return {"k": self.k, "eta": self.eta, "seed": self.seed, "batches_count": self.batches_count, "epochs": self.epochs,
+                "embedding_model_params": self.embedding_model_params, "optimizer": self.optimizer,
+                "optimizer_params": self.optimizer_params, "loss": self.loss, "loss_params": self.loss_params,
+                "regularizer": self.regularizer, "regularizer_params": self.regularizer_params,
+                "initializer": self.initializer, "initializer_params": self.initializer_params, "verbose": self.verbose}
+
+    def predict(self, X):
+        return self.model.predict(X)
+
+    def calibrate(self, X_pos, X_neg=None, positive_base_rate=None, batches_count=100, epochs=50):
+        X_pos = np.asarray(X_pos)
+        self.model.calibrate(X_pos, X_neg, positive_base_rate, int(math.ceil(X_pos.shape[0] / batches_count)), epochs)
+
+    def predict_proba(self, X):
+        return self.model.predict_proba(X)
+
+    def evaluate(self, x=None, batch_size=32, verbose=True, use_filter=False, corrupt_side="s,o", entities_subset=None,
+                 callbacks=None):
+        return self.model.evaluate(x, batch_size=batch_size, verbose=verbose, use_filter=use_filter, corrupt_side=corrupt_side,
+                                   entities_subset=entities_subset, callbacks=callbacks)
+
+
+class TransE(ScoringModelBase):
+    model_name = "TransE"
+
+
+class DistMult(ScoringModelBase):
+    model_name = "DistMult"
+
+
+class ComplEx(ScoringModelBase):
+    model_name = "ComplEx"
+
+
+class HolE(ScoringModelBase):
+    model_name = "HolE"
+
+
+def evaluate_performance(X, model, filter_triples=None, verbose=False, entities_subset=None, corrupt_side="s,o", batch_size=1):
+    """compat/evaluate.py:17-179: ranks (n, 1|2) of the test triples X; filter_triples = array/list (positives to filter),
+    dict of datasets, or None/False (unfiltered)."""
+    assert corrupt_side in ["s", "o", "s+o", "s,o"], "Invalid value for corrupt_side."
+    if isinstance(filter_triples, (np.ndarray, list)):
+        filter_triples = {"valid": np.asarray(filter_triples)}
+    elif filter_triples is None or (not isinstance(filter_triples, dict) and not filter_triples):
+        filter_triples = False
+    elif not isinstance(filter_triples, dict):
+        raise ValueError("Incorrect type for filter_triples")
+    return model.evaluate(x=X, batch_size=batch_size, verbose=verbose, use_filter=filter_triples, corrupt_side=corrupt_side,
+                          entities_subset=entities_subset, callbacks=None)

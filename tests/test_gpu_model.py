@@ -628,3 +628,35 @@ def test_filter_index_cache(gpu_lib):
     m2.compile(optimizer="adam", loss="nll")
     m2.fit(X[:200], batch_size=100, epochs=1, verbose=False)
     assert m2._filter_cache == (None, None)                   # ... a new model starts empty
+
+
+def test_compat_1x_api(gpu_lib):
+    """ampligraph_amd.compat (the reference's compat/models.py + compat/evaluate.py surface): argument mapping onto the
+    engine -- same result as driving ScoringBasedEmbeddingModel directly with the mapped arguments."""
+    from ampligraph_amd.compat import ComplEx, evaluate_performance
+    from ampligraph_amd.evaluation import hits_at_n_score, mrr_score
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers, regularizers
+
+    X = toy_graph(n=500, N=40, R=3)
+    tr, te = X[:400], X[400:]
+    cm = ComplEx(batches_count=4, epochs=3, k=8, eta=3, seed=5, loss="self_adversarial", loss_params={"margin": 2.0, "alpha": 0.3},
+                 optimizer="adam", optimizer_params={"lr": 1e-2}, regularizer="LP", regularizer_params={"p": 3, "lambda": 1e-4},
+                 initializer="xavier", initializer_params={"uniform": True})
+    cm.fit(tr)
+    assert cm.is_fit() and cm.get_count("entity") == len(set(tr[:, 0]) | set(tr[:, 2]))
+    ranks = evaluate_performance(te, cm, filter_triples=X, corrupt_side="s,o")
+    m = ScoringBasedEmbeddingModel(eta=3, k=8, scoring_type="ComplEx", seed=5)
+    from ampligraph_amd.latent_features import loss_functions
+
+    m.compile(optimizer=optimizers.get("adam", {"learning_rate": 1e-2}),
+              loss=loss_functions.get("self_adversarial", {"margin": 2.0, "alpha": 0.3}),
+              entity_relation_initializer="glorot_uniform",
+              entity_relation_regularizer=regularizers.get("LP", {"p": 3, "lambda": 1e-4}))
+    m.fit(tr, batch_size=100, epochs=3, verbose=False)
+    ref = m.evaluate(te, use_filter={"valid": X}, corrupt_side="s,o", verbose=False)
+    assert np.allclose(cm.predict(te), m.predict(te), rtol=1e-4, atol=1e-6)
+    assert (np.abs(ranks - ref) <= 1).mean() > 0.97 and 0 < mrr_score(ranks) <= 1 and 0 <= hits_at_n_score(ranks, 10) <= 1
+    assert cm.get_embeddings(["e1", "e2"], "entity").shape == (2, 16)
+    assert cm.get_hyperparameter_dict()["batches_count"] == 4
+    with pytest.raises(ValueError):
+        evaluate_performance(te, cm, filter_triples="nope")
