@@ -228,10 +228,11 @@ class KgeEngine:
         return self._work
 
     def rank_side(self, triples, side, strategy="worst", flt=None, ent_ids=None, subset_pos=None,
-                  ent_lo=0, ent_hi=None, out=None, out_stride=1):
+                  ent_lo=0, ent_hi=None, out=None, out_stride=1, flt_range=None):
         """Ranks (1-based, reference semantics) of `triples` for one corruption side.
 
-        flt: None or (lo int64[n], hi int64[n], ids int32[*]) cuda tensors."""
+        flt: None or (lo int64[n], hi int64[n], ids int32[*]) cuda tensors; flt_range: id range the filter ids are
+        checked against when it differs from the candidate positions [ent_lo, ent_hi) (row-sharded subsets)."""
         n = int(triples.shape[0])
         if ent_hi is None:
             ent_hi = self.n_ents if ent_ids is None else int(ent_ids.shape[0])
@@ -244,9 +245,10 @@ class KgeEngine:
         if flt is not None:
             lo, hi, ids = flt
             sub = torch.zeros(n, dtype=torch.int32, device=self.device)
+            f_lo, f_hi = (ent_lo, ent_hi) if flt_range is None else flt_range
             check(self.lib.amdkge_rank_filter(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples),
                                               n, side, _ptr(lo), _ptr(hi), _ptr(ids), _ptr(subset_pos),
-                                              int(ent_lo), int(ent_hi), _ptr(sub), _ptr(work), _stream()))
+                                              int(f_lo), int(f_hi), _ptr(sub), _ptr(work), _stream()))
         if out is None:
             out = torch.empty(n, dtype=torch.int32, device=self.device)
             out_stride = 1

@@ -59,3 +59,62 @@ def initialise(identifier, shape, rng):
     else:
         raise ValueError(f"Could not interpret initializer identifier: {identifier!r}")
     return np.ascontiguousarray(out, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Row-range access to the initial tables (row-sharded entity tables): a rank draws only ITS rows
+# and gets exactly the values of the whole-table draw above.  Works for the uniform family because
+# Generator.uniform consumes one PCG64 output per element, so rows [lo, hi) of a table that starts `skip` outputs
+# into the stream are reached with bit_generator.advance(skip + lo * cols) -- O(log) time, no memory.
+_UNIFORM_LIMITS = {"glorot_uniform": lambda fi, fo: math.sqrt(6.0 / (fi + fo)), "he_uniform": lambda fi, fo: math.sqrt(6.0 / fi),
+                   "random_uniform": lambda fi, fo: 0.05}
+_CONSTANTS = {"zeros": 0.0, "ones": 1.0}
+
+
+def stream_cost(identifier, shape):
+    """PCG64 outputs a whole-table draw of `identifier` consumes, or None when that is not a fixed number
+    (normal family: rejection sampling; callables: unknown)."""
+    if isinstance(identifier, np.ndarray):
+        return 0
+    if isinstance(identifier, str):
+        name = identifier.lower()
+        if name in _UNIFORM_LIMITS:
+            return int(shape[0]) * int(shape[1])
+        if name in _CONSTANTS:
+            return 0
+    return None
+
+
+class RowSource:
+    """rows(lo, hi) -> fp32 (hi-lo, cols) block of the table `identifier` would initialise to, given that the table
+    starts `skip` outputs into PCG64(seed)'s stream.  `streams` is False when the only way is to draw the whole
+    table once on the host (then kept; fine for tables that fit host RAM)."""
+
+    def __init__(self, identifier, shape, seed, skip=0):
+        self.identifier, self.shape, self.seed, self.skip = identifier, (int(shape[0]), int(shape[1])), seed, skip
+        self._whole = None
+        name = identifier.lower() if isinstance(identifier, str) else None
+        self._lim = _UNIFORM_LIMITS[name](*self.shape) if name in _UNIFORM_LIMITS else None
+        self._const = _CONSTANTS.get(name)
+        self.streams = skip is not None and (self._lim is not None or self._const is not None or isinstance(identifier, np.ndarray))
+        if isinstance(identifier, np.ndarray) and tuple(identifier.shape) != self.shape:
+            raise ValueError(f"initial value has shape {identifier.shape}, expected {self.shape}")
+
+    def rows(self, lo, hi):
+        lo, hi = int(lo), int(hi)
+        cols = self.shape[1]
+        if self._lim is not None and self.skip is not None:
+            bg = np.random.PCG64(self.seed)
+            bg.advance(self.skip + lo * cols)
+            return np.random.Generator(bg).uniform(-self._lim, self._lim, size=(hi - lo, cols)).astype(np.float32)
+        if self._const is not None:
+            return np.full((hi - lo, cols), self._const, dtype=np.float32)
+        if isinstance(self.identifier, np.ndarray):
+            return np.ascontiguousarray(self.identifier[lo:hi], dtype=np.float32)
+        if self._whole is None:
+            if self.skip is None:
+                raise ValueError("this initialiser follows one whose stream length is unknown: draw the tables in order")
+            bg = np.random.PCG64(self.seed)
+            bg.advance(self.skip)
+            self._whole = initialise(self.identifier, self.shape, np.random.Generator(bg))
+        return self._whole[lo:hi]

@@ -20,7 +20,7 @@ from ..datasets.indexer import DataIndexer
 from ..evaluation.metrics import hits_at_n_score, mr_score, mrr_score
 from ..trainer import StepLoop
 from . import loss_functions, optimizers, regularizers
-from .initializers import initialise
+from .initializers import RowSource, initialise, stream_cost
 
 SCORING_LAYER_REGISTRY = dict(_ffi.SCORING_TYPES)  # AbstractScoringLayer.py:15 (Random is out of scope)
 
@@ -129,35 +129,58 @@ class ScoringBasedEmbeddingModel:
     EVAL_CHUNK_SHARDED = 4096   # test triples per sharded evaluation / prediction pass (2 scratch rows each)
 
     def _build(self, n_ents, n_rels, batch_size=None, tables=None):
+        import torch
+
         from ..engine import KgeEngine  # raises loudly without the HIP library / a GPU
 
         self.max_ent_size, self.max_rel_size = int(n_ents), int(n_rels)
         self._n_ents, self._n_rels = int(n_ents), int(n_rels)
         self._filter_cache = (None, None)   # a new id map invalidates cached filter indexes
+        self._loop = None                   # the step loop is bound to the engine built below
+        K = self.internal_k
         if tables is None:
-            rng = np.random.Generator(np.random.PCG64(self.seed))
-            ent = initialise(self._initializers[0], (n_ents, self.internal_k), rng)
-            rel = initialise(self._initializers[1], (n_rels, self.internal_k), rng)
+            cost = stream_cost(self._initializers[0], (n_ents, K))
+            if cost is not None:   # a rank can draw just ITS rows of the whole-table stream (initializers.RowSource)
+                ent_rows = RowSource(self._initializers[0], (n_ents, K), self.seed, 0).rows
+                rel = RowSource(self._initializers[1], (n_rels, K), self.seed, cost).rows(0, n_rels)
+            else:
+                rng = np.random.Generator(np.random.PCG64(self.seed))
+                ent = initialise(self._initializers[0], (n_ents, K), rng)
+                rel = initialise(self._initializers[1], (n_rels, K), rng)
+                ent_rows = lambda lo, hi: ent[lo:hi]   # noqa: E731
         else:
             ent, rel = tables
+            ent_rows = ent if callable(ent) else (lambda lo, hi: ent[lo:hi])
         d = self._dist()
         self._spec = None
+        lo, hi = 0, int(n_ents)
         if self._sharding == "rows" and d is not None:
             from ..sharded import ShardedStepLoop, ShardSpec
 
-            # same initial values as one GPU (whole table drawn from the same stream, then sliced): fine up to
-            # host-RAM-sized tables; C5-scale tables need a counter-based per-row initialiser (not built)
+            # same initial values as one GPU: rows [lo, hi) of the whole-table draw
             sp = self._spec = ShardSpec(n_ents, d.get_world_size(), d.get_rank())
             per_rank = -(-int(batch_size or 1000) // sp.world)
             cap = max(ShardedStepLoop.rows_needed(per_rank, self.eta, self._sharded_negatives), 2 * self.EVAL_CHUNK_SHARDED)
             self._engine = KgeEngine(self.scoring_type, self.k, sp.n_local + cap, n_rels, max_rel_size=n_rels)
-            shard = np.zeros((sp.n_local + cap, self.internal_k), dtype=np.float32)
-            shard[:sp.n_local] = ent[sp.lo:sp.hi]
-            self._engine.set_tables(shard, rel)
+            lo, hi = sp.lo, sp.hi
         else:
             self._engine = KgeEngine(self.scoring_type, self.k, n_ents, n_rels, max_rel_size=n_rels)
-            self._engine.set_tables(ent, rel)
+        self._upload_rows(self._engine.ent, ent_rows, lo, hi)
+        self._engine.rel.copy_(torch.as_tensor(np.ascontiguousarray(rel, dtype=np.float32)))
         self._full_ent = None
+
+    @staticmethod
+    def _upload_rows(dst, rows, lo, hi, chunk_elems=1 << 24):
+        """dst[0 : hi-lo] <- rows(lo, hi), in host chunks of <= chunk_elems floats (C5 shards do not fit host RAM twice)."""
+        import torch
+
+        step = max(1, chunk_elems // int(dst.shape[1]))
+        for r0 in range(int(lo), int(hi), step):
+            r1 = min(int(hi), r0 + step)
+            blk = np.ascontiguousarray(rows(r0, r1), dtype=np.float32)
+            if blk.shape != (r1 - r0, int(dst.shape[1])):
+                raise ValueError(f"table rows have shape {blk.shape}, expected {(r1 - r0, int(dst.shape[1]))}")
+            dst[r0 - lo:r1 - lo].copy_(torch.as_tensor(blk))
 
     def _dist(self):
         if self._dist_override is not None:
@@ -246,8 +269,6 @@ class ScoringBasedEmbeddingModel:
             structural_wt = focusE_params.get("structural_wt", 0.001)
             assert 0 <= structural_wt <= 1, "Invalid focusE 'structural_wt' passed! It has to belong to [0,1]."
             self.focusE_params = {"non_linearity": nl, "stop_epoch": stop_epoch, "structural_wt": structural_wt}
-            if self._sharding == "rows" and self._dist() is not None:
-                raise NotImplementedError("FocusE with a row-sharded entity table")
             focus_w = np.ascontiguousarray(X[:, 3:].astype(np.float32).mean(axis=1), dtype=np.float32)   # :360
         elif X.shape[1] > 3:
             print("Data shape is {}: not only triples were given, but focusE is not active!".format(X.shape[1]))
@@ -365,13 +386,18 @@ class ScoringBasedEmbeddingModel:
         Xi = self._index_test(x)
         if Xi.shape[0] == 0:
             return np.zeros(0, dtype=np.float32)
-        Xd = torch.as_tensor(Xi).to(self._engine.device)
+        return self._score_dev(torch.as_tensor(Xi).to(self._engine.device)).cpu().numpy()
+
+    def _score_dev(self, Xd):
+        """Scores of the int32 device triples Xd (global ids) as a device tensor."""
+        import torch
+
         if self._spec is None:
-            return self._engine.score(Xd).cpu().numpy()
+            return self._engine.score(Xd)
         outs = []   # row-sharded: every rank fetches the rows it lacks and scores all triples (replicated result)
-        for c0 in range(0, Xi.shape[0], self.EVAL_CHUNK_SHARDED):
+        for c0 in range(0, int(Xd.shape[0]), self.EVAL_CHUNK_SHARDED):
             outs.append(self._engine.score(self._localise(Xd[c0:c0 + self.EVAL_CHUNK_SHARDED])))
-        return torch.cat(outs).cpu().numpy()
+        return torch.cat(outs) if outs else torch.zeros(0, dtype=torch.float32, device=Xd.device)
 
     # ------------------------------------------------------------------------------------ evaluate
     def evaluate(self, x=None, batch_size=32, verbose=True, use_filter=False, corrupt_side="s,o",
@@ -460,9 +486,11 @@ class ScoringBasedEmbeddingModel:
 
         from ..sharded import sharded_rank_counts
 
-        if entities_subset is not None and len(entities_subset) > 0:
-            raise NotImplementedError("entities_subset with a row-sharded entity table")
         eng, d = self._engine, self._dist()
+        subset = None
+        if entities_subset is not None and len(entities_subset) > 0:
+            sub = np.asarray(self.data_indexer.get_indexes(np.asarray(entities_subset), "e"), dtype=np.int64)
+            subset = self._spec.local_subset(torch.as_tensor(sub).to(eng.device))
         fi = self._filter_index(use_filter, Xi)
         dev = eng.device
         n = Xi.shape[0]
@@ -480,7 +508,7 @@ class ScoringBasedEmbeddingModel:
                     lo, hi = (fi.subject_ranges if sd == "s" else fi.object_ranges)(Xi[c0:c0 + CH])
                     flt = (torch.as_tensor(lo).to(dev), torch.as_tensor(hi).to(dev), flt_ids[sd])
                 counts, sub = sharded_rank_counts(eng, self._spec, d, Xd[c0:c0 + CH],
-                                                  _ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, flt)
+                                                  _ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, flt, subset)
                 eng.compose_ranks(counts, sub, ranking_strategy, out=ranks[c0:c0 + CH, col], out_stride=len(sides))
         r = ranks.cpu().numpy()
         if corrupt_side == "s+o":
@@ -530,8 +558,6 @@ class ScoringBasedEmbeddingModel:
         import torch
 
         assert self.is_fitted, "Model is not fit on the data yet!"
-        if self._spec is not None:
-            raise NotImplementedError("calibrate() with a row-sharded entity table")
         self.is_calibrated = False
         eng = self._engine
         Xp = self._index_test(X_pos)
@@ -558,8 +584,9 @@ class ScoringBasedEmbeddingModel:
         weight_neg = (1.0 - positive_base_rate) / positive_base_rate
         dev = eng.device
         Xpd = torch.as_tensor(Xp).to(dev)
-        sp_all = eng.score(Xpd) if pos_size else None          # the embeddings are frozen: score once
-        sn_all = eng.score(torch.as_tensor(Xn).to(dev)) if Xn is not None and neg_size else None
+        # row-sharded tables: the same code, scores come from _score_dev (replicated result on every rank)
+        sp_all = self._score_dev(Xpd) if pos_size else None    # the embeddings are frozen: score once
+        sn_all = self._score_dev(torch.as_tensor(Xn).to(dev)) if Xn is not None and neg_size else None
         slots = [(0.0, 0.0), (0.0, 0.0)]
         t = 0
         for epoch in range(int(epochs)):
@@ -568,8 +595,9 @@ class ScoringBasedEmbeddingModel:
                 if sn_all is not None:
                     sn = sn_all[bi * bs_neg:(bi + 1) * bs_neg]
                 else:
-                    neg = eng.sample_corruptions(Xpd[bi * batch_size:(bi + 1) * batch_size], 1, self.seed, t)
-                    sn = eng.score(neg)
+                    neg = eng.sample_corruptions(Xpd[bi * batch_size:(bi + 1) * batch_size], 1, self.seed, t,
+                                                 sample_range=self._n_ents)
+                    sn = self._score_dev(neg)
                 if sp.shape[0] == 0:
                     continue
                 t += 1
@@ -599,20 +627,41 @@ class ScoringBasedEmbeddingModel:
         return (1.0 / (1.0 + np.exp((w * s + b).astype(np.float64)))).astype(np.float32)
 
     # ------------------------------------------------------------------------------------ persistence
+    @staticmethod
+    def _shard_file(filepath, rank, world):
+        return "{}.shard{:03d}-of-{:03d}.npz".format(filepath, rank, world)
+
     def save_weights(self, filepath):
         """Own flat format (the reference writes a TF checkpoint, :1046-1071): <filepath>.npz holds tables,
-        optimizer slots and id maps; <filepath>.json the hyper-parameters."""
+        optimizer slots and id maps; <filepath>.json the hyper-parameters.
+
+        Row-sharded mode (collective: call on every rank): rank r writes ITS rows of the entity table and of the
+        optimizer slots to <filepath>.shardRRR-of-WWW.npz; rank 0 writes the replicated part (relation table + slots,
+        id maps, `shard_world`) to <filepath>.npz and the .json.  Nothing is gathered, so it works at C5 scale;
+        load_weights() re-slices, so a checkpoint can be resumed on a different number of GPUs (or on one)."""
         assert self.is_fitted, "Model is not fit on the data yet!"
+        eng = self._engine
+        arrays = {}
         if self._spec is not None:
-            # row-sharded: the gathered tables (every rank can write them; optimizer slots stay per rank and are
-            # not part of this file -- sharded checkpoints are a "next" row, SURVEY.md 8f.2)
-            arrays = {"ent": self._entity_table().cpu().numpy(), "rel": self._engine.rel.cpu().numpy()}
+            sp = self._spec
+            mine = {"ent": eng.ent[:sp.n_local].cpu().numpy(), "lo": np.int64(sp.lo), "hi": np.int64(sp.hi)}
+            for kname, t in getattr(eng, "slots", {}).items():
+                if kname.endswith("_e"):
+                    mine["slot_" + kname] = t[:sp.n_local].cpu().numpy()
+            np.savez(self._shard_file(filepath, sp.rank, sp.world), **mine)
+            arrays = {"rel": eng.rel.cpu().numpy(), "shard_world": np.int64(sp.world), "n_ents": np.int64(sp.n_ents)}
+            for kname, t in getattr(eng, "slots", {}).items():
+                if kname.endswith("_r"):
+                    arrays["slot_" + kname] = t.cpu().numpy()
+            self._dist().barrier()
+            if sp.rank != 0:
+                return
         else:
             if self._loop is not None and hasattr(self._loop, "sync_optimizer_slots"):
                 self._loop.sync_optimizer_slots()   # data-parallel sharded merge: collective, call on every rank
-            ent, rel = self._engine.get_tables()
+            ent, rel = eng.get_tables()
             arrays = {"ent": ent, "rel": rel}
-            for kname, t in self._engine.slots.items():
+            for kname, t in getattr(eng, "slots", {}).items():
                 arrays["slot_" + kname] = t.cpu().numpy()
         st = self.data_indexer.state()
         arrays["ent_raw"], arrays["rel_raw"] = st["ent_raw"], st["rel_raw"]
@@ -626,18 +675,53 @@ class ScoringBasedEmbeddingModel:
             json.dump(meta, f)
 
     def load_weights(self, filepath):
+        """Whole-table or row-sharded checkpoint -> this model, whatever its own sharding (rows are re-sliced)."""
+        import torch
+
+        from ..sharded import ShardSpec
+
         z = np.load(filepath + ".npz", allow_pickle=False)
         self.data_indexer = DataIndexer.from_state({"ent_raw": z["ent_raw"], "rel_raw": z["rel_raw"]})
         if not self.is_compiled:
             self._initializers = ["zeros", "zeros"]
-        self._build(z["ent"].shape[0], z["rel"].shape[0], tables=(z["ent"], z["rel"]))
-        slots = {k[5:]: z[k] for k in z.files if k.startswith("slot_")}
-        if slots and self.is_compiled and self._spec is None:
-            import torch
+        saved_world = int(z["shard_world"]) if "shard_world" in z.files else 0
+        n_ents = int(z["n_ents"]) if saved_world else int(z["ent"].shape[0])
 
+        def rows_of(key):
+            if not saved_world:
+                arr = z[key]
+                return lambda lo, hi: arr[lo:hi]
+            shards = {}
+
+            def rows(lo, hi):
+                out = []
+                for r in range(saved_world):
+                    s = ShardSpec(n_ents, saved_world, r)
+                    if s.hi <= lo or s.lo >= hi or s.n_local == 0:
+                        continue
+                    if r not in shards:
+                        shards.clear()   # one shard file in memory at a time
+                        shards[r] = np.load(self._shard_file(filepath, r, saved_world), allow_pickle=False)[key]
+                    out.append(shards[r][max(lo, s.lo) - s.lo:min(hi, s.hi) - s.lo])
+                return np.concatenate(out) if out else np.zeros((0, self.internal_k), np.float32)
+            return rows
+
+        self._build(n_ents, z["rel"].shape[0], tables=(rows_of("ent"), z["rel"]))
+        slot_keys = [k[5:] for k in z.files if k.startswith("slot_")]
+        if saved_world:
+            s0 = np.load(self._shard_file(filepath, 0, saved_world), allow_pickle=False)
+            slot_keys += [k[5:] for k in s0.files if k.startswith("slot_")]
+        if slot_keys and self.is_compiled:
             self._loop = self._make_loop()
-            for kname, v in slots.items():
-                self._engine.slots[kname].copy_(torch.as_tensor(v))
+            eng = self._engine
+            lo, hi = (self._spec.lo, self._spec.hi) if self._spec is not None else (0, n_ents)
+            for kname in slot_keys:
+                if kname not in eng.slots:
+                    continue   # checkpoint of another optimizer
+                if kname.endswith("_e"):
+                    self._upload_rows(eng.slots[kname], rows_of("slot_" + kname), lo, hi)
+                else:
+                    eng.slots[kname].copy_(torch.as_tensor(z["slot_" + kname]))
             if os.path.exists(filepath + ".json"):
                 self.optimizer.iterations = int(json.load(open(filepath + ".json")).get("iterations", 0))
         if os.path.exists(filepath + ".json"):

@@ -30,6 +30,7 @@ every score, loss, gradient and update is a libamdkge kernel.
 """
 import torch
 
+from . import _ffi
 from .trainer import prefer_tiled, shard_bounds
 
 
@@ -43,6 +44,15 @@ class ShardSpec:
 
     def owner(self, ids):
         return torch.div(ids, self.rows_per, rounding_mode="floor")
+
+    def local_subset(self, ids):
+        """entities_subset (GLOBAL ids, device tensor, duplicates kept: each is a candidate) -> (the local rows among
+        them as int32 candidate list, membership mask over the local rows) for sharded_rank_counts."""
+        ids = ids.to(torch.int64)
+        mine = ids[(ids >= self.lo) & (ids < self.hi)] - self.lo
+        mask = torch.zeros(max(1, self.n_local), dtype=torch.bool, device=ids.device)
+        mask[mine] = True
+        return mine.to(torch.int32).contiguous(), mask
 
 
 class RowExchange:
@@ -123,10 +133,19 @@ class ShardedStepLoop:
         """Upper bound of the scratch rows one step needs behind the shard (distinct remote ids)."""
         return int(batch_per_rank) * (2 + (int(eta) if negatives == "global" else 0))
 
-    def step(self, global_batch, rng_step):
+    def step(self, global_batch, rng_step, focus=None):
+        """focus: None or (w fp32 device tensor [Bg], beta, non-linearity name) -- FocusE, as trainer.StepLoop.step."""
         eng, sp = self.engine, self.spec
         bg = int(global_batch.shape[0])
         lo, hi = shard_bounds(bg, self.world, self.rank)
+        if focus is not None:
+            fw = focus[0][lo:hi].contiguous()   # kept alive until the launches below are enqueued
+            self.loss_ffi.focus_nonlinearity = _ffi.FOCUS_NONLINEARITY[focus[2]]
+            self.loss_ffi.focus_beta = float(focus[1])
+            self.loss_ffi.d_focus_w = fw.data_ptr()
+        else:
+            self.loss_ffi.focus_nonlinearity = 0
+            self.loss_ffi.d_focus_w = None
         xb = global_batch[lo:hi].to(torch.int64)
         b = int(xb.shape[0])
         negs = None
@@ -201,12 +220,14 @@ class ShardedStepLoop:
         return torch.cat(parts)[:sp.n_ents]
 
 
-def sharded_rank_counts(engine, spec, dist, triples, side, flt=None):
+def sharded_rank_counts(engine, spec, dist, triples, side, flt=None, subset=None):
     """evaluate() on a row-sharded table: every rank scores ALL queries against ITS rows and the partial
     (greater, equal) counts and filter subtractions are summed over ranks -- the reference's own loop over entity
     partitions (ScoringBasedEmbeddingModel.py:1431-1452) with the partitions living on different GPUs.
 
-    triples: (n,3) int64/int32 GLOBAL ids (same on every rank); flt: None or (lo, hi, ids) with GLOBAL ids.
+    triples: (n,3) int64/int32 GLOBAL ids (same on every rank); flt: None or (lo, hi, ids) with GLOBAL ids;
+    subset: None or ShardSpec.local_subset(entities_subset) -- candidates are then the subset's local rows, and filter
+    ids outside the subset are dropped (the mapping-table lookup of AbstractScoringLayer.py:266-275).
     Returns (counts (n,2) int32, sub (n,) int32 or None), identical on every rank."""
     sp = spec
     x = triples.to(torch.int64)
@@ -226,8 +247,17 @@ def sharded_rank_counts(engine, spec, dist, triples, side, flt=None):
         lo, hi, fid = flt
         # ids outside [0, n_local) after the shift fail the kernel's range check: exactly the partition rule
         # of AbstractScoringLayer.py:280-288
-        lflt = (lo, hi, (fid.to(torch.int64) - sp.lo).clamp(min=-1, max=2**31 - 1).to(torch.int32))
-    _, counts, sub = engine.rank_side(xl, side, "worst", lflt, ent_lo=0, ent_hi=sp.n_local)
+        lid = fid.to(torch.int64) - sp.lo
+        if subset is not None:
+            ok = (lid >= 0) & (lid < sp.n_local)
+            ok &= subset[1][lid.clamp(0, max(0, sp.n_local - 1))]
+            lid = torch.where(ok, lid, torch.full_like(lid, -1))
+        lflt = (lo, hi, lid.clamp(min=-1, max=2**31 - 1).to(torch.int32))
+    if subset is None:
+        _, counts, sub = engine.rank_side(xl, side, "worst", lflt, ent_lo=0, ent_hi=sp.n_local)
+    else:
+        _, counts, sub = engine.rank_side(xl, side, "worst", lflt, ent_ids=subset[0], ent_lo=0,
+                                          ent_hi=int(subset[0].shape[0]), flt_range=(0, sp.n_local))
     dist.all_reduce(counts)
     if sub is not None:
         dist.all_reduce(sub)

@@ -44,13 +44,14 @@ class OracleEngine:
         return torch.as_tensor(negs.astype(np.int32))
 
     def rank_side(self, triples, side, strategy="worst", flt=None, ent_ids=None, subset_pos=None, ent_lo=0,
-                  ent_hi=None, out=None, out_stride=1):
+                  ent_hi=None, out=None, out_stride=1, flt_range=None):
         """(None, counts (n,2) [greater, equal], sub (n,) or None) like KgeEngine.rank_side, on rows [ent_lo, ent_hi)."""
         X = triples.numpy().astype(np.int64)
         ent, rel = self.ent.numpy(), self.rel.numpy()
         s, p, o = O.lookup(ent, rel, X)
         tq = O.quantise(O.compute_scores(self.model, s, p, o, max_rel_size=self.n_rels))
-        cq = O.quantise(O.corruption_scores(self.model, "s" if side == 1 else "o", s, p, o, ent[ent_lo:ent_hi], self.n_rels))
+        cand = ent[ent_lo:ent_hi] if ent_ids is None else ent[ent_ids.numpy().astype(np.int64)[ent_lo:ent_hi]]
+        cq = O.quantise(O.corruption_scores(self.model, "s" if side == 1 else "o", s, p, o, cand, self.n_rels))
         counts = np.stack([(tq[:, None] < cq).sum(1), (tq[:, None] == cq).sum(1)], 1).astype(np.int32)
         sub = None
         if flt is not None:
@@ -58,8 +59,14 @@ class OracleEngine:
             sub = np.zeros(len(X), dtype=np.int32)
             for i in range(len(X)):
                 f = ids[lo[i]:hi[i]].astype(np.int64)
-                f = f[(f >= ent_lo) & (f < ent_hi)] - ent_lo
-                sub[i] = int((tq[i] <= cq[i, f]).sum())
+                if flt_range is None:
+                    f = f[(f >= ent_lo) & (f < ent_hi)] - ent_lo
+                    sub[i] = int((tq[i] <= cq[i, f]).sum())
+                else:   # filter ids are table rows in flt_range, scored directly (candidates are a subset list)
+                    f = f[(f >= flt_range[0]) & (f < flt_range[1])]
+                    fq = O.quantise(O.corruption_scores(self.model, "s" if side == 1 else "o", s[i:i + 1], p[i:i + 1],
+                                                        o[i:i + 1], ent[f], self.n_rels))[0] if len(f) else np.zeros(0)
+                    sub[i] = int((tq[i] <= fq).sum())
             sub = torch.as_tensor(sub)
         return None, torch.as_tensor(counts), sub
 

@@ -1,6 +1,8 @@
 """End-to-end parity of the drop-in surface (ScoringBasedEmbeddingModel.fit/predict/evaluate) on the GPU
 against the oracle replaying the same schedule: same id map, same initial tables, same batches
 (sequential slices), same Philox negatives, dense Keras-legacy optimizer."""
+import os
+
 import numpy as np
 import pytest
 
@@ -660,3 +662,82 @@ def test_compat_1x_api(gpu_lib):
     assert cm.get_hyperparameter_dict()["batches_count"] == 4
     with pytest.raises(ValueError):
         evaluate_performance(te, cm, filter_triples="nope")
+
+
+def test_row_sharded_focuse_calibrate_subset_checkpoint(gpu_lib, tmp_path):
+    """Row-sharded drop-in class, the rest of the surface: FocusE fit, calibrate/predict_proba, evaluate with
+    entities_subset, and the sharded checkpoint (per-rank shard files, no gather): written by 2 ranks, resumed by ONE
+    model (re-sliced) and by 2 ranks again -- the continued runs equal the uninterrupted ones."""
+    from threaded_dist import ThreadedWorld
+
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers
+
+    X = toy_graph(n=600, N=50, R=3)
+    rng = np.random.default_rng(3)
+    Xw = np.concatenate([X, rng.uniform(0, 1, size=(len(X), 1)).astype(str)], 1)
+    Xtest = X[:60]
+    subset = np.array([f"e{i}" for i in (3, 44, 17, 9, 3, 30, 31, 48)])
+    k, eta, bs = 8, 3, 128
+    fe = {"non_linearity": "sigmoid", "stop_epoch": 4, "structural_wt": 0.3}
+    ck = str(tmp_path / "ck")
+
+    def new(dist=None, **kw):
+        m = ScoringBasedEmbeddingModel(eta=eta, k=k, scoring_type="DistMult", seed=4)
+        m._dist_override = dist
+        m.compile(optimizer=optimizers.get("adam", {"learning_rate": 1e-2}), loss="nll", entity_relation_regularizer="l2", **kw)
+        return m
+
+    def body(dist):
+        m = new(dist, entity_sharding="rows", sharded_negatives="global")
+        h = m.fit(Xw, batch_size=bs, epochs=2, verbose=False, focusE=True, focusE_params=dict(fe))
+        m.save_weights(ck)
+        h2 = m.fit(Xw, batch_size=bs, epochs=4, initial_epoch=2, verbose=False, focusE=True, focusE_params=dict(fe))
+        m.calibrate(X[:200], positive_base_rate=0.4, batch_size=64, epochs=3)
+        r_sub = m.evaluate(Xtest, use_filter={"train": X}, corrupt_side="s,o", entities_subset=subset, verbose=False)
+        ents = np.array([f"e{i}" for i in range(50)])
+        out = (h.history["loss"] + h2.history["loss"], m.get_embeddings(ents), m.predict_proba(Xtest), r_sub)
+        # resume from the shard files on 2 ranks
+        m2 = new(dist, entity_sharding="rows", sharded_negatives="global")
+        m2.load_weights(ck)
+        h3 = m2.fit(Xw, batch_size=bs, epochs=4, initial_epoch=2, verbose=False, focusE=True, focusE_params=dict(fe))
+        return out + (h3.history["loss"], m2.get_embeddings(ents))
+
+    res = ThreadedWorld(2).run(body)
+    assert os.path.exists(ck + ".shard000-of-002.npz") and os.path.exists(ck + ".shard001-of-002.npz")
+    assert "ent" not in np.load(ck + ".npz").files
+    ents = np.array([f"e{i}" for i in range(50)])
+    m1 = new()
+    h1 = m1.fit(Xw, batch_size=bs, epochs=4, verbose=False, focusE=True, focusE_params=dict(fe))
+    m1.calibrate(X[:200], positive_base_rate=0.4, batch_size=64, epochs=3)
+    e1, pp1 = m1.get_embeddings(ents), m1.predict_proba(Xtest)
+    r1 = m1.evaluate(Xtest, use_filter={"train": X}, corrupt_side="s,o", entities_subset=subset, verbose=False)
+    for hist, emb, pp, r_sub, hist3, emb3 in res:
+        assert np.allclose(hist, h1.history["loss"], rtol=2e-4)
+        assert (np.abs(emb - e1) <= 1e-5 + 1e-3 * np.abs(e1)).mean() > 0.995
+        assert np.allclose(pp, pp1, rtol=1e-3, atol=1e-4)
+        assert (np.abs(r_sub - r1) <= 1).mean() > 0.97 and r_sub.max() <= len(subset) + 1
+        # the run resumed from the sharded checkpoint == the uninterrupted sharded run (same schedule, same slots)
+        assert np.allclose(hist3, hist[2:], rtol=1e-6) and np.allclose(emb3, emb, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(res[0][3], res[1][3])
+    # the 2-rank shard files resumed by ONE model (rows re-sliced, slots included)
+    m3 = new()
+    m3.load_weights(ck)
+    h3 = m3.fit(Xw, batch_size=bs, epochs=4, initial_epoch=2, verbose=False, focusE=True, focusE_params=dict(fe))
+    assert np.allclose(h3.history["loss"], h1.history["loss"][2:], rtol=2e-4)
+    assert (np.abs(m3.get_embeddings(ents) - e1) <= 1e-5 + 1e-3 * np.abs(e1)).mean() > 0.995
+    # and a whole-table checkpoint resumed by 2 row-sharded ranks
+    m4 = new()
+    m4.fit(Xw, batch_size=bs, epochs=2, verbose=False, focusE=True, focusE_params=dict(fe))
+    ck1 = str(tmp_path / "ck1")
+    m4.save_weights(ck1)
+
+    def body2(dist):
+        m = new(dist, entity_sharding="rows", sharded_negatives="global")
+        m.load_weights(ck1)
+        h = m.fit(Xw, batch_size=bs, epochs=4, initial_epoch=2, verbose=False, focusE=True, focusE_params=dict(fe))
+        return h.history["loss"], m.get_embeddings(ents)
+
+    for hist, emb in ThreadedWorld(2).run(body2):
+        assert np.allclose(hist, h1.history["loss"][2:], rtol=2e-4)
+        assert (np.abs(emb - e1) <= 1e-5 + 1e-3 * np.abs(e1)).mean() > 0.995
+

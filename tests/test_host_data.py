@@ -1,6 +1,7 @@
 """Host data semantics (filter sets, id assignment, batching) against the oracle's restatement of the
 reference (graph_data_loader.py:287-350,382-439; data_indexer.py:373-399,485-549)."""
 import numpy as np
+import pytest
 
 from ampligraph_amd.datasets.filters import FilterIndex
 from oracle import kge_oracle as O
@@ -72,3 +73,28 @@ def test_evaluation_protocol_helpers():
     Y = np.array([["1", "0", "2"], ["zz", "0", "2"], ["1", "0", "qq"]])
     assert filter_unseen_entities(Y, m).tolist() == [["1", "0", "2"]]
     assert filter_unseen_entities(Y[:1], m) is not None and len(filter_unseen_entities(Y[:1], m)) == 1
+
+
+def test_row_source_equals_whole_table_draw():
+    """initializers.RowSource: any row range of the entity table, and the relation table behind it in the stream, equal
+    the whole-table draw (what lets a row-sharded rank initialise only its rows)."""
+    from ampligraph_amd.latent_features.initializers import RowSource, initialise, stream_cost
+
+    for e_init, r_init in (("glorot_uniform", "glorot_uniform"), ("he_uniform", "random_uniform"), ("zeros", "glorot_uniform"),
+                           ("glorot_normal", "glorot_uniform")):
+        rng = np.random.Generator(np.random.PCG64(11))
+        ent = initialise(e_init, (333, 20), rng)
+        rel = initialise(r_init, (5, 20), rng)
+        cost = stream_cost(e_init, (333, 20))
+        if e_init == "glorot_normal":
+            assert cost is None      # rejection sampling: no fixed stream length, whole-table path is used
+            continue
+        se = RowSource(e_init, (333, 20), 11, 0)
+        assert se.streams
+        for lo, hi in ((0, 333), (0, 1), (100, 250), (332, 333), (7, 7)):
+            assert np.array_equal(se.rows(lo, hi), ent[lo:hi])
+        assert np.array_equal(RowSource(r_init, (5, 20), 11, cost).rows(0, 5), rel)
+    arr = np.arange(60, dtype=np.float32).reshape(6, 10)
+    assert np.array_equal(RowSource(arr, (6, 10), 0, 0).rows(2, 5), arr[2:5])
+    with pytest.raises(ValueError):
+        RowSource(arr, (7, 10), 0, 0)

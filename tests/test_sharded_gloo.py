@@ -19,6 +19,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODEL, K_UNITS, ETA, SEED, BS = "ComplEx", 6, 3, 5, 37
+SUBSET = np.array([3, 40, 17, 22, 3, 0, 35, 20, 21], dtype=np.int64)
 
 
 def _free_port():
@@ -81,8 +82,12 @@ def _run_sharded(rank, world, port, out, negatives, tiled):
     flt = (torch.as_tensor(lo), torch.as_tensor(hi), torch.as_tensor(np.concatenate(fl)))
     cs, ss = sharded_rank_counts(eng, sp, dist, torch.as_tensor(T), 1, flt)
     co, _ = sharded_rank_counts(eng, sp, dist, torch.as_tensor(T), 2, None)
+    # entities_subset (with a duplicate and ids of both shards): candidates and filter restricted to the subset
+    subset = sp.local_subset(torch.as_tensor(SUBSET))
+    cu, su = sharded_rank_counts(eng, sp, dist, torch.as_tensor(T), 1, flt, subset)
     if rank == 0:
-        np.savez(out, ent=full, rel=eng.state.rel, loss=lossv, cs=cs.numpy(), ss=ss.numpy(), co=co.numpy())
+        np.savez(out, ent=full, rel=eng.state.rel, loss=lossv, cs=cs.numpy(), ss=ss.numpy(), co=co.numpy(),
+                 cu=cu.numpy(), su=su.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -168,6 +173,12 @@ def test_row_sharded_two_ranks(tmp_path, negatives, tiled):
     tq_g = O.quantise(O.compute_scores(MODEL, *O.lookup(got["ent"], got["rel"], T), max_rel_size=3))
     sub = np.array([int((tq_g[i] <= cq[i, fl[i]]).sum()) for i in range(len(T))])
     assert (got["ss"] == sub).all()
+    # entities_subset: counts over the subset rows (duplicates count twice), filter ids outside the subset dropped
+    cqs = cq[:, SUBSET]
+    assert (got["cu"] == np.stack([(tq_g[:, None] < cqs).sum(1), (tq_g[:, None] == cqs).sum(1)], 1)).all()
+    members = set(SUBSET.tolist())
+    subu = np.array([int(sum(tq_g[i] <= cq[i, f] for f in fl[i] if int(f) in members)) for i in range(len(T))])
+    assert (got["su"] == subu).all()
     del tq
 
 
