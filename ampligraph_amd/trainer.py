@@ -80,6 +80,10 @@ class StepLoop:
         if merge not in ("sharded", "allreduce"):
             raise ValueError("merge must be 'sharded' or 'allreduce'")
         self.merge = merge if hasattr(engine, "opt_step_flat") else "allreduce"
+        self.merge_report = None
+        self.collectives = os.environ.get("AMDKGE_DP_GATHER", "alltoall")   # sharded merge: "alltoall" | "native"
+        if self.collectives == "allgather":   # older spelling: all_to_all reduce-scatter + native all_gather
+            self.collectives = "alltoall+allgather"
         self.n_steps = 0
         self.use_tiled = prefer_tiled(engine)
         self.pos_atomic = False   # see configure_for_data
@@ -146,19 +150,72 @@ class StepLoop:
         eng, W, r = self.engine, self.world, self.rank
         g, p = eng.g_flat, eng.p_flat
         chunk = g.numel() // W                      # the flat buffers are padded to a multiple of 16 * 64 floats
-        recv = torch.empty_like(g)
-        self.dist.all_to_all_single(recv, g)        # recv[q*chunk:(q+1)*chunk] = rank q's partial sums of MY slice
-        g.zero_()                                   # gradients of the other slices are spent
         mine = g[r * chunk:(r + 1) * chunk]
-        torch.sum(recv.view(W, chunk), dim=0, out=mine)
+        if self.collectives == "native":            # the library's own reduce-scatter / all-gather schedules
+            red = torch.empty(chunk, dtype=g.dtype, device=g.device)
+            self.dist.reduce_scatter_tensor(red, g)
+            g.zero_()
+            mine.copy_(red)
+        else:
+            recv = torch.empty_like(g)
+            self.dist.all_to_all_single(recv, g)    # recv[q*chunk:(q+1)*chunk] = rank q's partial sums of MY slice
+            g.zero_()                               # gradients of the other slices are spent
+            torch.sum(recv.view(W, chunk), dim=0, out=mine)
         eng.opt_step_flat(opt_ffi, r * chunk, (r + 1) * chunk, lam, lam_r, reg_slot=1)   # leaves my gradient slice zero
         # parameters back to everyone.  Also as an all_to_all (the same slice to every peer, one link each) rather than a
         # ring all-gather, which would push W - 1 hops through a single xGMI link.  AMDKGE_DP_GATHER=allgather switches.
         mine_p = p[r * chunk:(r + 1) * chunk]
-        if os.environ.get("AMDKGE_DP_GATHER", "alltoall") == "allgather":
+        if self.collectives != "alltoall":
             self.dist.all_gather_into_tensor(p, mine_p.clone())
         else:
             self.dist.all_to_all_single(p, mine_p.expand(W, chunk).contiguous().view(-1))
+
+    def tune_merge(self, batch_of, first_step=0, trials=4, pick=None):
+        """Measure the merge schedules on THIS machine's fabric and keep the fastest (collective: call on every rank).
+
+        Every schedule computes the same update (up to fp32 summation order), so the 1 + `trials` steps spent on each
+        candidate are ordinary training steps: batch_of(step) -> global batch, steps first_step, first_step + 1, ...
+        Which schedule wins depends on the RCCL version and the xGMI topology (ring all-reduce vs. point-to-point
+        all_to_all vs. the library's reduce-scatter/all-gather), which is why it is measured rather than assumed.
+        Resets the loss accumulators (the schedules book the regulariser term differently).  Returns the number of
+        steps consumed; the choice is left in self.merge / self.collectives and described by self.merge_report.
+        pick: optional callable(candidates, seconds) -> index overriding "fastest" (must agree on every rank)."""
+        import time
+
+        import torch
+
+        self.merge_report = None
+        if self.world == 1 or not hasattr(self.engine, "opt_step_flat") or int(self.engine.g_flat.numel()) % self.world:
+            return 0
+        backend = getattr(self.dist, "get_backend", lambda: "")()
+        cands = [("allreduce", self.collectives), ("sharded", "alltoall"), ("sharded", "alltoall+allgather")]
+        if backend == "nccl":   # gloo has no reduce_scatter_tensor
+            cands.append(("sharded", "native"))
+        cuda = torch.cuda.is_available()
+        step, times = int(first_step), []
+        for merge, coll in cands:   # all-reduce first: it needs complete optimizer slots on every rank
+            self.merge, self.collectives = merge, coll
+            self.step(batch_of(step), step)
+            step += 1
+            if cuda:
+                torch.cuda.synchronize()
+            self.dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(int(trials)):
+                self.step(batch_of(step), step)
+                step += 1
+            if cuda:
+                torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / max(1, int(trials)))
+        t = torch.tensor(times, dtype=torch.float64, device=self.engine.g_flat.device)
+        self.dist.all_reduce(t, op=torch.distributed.ReduceOp.MAX)   # slowest rank decides, same choice everywhere
+        best = int(torch.argmin(t).item()) if pick is None else int(pick(cands, t.tolist()))
+        if cands[best][0] == "allreduce":
+            self.sync_optimizer_slots()   # the sharded candidates left every rank with only ITS slice up to date
+        self.merge, self.collectives = cands[best]
+        self.merge_report = {f"{m}/{c}" if m == "sharded" else m: float(x) * 1e3 for (m, c), x in zip(cands, t.tolist())}
+        self.reset_loss()
+        return step - int(first_step)
 
     def sync_optimizer_slots(self):
         """Sharded merge: every rank only maintains ITS slice of the optimizer slots.  Before a checkpoint is written

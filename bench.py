@@ -207,9 +207,14 @@ def main():
         if cur["i"] is not None:
             ev[cur["i"]][phase].record()
 
+    # N > 1, replicated tables: which gradient-merge schedule is fastest depends on the fabric -- measure the candidates
+    # on this node first (ordinary training steps, before the warmup; AMDKGE_DP_MERGE pins one instead)
+    tuned = 0
+    if world > 1 and not sharded and "AMDKGE_DP_MERGE" not in os.environ:
+        tuned = loop.tune_merge(batch_of, 0)
     loop.kernel_hook = hook
     loop.reset_loss()
-    for s in range(args.warmup):
+    for s in range(tuned, tuned + args.warmup):
         loop.step(batch_of(s), s)
     torch.cuda.synchronize()
     if world > 1:
@@ -218,7 +223,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         cur["i"] = s
-        loop.step(batch_of(args.warmup + s), args.warmup + s)
+        loop.step(batch_of(tuned + args.warmup + s), tuned + args.warmup + s)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -258,7 +263,9 @@ def main():
                        "global_batch": Bg, "n_ents": N, "n_rels": R, "row_floats": eng.K,
                        "parallelism": (f"rows{world} (row-sharded entity table, {args.parallelism.split('-')[1]} negatives, "
                                        "all_to_all row/gradient exchange)" if sharded else
-                                       f"dp{world} (replicated tables, gradient merge: {getattr(loop, 'merge', 'allreduce')})" if world > 1 else "single GPU")},
+                                       f"dp{world} (replicated tables, gradient merge: {getattr(loop, 'merge', 'allreduce')}"
+                                       f"{'/' + loop.collectives if getattr(loop, 'merge', '') == 'sharded' else ''})" if world > 1 else "single GPU"),
+                       "merge_ms_per_step_measured": getattr(loop, "merge_report", None)},
             "mean_batch_loss": loss_mean,
             "roofline": {"bound": "hbm", "kernel": " + ".join(kernel_names), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -120,6 +120,10 @@ class OracleEngine:
         for k, v in self._slot_flat.items():
             v[mask] = keep_s[k][mask]
 
+    @property
+    def slot_flat(self):
+        return {k: torch.from_numpy(v) for k, v in self._slot_flat.items()}
+
     def grad_tensors(self):
         return [self.g_flat]
 

@@ -150,3 +150,58 @@ def _run3(world, rank, port, out):
         np.savez(out, ent=eng.state.ent, rel=eng.state.rel, loss=loss)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _run_tuned(rank, world, port, out, force=None):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleEngine
+
+    from ampligraph_amd.latent_features import loss_functions, optimizers, regularizers
+    from ampligraph_amd.trainer import StepLoop
+
+    d = None
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        d = dist
+    ent, rel, X, k = _problem()
+    eng = OracleEngine("ComplEx", k, ent, rel, tiled=True, flat=True)
+    loop = StepLoop(eng, 3, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}),
+                    regularizers.get("LP", {"p": 2, "lambda": 1e-3}), seed=5, dist=d)
+    Xt = torch.as_tensor(X)
+    bs, nb = 37, 3
+
+    def batch_of(step):
+        b0 = (step % nb) * bs
+        return Xt[b0:b0 + bs]
+
+    pick = (lambda cands, secs: [c[0] for c in cands].index(force)) if force else None
+    used = loop.tune_merge(batch_of, 0, trials=2, pick=pick) if world > 1 else 0
+    if world > 1:
+        assert used == 9 and set(loop.merge_report) == {"allreduce", "sharded/alltoall", "sharded/alltoall+allgather"}
+        assert loop.merge in ("sharded", "allreduce") and (force is None or loop.merge == force)
+    for step in range(used, 14):
+        loop.step(batch_of(step), step)
+    # whichever schedule won, a checkpoint needs complete optimizer slots on every rank
+    loop.sync_optimizer_slots()
+    np.savez(out + f".{rank}.npz", ent=eng.state.ent, rel=eng.state.rel, m=eng._slot_flat["m"], v=eng._slot_flat["v"])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("force", [None, "allreduce"])
+def test_tune_merge_switches_schedules_mid_training(tmp_path, force):
+    """StepLoop.tune_merge: the candidates (all-reduce, all_to_all/all_to_all, all_to_all/all_gather) each take a few REAL
+    training steps; whatever is picked, tables and optimizer slots after 14 steps equal the single-rank run's.  With
+    force="allreduce" the choice is pinned to the all-reduce: exercises the switch back from sharded slots."""
+    single = str(tmp_path / "single")
+    _run_tuned(0, 1, 0, single)
+    port = _free_port()
+    multi = str(tmp_path / "multi")
+    mp.spawn(_run_tuned, args=(2, port, multi, force), nprocs=2, join=True)
+    a = np.load(single + ".0.npz")
+    for r in range(2):
+        b = np.load(multi + f".{r}.npz")
+        for key in ("ent", "rel", "m", "v"):
+            assert np.abs(a[key] - b[key]).max() < 5e-6, (r, key)
