@@ -33,6 +33,17 @@ template <> struct ModeTraits<MODE_ROT_S> { static constexpr int NQF = 4, NEF = 
 // and the tile and the filter kernel share this function, so they still agree bit for bit.
 __device__ __forceinline__ float rank_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
+// acc + |d| as ONE v_add_f32 with the abs source modifier.  Written as plain C the SLP vectoriser pairs the accumulations into
+// v_pk_add_f32, which has no abs modifier, and pays a v_and_b32 per unit for it: 4 issue slots per 2 units (pk sub, 2 and, pk add)
+// instead of 3 (pk sub, 2 add-abs).  Same IEEE operations, same order: bitwise identical scores.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float add_abs(float acc, float d) {
+    float r;
+    asm("v_add_f32 %0, %1, |%2|" : "=v"(r) : "v"(acc), "v"(d));
+    return r;
+}
+
 // One unit of the corruption score, accumulated in unit order.  Shared by the tile kernel and the
 // filter kernel so that both produce bitwise identical scores (compiled with -ffp-contract=off).
 template <int MODE>
@@ -41,9 +52,9 @@ __device__ __forceinline__ float rank_op(float acc, const float (&q)[ModeTraits<
     if constexpr (MODE == MODE_DOT) {
         return fmaf(q[0], e[0], acc);
     } else if constexpr (MODE == MODE_L1) {
-        return acc + fabsf(q[0] + e[0]);   // subject side: e + (p - o)        (TransE.py:77-83)
+        return add_abs(acc, q[0] + e[0]);  // subject side: e + (p - o)        (TransE.py:77-83)
     } else if constexpr (MODE == MODE_L1_SUB) {
-        return acc + fabsf(q[0] - e[0]);   // object side: (s + p) - e         (TransE.py:107-113); the sign is a template
+        return add_abs(acc, q[0] - e[0]);  // object side: (s + p) - e         (TransE.py:107-113); the sign is a template
                                            // parameter, not a multiply: 2 VALU instructions per unit instead of 3
     } else if constexpr (MODE == MODE_ROT_O) {
         const float re = q[0] - e[0], im = q[1] - e[1];   // RotatE.py:209-214
@@ -232,17 +243,31 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
                     const float4 t = *reinterpret_cast<const float4*>(&Es[f][kk][te * 4]);
                     ev[f][0] = t.x; ev[f][1] = t.y; ev[f][2] = t.z; ev[f][3] = t.w;
                 }
+                if constexpr (MODE == MODE_L1 || MODE == MODE_L1_SUB) {
+                    // rank_op's two operations with the first one packed: v_pk_add_f32 forms q +- e for two entities at
+                    // once (q broadcast through op_sel), add_abs accumulates each -- 3 issue slots per 2 units
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
+                    for (int x = 0; x < 4; ++x)
 #pragma unroll
-                    for (int y = 0; y < 4; ++y) {
-                        float qq[NQF], ee[NEF];
+                        for (int y = 0; y < 4; y += 2) {
+                            const f32x2 qq = {qv[0][x], qv[0][x]}, ee = {ev[0][y], ev[0][y + 1]};
+                            const f32x2 d = (MODE == MODE_L1) ? qq + ee : qq - ee;
+                            acc[x][y] = add_abs(acc[x][y], d.x);
+                            acc[x][y + 1] = add_abs(acc[x][y + 1], d.y);
+                        }
+                } else {
 #pragma unroll
-                        for (int f = 0; f < NQF; ++f) qq[f] = qv[f][x];
+                    for (int x = 0; x < 4; ++x)
 #pragma unroll
-                        for (int f = 0; f < NEF; ++f) ee[f] = ev[f][y];
-                        acc[x][y] = rank_op<MODE>(acc[x][y], qq, ee, a.g.sgn);
-                    }
+                        for (int y = 0; y < 4; ++y) {
+                            float qq[NQF], ee[NEF];
+#pragma unroll
+                            for (int f = 0; f < NQF; ++f) qq[f] = qv[f][x];
+#pragma unroll
+                            for (int f = 0; f < NEF; ++f) ee[f] = ev[f][y];
+                            acc[x][y] = rank_op<MODE>(acc[x][y], qq, ee, a.g.sgn);
+                        }
+                }
             }
             __syncthreads();
         }
