@@ -218,3 +218,80 @@ def test_fullsize_ranks_against_oracle(gpu_lib, model, k, N, n):
         assert (diff <= 2 * frag).all(), (side, diff.max())
     assert (got != ref).mean() < 0.05
     assert abs(O.mrr_score(got) - O.mrr_score(ref)) < 2e-3
+
+
+@pytest.mark.parametrize("model,k", [("RotatE", 1000), ("DistMult", 2000)])
+def test_table_beyond_2_31_elements(gpu_lib, model, k):
+    """(DistMult: the same through the single-pass F and the MFMA rank kernel.)  One GPU's C5 shard is 6.25 M rows x 2 000 floats = 12.5 G elements: every row offset must be 64-bit.  A RotatE
+    k=1000 table of 1.15 M rows (2.3 G floats, beyond 2^31) is trained / scored / ranked on its LAST 4 096 rows only
+    (sample_base / sample_range, ent_lo / ent_hi) and compared with the oracle on exactly those rows; rows outside stay
+    bit-identical; the same on the FIRST 4 096 rows."""
+    from oracle import kge_oracle as O
+
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+
+    N, R, eta, B, M = 1_150_000, 16, 8, 192, 4096
+    eng = KgeEngine(model, k, N, R, max_rel_size=R)
+    assert eng.ent.numel() > 2**31
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for r0 in range(0, N, 1 << 18):
+        eng.ent[r0:r0 + (1 << 18)].uniform_(-0.05, 0.05, generator=g)
+    eng.rel.uniform_(-0.5, 0.5, generator=g)
+    eng.prepare_training("adam")
+    rng = np.random.default_rng(5)
+    ld = _loss("self_adversarial")
+    opt = lambda t: _ffi.Opt(2, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, t)   # noqa: E731
+    for base in (N - M, 0):
+        ent_c = eng.ent[base:base + M].cpu().numpy()
+        rel = eng.rel.cpu().numpy()
+        Xc = np.stack([rng.integers(0, M, B), rng.integers(0, R, B), rng.integers(0, M, B)], 1).astype(np.int32)
+        X = Xc.copy(); X[:, 0] += base; X[:, 2] += base
+        Xd = torch.as_tensor(X).cuda()
+        # scores
+        ref_s = O.compute_scores(model, *O.lookup(ent_c, rel, Xc.astype(np.int64)), max_rel_size=R)
+        assert np.allclose(eng.score(Xd).cpu().numpy(), ref_s, rtol=2e-5, atol=1e-5 * np.abs(ref_s).max())
+        # gradients of both fused paths against the oracle on the compact table
+        negs_c = O.generate_corruptions(Xc, M, eta, 3, 7)
+        tot, Ge, Gr, (sp, sn, per) = O.dense_gradients(model, ent_c, rel, Xc, negs_c, eta, "self_adversarial", None, "sum", R)
+        for path in ("tiled", "atomic"):
+            eng.g_flat.zero_(); eng.loss_acc.zero_()
+            if path == "tiled":
+                eng.train_step_tiled(Xd, eta, ld, opt(1), 3, 7, sample_base=base, sample_range=M, grad_only=True)
+            else:
+                eng.train_fwdbwd(Xd, eta, ld, 3, 7, sample_base=base, sample_range=M)
+            L = float(eng.loss_acc[0])
+            assert abs(L - float(per.astype(np.float64).sum())) <= 2e-5 * abs(L), path
+            got = eng.g_ent[base:base + M].cpu().numpy()
+            scale = np.maximum(np.abs(Ge).max(axis=1, keepdims=True), 1e-6 * np.abs(Ge).max())
+            assert (np.abs(got - Ge) / scale).max() < 2e-4, path
+            assert (np.abs(eng.g_rel.cpu().numpy() - Gr) / np.maximum(np.abs(Gr).max(axis=1, keepdims=True), 1e-30)).max() < 2e-4
+            outside = eng.g_ent[:base] if base else eng.g_ent[M:]
+            assert float(outside.abs().max()) == 0.0, path
+            if path == "tiled":
+                g_tiled = got.copy()
+        # the complete in-place step: rows of the window follow Adam on the gradient just checked (the kernel's own bits: the
+        # update is ill-conditioned where |g| ~ eps, so the oracle's gradient would not do), all other rows keep their bits
+        eng.g_flat.zero_()
+        probe = [0, 1, N // 2, N - 1, base - 1 if base else M, (base + M) % N]
+        probe = [r for r in probe if not (base <= r < base + M)]
+        before = eng.ent[probe].clone()
+        eng.train_step_tiled(Xd, eta, ld, opt(1), 3, 7, sample_base=base, sample_range=M)
+        m = np.float32(1 - 0.9) * g_tiled; v = np.float32(1 - 0.999) * g_tiled * g_tiled
+        want = ent_c - np.float32(1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)) * m / (np.sqrt(v) + np.float32(1e-7))
+        got = eng.ent[base:base + M].cpu().numpy()
+        assert np.abs(got - want).max() < 5e-6 and np.abs(got - ent_c).max() > 1e-4
+        assert torch.equal(eng.ent[probe], before)
+        for s in eng.slots.values():   # fresh slots for the second window
+            s.zero_()
+        eng.ent[base:base + M].copy_(torch.as_tensor(ent_c))
+        # ranks against the window's rows (what a row-sharded rank counts against its shard)
+        T = Xc[:12].astype(np.int64)
+        rel = eng.rel.cpu().numpy()   # the in-place step above also swept the relation table
+        s_, p_, o_ = O.lookup(ent_c, rel, T)
+        tq = O.quantise(O.compute_scores(model, s_, p_, o_, max_rel_size=R))
+        for side, nm in ((_ffi.SIDE_S, "s"), (_ffi.SIDE_O, "o")):
+            cq = O.quantise(O.corruption_scores(model, nm, s_, p_, o_, ent_c, R))
+            ref = np.stack([(tq[:, None] < cq).sum(1), (tq[:, None] == cq).sum(1)], 1)
+            _, counts, _ = eng.rank_side(Xd[:12], side, "worst", None, ent_lo=base, ent_hi=base + M)
+            assert np.abs(counts.cpu().numpy() - ref).max() <= 2, nm
