@@ -243,7 +243,8 @@ def main():
         achieved = bytes_per_pos * B / (kern_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and world == 1:
+        headline = (args.model, args.k, args.eta, args.dataset, args.batch, args.popularity) == ("ComplEx", 200, 20, "synth-fb15k237", 10000, "uniform")
+        if os.path.exists(pmc) and world == 1 and headline:   # the PMC passes were collected on the headline workload only
             try:
                 traffic = json.load(open(pmc)).get("train_step_hbm_bytes_per_launch")
             except Exception:
