@@ -14,6 +14,7 @@
 //                 outrank the positive (always "<=", AbstractScoringLayer.py:292-303).
 //   rank_compose: tie strategy + filter subtraction + 1 (ScoringBasedEmbeddingModel.py:1684).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "kge_host.h"
 
@@ -307,7 +308,10 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
 //   the instruction, A[i = l & 31][k = l >> 5], then reads consecutive LDS words), next stage prefetched into
 //   registers while the current one is multiplied; epilogue = quantise -> compare with q(pos) -> packed count.
 // ------------------------------------------------------------------------------------------------
-constexpr int MQ = 128, ME = 128, MK = 32, MLD = 132;
+#ifndef KGE_MLD
+#define KGE_MLD 132
+#endif
+constexpr int MQ = 128, ME = 128, MK = 32, MLD = KGE_MLD;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr size_t MFMA_LDS_BYTES = (size_t)2 * 2 * MK * MLD * sizeof(float) + MQ * sizeof(int);
@@ -486,6 +490,222 @@ __global__ __launch_bounds__(256, 2) void rank_count_mfma_kernel(CountArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same tile computation as rank_count_mfma_kernel<true>, organised as ONE instruction stream per stage in which every
+// non-matrix instruction sits between two MFMAs.  A wave issues in order, so whatever is placed after the four MFMAs of a
+// unit pair only starts when the last of them has been issued; in the kernel above the global prefetch (with its bounds
+// branches), the 32 transposing ds_write_b32 and the barrier therefore run with the matrix pipe idle (MfmaUtil 0.70).  Here:
+//   * loads are two stages ahead (two register sets): stage g issues the global loads of stage g + 2 during its first four
+//     unit pairs and writes the set loaded during stage g - 1 to the other LDS buffer during its last eight pairs, one or
+//     two instructions behind each MFMA; a stage of matrix work (>= 4 096 cycles) covers the load latency;
+//   * no branches inside a stage: out-of-range units read the row start and are zeroed by a select, the load cursor runs
+//     past the last stage onto clamped addresses instead of being guarded;
+//   * operands of pair kk + 2 are read behind the first two MFMAs of pair kk.
+// Same MFMA order per accumulator => the same bits as the kernel above and as rank_op<MODE_DOT>.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void rank_count_mfma_pipe_kernel(CountArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_rank[];
+    typedef float (*tile_t)[MK][MLD];
+    tile_t Qs = reinterpret_cast<tile_t>(smem_rank);                                     // [2][MK][MLD]
+    tile_t Es = reinterpret_cast<tile_t>(smem_rank + (size_t)2 * MK * MLD * sizeof(float));
+    int* qps = reinterpret_cast<int*>(smem_rank + (size_t)4 * MK * MLD * sizeof(float));
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wq = (wv >> 1) * 64, we = (wv & 1) * 64;
+    const int l31 = lane & 31, lh = lane >> 5;
+    int bx, by;   // XCD-aware work order, see rank_count_mfma_kernel
+    {
+        const int xcd = blockIdx.x & 7;
+        const int64_t i = blockIdx.x >> 3;
+        const int qlo = (int)(((int64_t)a.qtiles * xcd) / 8), qhi = (int)(((int64_t)a.qtiles * (xcd + 1)) / 8);
+        const int nq = qhi - qlo;
+        if (i >= (int64_t)nq * a.splits) return;
+        const int full = nq / 8;
+        const int64_t per_group = (int64_t)8 * a.splits;
+        if (i < full * per_group) {
+            const int64_t r = i % per_group;
+            bx = qlo + (int)(i / per_group) * 8 + (int)(r & 7);
+            by = (int)(r >> 3);
+        } else {
+            const int rem = nq - full * 8;
+            const int64_t r = i - full * per_group;
+            bx = qlo + full * 8 + (int)(r % rem);
+            by = (int)(r / rem);
+        }
+    }
+    const int64_t q0 = (int64_t)bx * MQ;
+    const int64_t e_begin = a.ent_lo + (int64_t)by * a.ent_per_block;
+    const int64_t e_end = min(a.ent_hi, e_begin + a.ent_per_block);
+    const int U = a.g.U;
+    const int S = (U + MK - 1) / MK;
+    const int64_t ntile = (e_end - e_begin + ME - 1) / ME;
+    const int64_t G = ntile * S;
+
+    if (tid < MQ) { const int64_t qi = q0 + tid; qps[tid] = a.qpos[qi < a.n ? qi : a.n - 1]; }
+
+    // loader: float4 f = tid + 256 * i, i < 4 : row = f >> 3 (128 rows), 4-unit group kg = (f & 7) * 4 (32 units)
+    const int kg = (tid & 7) * 4, lrow = tid >> 3;   // (tid + 256 i) & 7 == tid & 7 ; row = lrow + 32 i
+    const float* qbase[4];
+    const float* ebase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t lq = q0 + lrow + 32 * i;
+        qbase[i] = a.Q + (lq < a.n ? lq : a.n - 1) * (int64_t)a.g.QW;
+    }
+    auto set_erow = [&](int64_t et) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t le = et + lrow + 32 * i;
+            const int64_t le_c = le < e_end ? le : e_end - 1;
+            const int64_t id = a.ent_ids ? (int64_t)a.ent_ids[le_c] : le_c;
+            ebase[i] = a.ent + id * a.g.K;
+        }
+    };
+    int ld_k0 = 0;          // load cursor: unit offset of the stage the next loads belong to ...
+    int64_t ld_tile = 0;    // ... and its entity tile (clamped to the last one once the cursor runs past the end)
+    // raw load of 4 units; units beyond U read the row start instead and are zeroed when the registers go to LDS (a select
+    // right here would make the wave wait for the load it has just issued)
+    auto fetch = [&](const float* base, int k0) -> float4 {
+        const int ku = k0 + kg;
+        return *reinterpret_cast<const float4*>(base + (ku < U ? ku : 0));
+    };
+    auto advance = [&]() {
+        ld_k0 += MK;
+        if (ld_k0 >= S * MK) {
+            ld_k0 = 0;
+            ld_tile = (ld_tile + 1 < ntile) ? ld_tile + 1 : ntile - 1;
+            set_erow(e_begin + ld_tile * ME);
+        }
+    };
+    float4 pq[2][4], pe[2][4];
+
+    int cnt[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cnt[mi][r] = 0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // prologue: stage 0 -> LDS buffer 0, stage 1 -> register set 1
+    set_erow(e_begin);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pq[0][i] = fetch(qbase[i], 0); pe[0][i] = fetch(ebase[i], 0); }
+    advance();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pq[1][i] = fetch(qbase[i], ld_k0); pe[1][i] = fetch(ebase[i], ld_k0); }
+    advance();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = lrow + 32 * i;
+        const float z = (kg < U) ? 1.f : 0.f;   // U % 4 == 0: a 4-unit group is inside or outside as a whole
+        Qs[0][kg + 0][row] = z * pq[0][i].x; Qs[0][kg + 1][row] = z * pq[0][i].y; Qs[0][kg + 2][row] = z * pq[0][i].z; Qs[0][kg + 3][row] = z * pq[0][i].w;
+        Es[0][kg + 0][row] = z * pe[0][i].x; Es[0][kg + 1][row] = z * pe[0][i].y; Es[0][kg + 2][row] = z * pe[0][i].z; Es[0][kg + 3][row] = z * pe[0][i].w;
+    }
+    __syncthreads();
+
+    int st = 0;
+    int64_t t = 0;
+    auto stage = [&](auto set_c) {
+        constexpr int SET = decltype(set_c)::value;   // LDS buffer of this stage == register set that is free for new loads
+        constexpr int OTH = SET ^ 1;                  // register set holding the next stage's data == LDS buffer it goes to
+        const bool okn = ((st + 1 == S) ? 0 : (st + 1) * MK) + kg < U;   // is this lane's unit group of the NEXT stage inside the row?
+        float opa[2][2], opb[2][2];
+        opa[0][0] = Qs[SET][lh][wq + l31]; opa[0][1] = Qs[SET][lh][wq + 32 + l31];
+        opb[0][0] = Es[SET][lh][we + l31]; opb[0][1] = Es[SET][lh][we + 32 + l31];
+        __builtin_amdgcn_sched_barrier(0);
+        // unit pairs 0..7: the four MFMAs of a pair, each followed by its share of the stage's other work
+#pragma unroll
+        for (int it = 0; it < MK / 4; ++it) {
+            const int kk = 2 * it, cur = it & 1, nxt = cur ^ 1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][0], opb[cur][0], acc[0][0], 0, 0, 0);
+            opa[nxt][0] = Qs[SET][kk + 2 + lh][wq + l31]; opb[nxt][0] = Es[SET][kk + 2 + lh][we + l31];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][0], opb[cur][1], acc[0][1], 0, 0, 0);
+            opa[nxt][1] = Qs[SET][kk + 2 + lh][wq + 32 + l31]; opb[nxt][1] = Es[SET][kk + 2 + lh][we + 32 + l31];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][1], opb[cur][0], acc[1][0], 0, 0, 0);
+            if (it < 4) {
+                pq[SET][it] = fetch(qbase[it], ld_k0);
+            } else {
+                const int i = it - 4, row = lrow + 32 * i;
+                Qs[OTH][kg + 0][row] = okn ? pq[OTH][i].x : 0.f; Qs[OTH][kg + 1][row] = okn ? pq[OTH][i].y : 0.f;
+                Qs[OTH][kg + 2][row] = okn ? pq[OTH][i].z : 0.f; Qs[OTH][kg + 3][row] = okn ? pq[OTH][i].w : 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][1], opb[cur][1], acc[1][1], 0, 0, 0);
+            if (it < 4) {
+                pe[SET][it] = fetch(ebase[it], ld_k0);
+            } else {
+                const int i = it - 4, row = lrow + 32 * i;
+                Es[OTH][kg + 0][row] = okn ? pe[OTH][i].x : 0.f; Es[OTH][kg + 1][row] = okn ? pe[OTH][i].y : 0.f;
+                Es[OTH][kg + 2][row] = okn ? pe[OTH][i].z : 0.f; Es[OTH][kg + 3][row] = okn ? pe[OTH][i].w : 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // unit pairs 8..15: nothing but matrix work and operand reads -- skipped as a whole when the stage holds <= 16 real
+        // units (the zero-padded half of a row's last stage: U = 400 -> 16 of 32 units; acc + 0 * 0 == acc)
+        if (U - st * MK > MK / 2) {
+#pragma unroll
+            for (int it = MK / 4; it < MK / 2; ++it) {
+                const int kk = 2 * it, cur = it & 1, nxt = cur ^ 1;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][0], opb[cur][0], acc[0][0], 0, 0, 0);
+                if (kk + 2 < MK) { opa[nxt][0] = Qs[SET][kk + 2 + lh][wq + l31]; opb[nxt][0] = Es[SET][kk + 2 + lh][we + l31]; }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][0], opb[cur][1], acc[0][1], 0, 0, 0);
+                if (kk + 2 < MK) { opa[nxt][1] = Qs[SET][kk + 2 + lh][wq + 32 + l31]; opb[nxt][1] = Es[SET][kk + 2 + lh][we + 32 + l31]; }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][1], opb[cur][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[cur][1], opb[cur][1], acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        advance();
+        __syncthreads();
+        if (++st == S) {   // ---- tile epilogue: C/D map col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+            const int64_t et = e_begin + t * ME;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const bool valid = (et + we + ni * 32 + l31) < e_end;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int qp = qps[wq + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                        const int q = quantise(a.sgn_scale * acc[mi][ni][r]);
+                        cnt[mi][r] += (valid && qp < q) ? 1 : 0;
+                        cnt[mi][r] += (valid && qp == q) ? 0x10000 : 0;
+                        acc[mi][ni][r] = 0.f;
+                    }
+            }
+            st = 0;
+            ++t;
+        }
+    };
+    for (int64_t g = 0; g < G; g += 2) {
+        stage(std::integral_constant<int, 0>{});
+        if (g + 1 < G) stage(std::integral_constant<int, 1>{});
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int g = cnt[mi][r] & 0xFFFF, e = cnt[mi][r] >> 16;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); e += __shfl_xor(e, o, 64); }
+            const int64_t qi = q0 + wq + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (l31 == 0 && qi < a.n) {
+                if (g) atomicAdd(&a.counts[2 * qi + 0], g);
+                if (e) atomicAdd(&a.counts[2 * qi + 1], e);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // filter kernel: one wave per test triple, one lane per true-positive id
 // ------------------------------------------------------------------------------------------------
 struct FilterArgs {
@@ -642,23 +862,35 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
     a.ent_lo = ent_lo; a.ent_hi = ent_hi; a.g = g; a.sgn_scale = mc.score_sign * mc.score_scale;
     const bool v4 = (g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
     const int mode = mode_of(m->scoring_type, side);
-    const char* force = getenv("AMDKGE_RANK_PATH");   // development: "valu" forces the VALU tile kernel
+    const char* force = getenv("AMDKGE_RANK_PATH");   // development: "valu" forces the VALU tile kernel, "mfma0" the first MFMA kernel
     const bool mfma = (mode == MODE_DOT) && !(force && force[0] == 'v');
     const int qt = mfma ? MQ : QT, et_ = mfma ? ME : ET;
     const int64_t qtiles = (n + qt - 1) / qt;
     const int64_t etiles = (ent_hi - ent_lo + et_ - 1) / et_;
-    // Entity tiles per block: the grid is (query tiles) x (entity splits).  Pick the split that minimises
-    // (rounds of resident blocks) x (tiles per block), i.e. the tail of the last round, with a mild bias towards
-    // longer blocks (one counter flush per block).
-    const int64_t slots = mfma ? 512 : 2048;   // resident workgroups on 256 CUs (2 resp. 8 per CU)
+    // Entity tiles per block: the grid is (query tiles) x (entity splits).  VALU kernel: pick the split that minimises
+    // (rounds of resident blocks) x (tiles per block), i.e. the tail of the last round, with a mild bias towards longer
+    // blocks (one counter flush per block).  MFMA kernel: the two workgroups resident on a CU share its matrix pipes, so
+    // what counts is the work of the busiest CU, ceil(blocks / 256) x (tiles per block + ~3/16 tile of prologue and
+    // flush) -- and a CU needs a SUCCESSION of blocks to keep two of them out of phase: measured on C3 (23 x 320 tiles)
+    // 5-10 tiles per block 1.96 ms, 15 (two blocks per CU, started together) 2.16 ms, 30 (one block per CU) 2.85 ms.
+    // So: at least 4 blocks per CU when the problem is large enough, else the cheapest split with a lone block priced
+    // at its measured ~0.6 efficiency.
+    const int64_t slots = mfma ? 256 : 2048;   // CUs resp. resident workgroups (8 per CU)
     int64_t tiles_per = 1, best_cost = -1;
-    for (int64_t tp = 1; tp <= (mfma ? 256 : 4096) && tp <= etiles; ++tp) {
-        const int64_t sp = (etiles + tp - 1) / tp;
-        if (sp > 65535) continue;
-        const int64_t rounds = (qtiles * sp + slots - 1) / slots;
-        const int64_t cost = rounds * (tp * 16 + 1);   // +1/16 tile per block for the flush
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; tiles_per = tp; }
+    for (int pass = 0; pass < 2 && best_cost < 0; ++pass) {
+        for (int64_t tp = 1; tp <= (mfma ? 256 : 4096) && tp <= etiles; ++tp) {
+            const int64_t sp = (etiles + tp - 1) / tp;
+            if (sp > 65535) continue;
+            const int64_t blocks = qtiles * sp;
+            if (mfma && pass == 0 && blocks < 4 * slots) continue;
+            const int64_t rounds = (blocks + slots - 1) / slots;
+            int64_t cost = rounds * (tp * 16 + (mfma ? 3 : 1));
+            if (mfma && rounds == 1) cost = cost * 5 / 3;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; tiles_per = tp; }
+        }
+        if (!mfma) break;
     }
+    if (const char* tp = getenv("AMDKGE_RANK_TP")) { if (atoi(tp) > 0) tiles_per = atoi(tp); }   // development knob
     if (best_cost < 0) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: entity range too large for one launch; split [ent_lo, ent_hi)");
     int64_t splits;
     a.ent_per_block = (int)(tiles_per * et_);
@@ -669,6 +901,7 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
         if (!attr_done) {
             hipError_t e1 = hipFuncSetAttribute((const void*)rank_count_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_BYTES);
             hipError_t e2 = hipFuncSetAttribute((const void*)rank_count_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_BYTES);
+            if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)rank_count_mfma_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_BYTES);
             if (e1 != hipSuccess || e2 != hipSuccess) return set_error_hip(e1 != hipSuccess ? e1 : e2, "hipFuncSetAttribute(rank_count_mfma)");
             attr_done = true;
         }
@@ -676,7 +909,9 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
         const int64_t nblk = 8 * ((qtiles + 7) / 8) * splits;
         if (nblk > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch; split the triples or the entity range");
         const dim3 grid1((unsigned)nblk);
-        if (v4) hipLaunchKernelGGL((rank_count_mfma_kernel<true>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
+        const bool pipe = !(force && force[0] == 'm');   // development: AMDKGE_RANK_PATH=mfma0 keeps the first MFMA kernel
+        if (v4 && pipe) hipLaunchKernelGGL(rank_count_mfma_pipe_kernel, grid1, dim3(256), MFMA_LDS_BYTES, st, a);
+        else if (v4) hipLaunchKernelGGL((rank_count_mfma_kernel<true>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         else hipLaunchKernelGGL((rank_count_mfma_kernel<false>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         return check_launch("rank_counts_mfma");
     }

@@ -483,10 +483,13 @@ def test_rank_filter_consistent_with_tile_kernel(gpu_lib):
 
 
 @pytest.mark.parametrize("model,k,N,n", [("DistMult", 37, 130, 50), ("ComplEx", 200, 1000, 333), ("HolE", 66, 257, 129),
-                                           ("DistMult", 400, 4100, 300)])
+                                           ("DistMult", 400, 4100, 300), ("DistMult", 16, 300, 77), ("DistMult", 32, 300, 77),
+                                           ("ComplEx", 24, 300, 200), ("ComplEx", 2, 150, 40)])
 def test_rank_mfma_kernel_bitwise_equals_valu_kernel(gpu_lib, model, k, N, n, monkeypatch):
-    """v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain: the MFMA tile kernel must return exactly the
-    (greater, equal) counts of the VALU tile kernel on random fp32 tables (ragged tiles, both sides, subset)."""
+    """v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain: the MFMA tile kernels (the software-pipelined default for rows of
+    whole float4s, the first kernel otherwise / with AMDKGE_RANK_PATH=mfma0) must return exactly the (greater, equal)
+    counts of the VALU tile kernel on random fp32 tables (ragged tiles, both sides, subset; rows of 4..800 units: one
+    stage, a half-empty last stage, odd and even stage counts)."""
     from ampligraph_amd import _ffi
 
     rng = np.random.default_rng(11)
@@ -497,9 +500,12 @@ def test_rank_mfma_kernel_bitwise_equals_valu_kernel(gpu_lib, model, k, N, n, mo
         for ent_ids in (None, sub):
             monkeypatch.delenv("AMDKGE_RANK_PATH", raising=False)
             c_mfma = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
+            monkeypatch.setenv("AMDKGE_RANK_PATH", "mfma0")
+            c_mfma0 = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
             monkeypatch.setenv("AMDKGE_RANK_PATH", "valu")
             c_valu = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
             assert (c_mfma == c_valu).all(), (model, side, np.abs(c_mfma - c_valu).max())
+            assert (c_mfma0 == c_valu).all(), (model, side, np.abs(c_mfma0 - c_valu).max())
             m = N if ent_ids is None else int(ent_ids.shape[0])
             assert (c_mfma.sum(1) <= m).all() and c_mfma.min() >= 0
 
