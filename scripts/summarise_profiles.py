@@ -70,7 +70,7 @@ if f:
     if per:
         m = {k: sum(v) / len(v) for k, v in per.items()}
         gui = m.get("GRBM_GUI_ACTIVE", 0.0) / 8.0          # summed over the 8 XCDs
-        mf = {"kernel": "rank_count_mfma_kernel", "launches": len(next(iter(per.values()))), "mean_per_launch": m,
+        mf = {"kernel": "rank_count_mfma_pipe_kernel", "launches": len(next(iter(per.values()))), "mean_per_launch": m,
               "gui_active_cycles_per_xcd": gui,
               "mfma_flop_per_launch": m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0,
               "mfma_util": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0) if gui else None,
