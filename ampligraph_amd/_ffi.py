@@ -82,6 +82,7 @@ SIGNATURES = {
     "amdkge_rank_counts": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, I64, I64, P, P, P]),
     "amdkge_rank_filter": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, P, P, P, I64, I64, P, P, P]),
     "amdkge_rank_compose": (C.c_int, [P, P, I64, I32, P, I64, P]),
+    "amdkge_filter_ranges": (C.c_int, [P, P, I64, P, I64, I32, I64, I64, P, P, P]),
 }
 
 _lib = None

@@ -928,6 +928,35 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
     return check_launch("rank_counts");
 }
 
+// filter lookup: one thread per test triple, lower_bound in the sorted (p,o) / (s,p) keys
+__global__ void filter_ranges_kernel(const int64_t* keys, const int64_t* start, int64_t n_keys, const int32_t* triples, int64_t n,
+                                     int side, int64_t n_ents, int64_t n_rels, int64_t* lo_out, int64_t* hi_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t s = triples[3 * i], p = triples[3 * i + 1], o = triples[3 * i + 2];
+    const int64_t q = (side == AMDKGE_SIDE_S) ? p * n_ents + o : s * n_rels + p;
+    int64_t a = 0, b = n_keys;
+    while (a < b) {
+        const int64_t m = (a + b) >> 1;
+        if (keys[m] < q) a = m + 1; else b = m;
+    }
+    const bool hit = a < n_keys && keys[a] == q;
+    lo_out[i] = hit ? start[a] : 0;
+    hi_out[i] = hit ? start[a + 1] : 0;
+}
+
+extern "C" int amdkge_filter_ranges(const int64_t* d_keys, const int64_t* d_start, int64_t n_keys, const int32_t* d_triples,
+                                    int64_t n, int32_t side, int64_t n_ents, int64_t n_rels, int64_t* d_lo, int64_t* d_hi,
+                                    void* stream) {
+    if (side != AMDKGE_SIDE_S && side != AMDKGE_SIDE_O) return set_error(AMDKGE_EINVAL, "filter_ranges: side must be AMDKGE_SIDE_S or AMDKGE_SIDE_O");
+    if (n < 0 || n_keys < 0 || n_ents <= 0 || n_rels <= 0) return set_error(AMDKGE_EINVAL, "filter_ranges: bad sizes");
+    if (n == 0) return AMDKGE_OK;
+    if (!d_triples || !d_lo || !d_hi || (n_keys > 0 && (!d_keys || !d_start))) return set_error(AMDKGE_EINVAL, "filter_ranges: NULL pointer");
+    hipLaunchKernelGGL(filter_ranges_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_keys, d_start,
+                       n_keys, d_triples, n, (int)side, n_ents, n_rels, d_lo, d_hi);
+    return check_launch("filter_ranges");
+}
+
 extern "C" int amdkge_rank_filter(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
                                   int64_t n, int32_t side, const int64_t* d_flt_lo, const int64_t* d_flt_hi,
                                   const int32_t* d_flt_ids, const int32_t* d_subset_pos, int64_t ent_lo, int64_t ent_hi,

@@ -194,6 +194,15 @@ class KgeEngine:
             int(step), int(row_offset), int(b_global), _ptr(out), _stream()))
         return out
 
+    def filter_ranges(self, keys, start, triples, side, n_ents, n_rels):
+        """(lo, hi) int64 device tensors: each triple's range in a FilterIndex id array (amdkge_filter_ranges)."""
+        n = int(triples.shape[0])
+        lo = torch.empty(n, dtype=torch.int64, device=self.device)
+        hi = torch.empty(n, dtype=torch.int64, device=self.device)
+        check(self.lib.amdkge_filter_ranges(_ptr(keys), _ptr(start), int(keys.shape[0]), _ptr(triples), n, int(side),
+                                            int(n_ents), int(n_rels), _ptr(lo), _ptr(hi), _stream()))
+        return lo, hi
+
     def compose_ranks(self, counts, sub, strategy, out=None, out_stride=1):
         """(greater, equal) counts [+ filter subtraction] -> 1-based ranks (amdkge_rank_compose)."""
         n = int(counts.shape[0])

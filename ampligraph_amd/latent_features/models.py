@@ -433,18 +433,11 @@ class ScoringBasedEmbeddingModel:
             ent_ids, subset_pos = torch.as_tensor(sub).to(dev), torch.as_tensor(pos).to(dev)
         Xd = torch.as_tensor(Xi).to(dev)
         ranks = torch.empty(n, len(sides), dtype=torch.int32, device=dev)
-        flt_ids = {}
-        if fi is not None:
-            flt_ids = {"s": torch.as_tensor(fi.s_ids if fi.s_ids.size else np.zeros(1, np.int32)).to(dev),
-                       "o": torch.as_tensor(fi.o_ids if fi.o_ids.size else np.zeros(1, np.int32)).to(dev)}
         CH = 1 << 16
         for c0 in range(0, n, CH):
             xs = Xd[c0:c0 + CH]
             for col, sd in enumerate(sides):
-                flt = None
-                if fi is not None:
-                    lo, hi = (fi.subject_ranges if sd == "s" else fi.object_ranges)(Xi[c0:c0 + CH])
-                    flt = (torch.as_tensor(lo).to(dev), torch.as_tensor(hi).to(dev), flt_ids[sd])
+                flt = fi.device_filter(dev, xs, sd, eng) if fi is not None else None   # range lookup on the device
                 eng.rank_side(xs, _ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, ranking_strategy, flt, ent_ids,
                               subset_pos, out=ranks[c0:c0 + CH, col], out_stride=len(sides))
         r = ranks.cpu().numpy()
@@ -495,18 +488,11 @@ class ScoringBasedEmbeddingModel:
         dev = eng.device
         n = Xi.shape[0]
         ranks = torch.empty(n, len(sides), dtype=torch.int32, device=dev)
-        flt_ids = {}
-        if fi is not None:
-            flt_ids = {"s": torch.as_tensor(fi.s_ids if fi.s_ids.size else np.zeros(1, np.int32)).to(dev),
-                       "o": torch.as_tensor(fi.o_ids if fi.o_ids.size else np.zeros(1, np.int32)).to(dev)}
         CH = self.EVAL_CHUNK_SHARDED
         Xd = torch.as_tensor(Xi).to(dev)
         for c0 in range(0, n, CH):
             for col, sd in enumerate(sides):
-                flt = None
-                if fi is not None:
-                    lo, hi = (fi.subject_ranges if sd == "s" else fi.object_ranges)(Xi[c0:c0 + CH])
-                    flt = (torch.as_tensor(lo).to(dev), torch.as_tensor(hi).to(dev), flt_ids[sd])
+                flt = fi.device_filter(dev, Xd[c0:c0 + CH], sd, eng) if fi is not None else None
                 counts, sub = sharded_rank_counts(eng, self._spec, d, Xd[c0:c0 + CH],
                                                   _ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, flt, subset)
                 eng.compose_ranks(counts, sub, ranking_strategy, out=ranks[c0:c0 + CH, col], out_stride=len(sides))

@@ -206,6 +206,16 @@ int amdkge_rank_filter(const amdkge_model* m, const float* d_ent, const float* d
                        const int32_t* d_subset_pos, int64_t ent_lo, int64_t ent_hi,
                        int32_t* d_sub, void* d_work, void* stream);
 
+/* Filter lookup for a batch of test triples: what the reference's data handler does per batch with pandas
+ * (graph_data_loader.py:287-350 get_participating_entities, :382-439) -- here a binary search per triple in a
+ * sorted key array built once on the host (datasets/filters.py: key = p * n_ents + o for the subject side,
+ * s * n_rels + p for the object side; d_start[n_keys + 1] = CSR offsets of each key's ids).
+ * d_lo[i], d_hi[i] = the range of triple i's true-positive ids (0, 0 when the key is absent): the d_flt_lo / d_flt_hi
+ * arguments of amdkge_rank_filter. */
+int amdkge_filter_ranges(const int64_t* d_keys, const int64_t* d_start, int64_t n_keys,
+                         const int32_t* d_triples, int64_t n, int32_t side, int64_t n_ents, int64_t n_rels,
+                         int64_t* d_lo, int64_t* d_hi, void* stream);
+
 /* Tie strategy + "+1" (AbstractScoringLayer.py:217-258, ScoringBasedEmbeddingModel.py:1684):
  * d_ranks[i] = strategy(gt,eq) - sub + 1;  d_sub may be NULL (unfiltered). */
 int amdkge_rank_compose(const int32_t* d_counts, const int32_t* d_sub, int64_t n, int32_t strategy,

@@ -36,6 +36,8 @@ def test_abi_argument_validation_without_gpu():
     assert lib.amdkge_score(ctypes.byref(m), None, None, None, 0, None, None) == 0       # empty input is a no-op
     assert lib.amdkge_score(ctypes.byref(m), None, None, None, 3, None, None) == -1      # NULL pointers
     assert lib.amdkge_rank_compose(None, None, 3, 7, None, 1, None) == -1                # unknown strategy
+    assert lib.amdkge_filter_ranges(None, None, 0, None, 5, 3, 10, 2, None, None, None) == -1   # bad side
+    assert lib.amdkge_filter_ranges(None, None, 0, None, 0, 1, 10, 2, None, None, None) == 0    # empty batch
     o = _ffi.Opt(2, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 0)
     assert lib.amdkge_opt_step(ctypes.byref(o), None, None, None, None, 0, None, None) == -1   # iteration is 1-based
     o = _ffi.Opt(2, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 1)

@@ -592,3 +592,23 @@ def test_empty_inputs(gpu_lib):
     eng.train_step_tiled(empty, 3, loss_desc("nll"), d, 0, 0)          # a zero-gradient Adam step: tables unchanged
     torch.cuda.synchronize()
     assert torch.equal(eng.ent, before)
+
+
+def test_filter_ranges_kernel_equals_host_lookup(gpu_lib):
+    """amdkge_filter_ranges (binary search per test triple on the device) == FilterIndex.subject_ranges / object_ranges
+    (numpy searchsorted), including triples whose (p,o) / (s,p) key is absent and an empty index."""
+    from ampligraph_amd.datasets.filters import FilterIndex
+
+    rng = np.random.default_rng(21)
+    N, R = 300, 7
+    eng, _, _ = make_engine("DistMult", 8, N, R)
+    X = rand_triples(rng, 4000, N, R)
+    T = rand_triples(rng, 1000, N, R)
+    T[:300] = X[rng.integers(0, len(X), 300)]
+    for fi in (FilterIndex([X], N, R), FilterIndex([X[:1]], N, R), FilterIndex([], N, R)):
+        for sd, fn in (("s", fi.subject_ranges), ("o", fi.object_ranges)):
+            lo, hi = fn(T)
+            l2, h2, ids = fi.device_filter(eng.device, dev(T), sd, eng)
+            assert np.array_equal(lo, l2.cpu().numpy()) and np.array_equal(hi, h2.cpu().numpy()), sd
+            l3, h3, _ = fi.device_filter(eng.device, dev(T), sd)   # torch fallback agrees too
+            assert np.array_equal(lo, l3.cpu().numpy()) and np.array_equal(hi, h3.cpu().numpy()), sd
