@@ -193,7 +193,28 @@ class StepLoop:
             cands.append(("sharded", "native"))
         cuda = torch.cuda.is_available()
         step, times = int(first_step), []
+        dev = self.engine.g_flat.device
+
+        def usable(coll):
+            """Probe the collectives of a schedule on scratch tensors first: a backend build that rejects one (raised at
+            call time, identically on every rank) drops the candidate before any training state is touched."""
+            W = self.world
+            a, b = torch.zeros(W * 4, device=dev), torch.zeros(W * 4, device=dev)
+            try:
+                if coll.startswith("alltoall"):
+                    self.dist.all_to_all_single(b, a)
+                if coll == "native":
+                    self.dist.reduce_scatter_tensor(b[:4], a)
+                if coll != "alltoall":
+                    self.dist.all_gather_into_tensor(b, a[:4].clone())
+            except RuntimeError:
+                return False
+            return True
+
         for merge, coll in cands:   # all-reduce first: it needs complete optimizer slots on every rank
+            if merge == "sharded" and not usable(coll):
+                times.append(float("inf"))
+                continue
             self.merge, self.collectives = merge, coll
             self.step(batch_of(step), step)
             step += 1
@@ -213,7 +234,8 @@ class StepLoop:
         if cands[best][0] == "allreduce":
             self.sync_optimizer_slots()   # the sharded candidates left every rank with only ITS slice up to date
         self.merge, self.collectives = cands[best]
-        self.merge_report = {f"{m}/{c}" if m == "sharded" else m: float(x) * 1e3 for (m, c), x in zip(cands, t.tolist())}
+        self.merge_report = {f"{m}/{c}" if m == "sharded" else m: (float(x) * 1e3 if x != float("inf") else None)
+                             for (m, c), x in zip(cands, t.tolist())}
         self.reset_loss()
         return step - int(first_step)
 

@@ -164,6 +164,14 @@ def _run_tuned(rank, world, port, out, force=None):
     if world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         d = dist
+        if force == "reject":   # a backend that rejects one of the collectives: that candidate is dropped, training goes on
+            class Rejecting:
+                def __getattr__(self, name):
+                    return getattr(dist, name)
+
+                def all_gather_into_tensor(self, *a, **kw):
+                    raise RuntimeError("all_gather_into_tensor: not supported by this backend build")
+            d, force = Rejecting(), None
     ent, rel, X, k = _problem()
     eng = OracleEngine("ComplEx", k, ent, rel, tiled=True, flat=True)
     loop = StepLoop(eng, 3, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}),
@@ -177,7 +185,9 @@ def _run_tuned(rank, world, port, out, force=None):
 
     pick = (lambda cands, secs: [c[0] for c in cands].index(force)) if force else None
     used = loop.tune_merge(batch_of, 0, trials=2, pick=pick) if world > 1 else 0
-    if world > 1:
+    if world > 1 and not isinstance(d, type(dist)):
+        assert used == 6 and loop.merge_report["sharded/alltoall+allgather"] is None and loop.collectives != "alltoall+allgather"
+    elif world > 1:
         assert used == 9 and set(loop.merge_report) == {"allreduce", "sharded/alltoall", "sharded/alltoall+allgather"}
         assert loop.merge in ("sharded", "allreduce") and (force is None or loop.merge == force)
     for step in range(used, 14):
@@ -190,7 +200,7 @@ def _run_tuned(rank, world, port, out, force=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("force", [None, "allreduce"])
+@pytest.mark.parametrize("force", [None, "allreduce", "reject"])
 def test_tune_merge_switches_schedules_mid_training(tmp_path, force):
     """StepLoop.tune_merge: the candidates (all-reduce, all_to_all/all_to_all, all_to_all/all_gather) each take a few REAL
     training steps; whatever is picked, tables and optimizer slots after 14 steps equal the single-rank run's.  With
