@@ -19,7 +19,10 @@ ABI_VERSION = 1
 # enums of include/amdkge.h
 SCORING_TYPES = {"TransE": 0, "DistMult": 1, "ComplEx": 2, "HolE": 3, "RotatE": 4}
 LOSSES = {"pairwise": 0, "nll": 1, "absolute_margin": 2, "self_adversarial": 3, "multiclass_nll": 4}
-OPTIMIZERS = {"sgd": 0, "adagrad": 1, "adam": 2}
+OPTIMIZERS = {"sgd": 0, "adagrad": 1, "adam": 2, "momentum": 3, "rmsprop": 4, "rmsprop_mom": 5, "adadelta": 6, "adamax": 7}
+# optimizer state tensors per table, in the slot order of include/amdkge.h (checkpoint keys are "<name>_e" / "<name>_r")
+OPT_SLOTS = {"sgd": (), "adagrad": ("a",), "adam": ("m", "v"), "momentum": ("mom",), "rmsprop": ("rms",),
+             "rmsprop_mom": ("rms", "mom"), "adadelta": ("acc", "dacc"), "adamax": ("m", "u")}
 SIDE_S, SIDE_O = 1, 2
 RANK_STRATEGY = {"worst": 0, "best": 1, "middle": 2}
 FOCUS_NONLINEARITY = {"linear": 1, "tanh": 2, "sigmoid": 3, "softplus": 4}

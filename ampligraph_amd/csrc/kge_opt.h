@@ -38,10 +38,48 @@ __device__ __forceinline__ void opt_elem(const OptArgs& a, float& x, float g, fl
     } else if constexpr (KIND == AMDKGE_OPT_ADAGRAD) {
         s0 += g * g;
         x -= a.lr * g / (sqrtf(s0) + a.eps);
+    } else if constexpr (KIND == AMDKGE_OPT_MOMENTUM) {      // ResourceApplyKerasMomentum
+        s0 = s0 * a.beta1 - a.lr * g;
+        x += (a.beta2 != 0.f) ? (s0 * a.beta1 - a.lr * g) : s0;
+    } else if constexpr (KIND == AMDKGE_OPT_RMSPROP) {       // RMSprop._resource_apply_dense, momentum == 0
+        s0 += (g * g - s0) * a.omb1;
+        x -= a.lr * g / (sqrtf(s0) + a.eps);
+    } else if constexpr (KIND == AMDKGE_OPT_RMSPROP_MOM) {   // ResourceApplyRMSProp
+        s0 += (g * g - s0) * a.omb1;
+        s1 = s1 * a.beta2 + (a.lr * g) / sqrtf(s0 + a.eps);
+        x -= s1;
+    } else if constexpr (KIND == AMDKGE_OPT_ADADELTA) {      // ResourceApplyAdadelta
+        s0 = s0 * a.beta1 + (g * g) * a.omb1;
+        const float u = sqrtf(s1 + a.eps) * (1.f / sqrtf(s0 + a.eps)) * g;
+        x -= u * a.lr;
+        s1 = s1 * a.beta1 + (u * u) * a.omb1;
+    } else if constexpr (KIND == AMDKGE_OPT_ADAMAX) {        // ResourceApplyAdaMax
+        s0 += (g - s0) * a.omb1;
+        s1 = fmaxf(a.beta2 * s1, fabsf(g));
+        x -= a.lr_t * s0 / (s1 + a.eps);
     } else {
         x -= a.lr * g;
     }
 }
+
+// number of optimizer state tensors a kind keeps per table
+__host__ __device__ constexpr int opt_nslots(int kind) {
+    return kind == AMDKGE_OPT_SGD ? 0
+         : (kind == AMDKGE_OPT_ADAGRAD || kind == AMDKGE_OPT_MOMENTUM || kind == AMDKGE_OPT_RMSPROP) ? 1 : 2;
+}
+
+// KGE_OPT_DISPATCH(kind, F): run F(KIND) with KIND a compile-time constant
+#define KGE_OPT_DISPATCH(kind, F)                                              \
+    switch (kind) {                                                            \
+        case AMDKGE_OPT_ADAM: F(AMDKGE_OPT_ADAM); break;                       \
+        case AMDKGE_OPT_ADAGRAD: F(AMDKGE_OPT_ADAGRAD); break;                 \
+        case AMDKGE_OPT_MOMENTUM: F(AMDKGE_OPT_MOMENTUM); break;               \
+        case AMDKGE_OPT_RMSPROP: F(AMDKGE_OPT_RMSPROP); break;                 \
+        case AMDKGE_OPT_RMSPROP_MOM: F(AMDKGE_OPT_RMSPROP_MOM); break;         \
+        case AMDKGE_OPT_ADADELTA: F(AMDKGE_OPT_ADADELTA); break;               \
+        case AMDKGE_OPT_ADAMAX: F(AMDKGE_OPT_ADAMAX); break;                   \
+        default: F(AMDKGE_OPT_SGD); break;                                     \
+    }
 
 
 // Grid-stride dense sweep over a.n elements (float4 body + scalar tail): optimizer + regulariser + gradient
@@ -57,27 +95,27 @@ __device__ __forceinline__ float opt_sweep(const OptArgs& a, int64_t first, int6
     for (int64_t i = first; i < n4; i += stride) {
         float4 x = x4[i], g = g4[i];
         float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
-        if constexpr (KIND != AMDKGE_OPT_SGD) m = m4[i];
-        if constexpr (KIND == AMDKGE_OPT_ADAM) v = v4[i];
+        if constexpr (opt_nslots(KIND) >= 1) m = m4[i];
+        if constexpr (opt_nslots(KIND) == 2) v = v4[i];
         opt_elem<KIND>(a, x.x, g.x, m.x, v.x, reg_acc);
         opt_elem<KIND>(a, x.y, g.y, m.y, v.y, reg_acc);
         opt_elem<KIND>(a, x.z, g.z, m.z, v.z, reg_acc);
         opt_elem<KIND>(a, x.w, g.w, m.w, v.w, reg_acc);
         x4[i] = x;
         g4[i] = make_float4(0, 0, 0, 0);
-        if constexpr (KIND != AMDKGE_OPT_SGD) m4[i] = m;
-        if constexpr (KIND == AMDKGE_OPT_ADAM) v4[i] = v;
+        if constexpr (opt_nslots(KIND) >= 1) m4[i] = m;
+        if constexpr (opt_nslots(KIND) == 2) v4[i] = v;
     }
     // scalar tail (n % 4)
     for (int64_t i = (n4 << 2) + first; i < a.n; i += stride) {
         float x = a.x[i], g = a.g[i], m = 0.f, v = 0.f;
-        if constexpr (KIND != AMDKGE_OPT_SGD) m = a.s0[i];
-        if constexpr (KIND == AMDKGE_OPT_ADAM) v = a.s1[i];
+        if constexpr (opt_nslots(KIND) >= 1) m = a.s0[i];
+        if constexpr (opt_nslots(KIND) == 2) v = a.s1[i];
         opt_elem<KIND>(a, x, g, m, v, reg_acc);
         a.x[i] = x;
         a.g[i] = 0.f;
-        if constexpr (KIND != AMDKGE_OPT_SGD) a.s0[i] = m;
-        if constexpr (KIND == AMDKGE_OPT_ADAM) a.s1[i] = v;
+        if constexpr (opt_nslots(KIND) >= 1) a.s0[i] = m;
+        if constexpr (opt_nslots(KIND) == 2) a.s1[i] = v;
     }
     return reg_acc;
 }
@@ -89,12 +127,13 @@ inline void fill_opt_args(OptArgs& a, const amdkge_opt* opt) {
     a.omb2 = (float)(1.0 - (double)opt->beta2);
     a.lam = opt->reg_lambda; a.kind = opt->kind; a.reg_p = opt->reg_p;
     const double t = (double)opt->iteration;
-    a.lr_t = (float)((double)opt->lr * sqrt(1.0 - pow((double)opt->beta2, t)) / (1.0 - pow((double)opt->beta1, t)));
+    if (opt->kind == AMDKGE_OPT_ADAMAX) a.lr_t = (float)((double)opt->lr / (1.0 - pow((double)opt->beta1, t)));
+    else a.lr_t = (float)((double)opt->lr * sqrt(1.0 - pow((double)opt->beta2, t)) / (1.0 - pow((double)opt->beta1, t)));
 }
 
 inline int validate_opt(const amdkge_opt* opt) {
     if (!opt) return set_error(AMDKGE_EINVAL, "NULL optimizer descriptor");
-    if (opt->kind < AMDKGE_OPT_SGD || opt->kind > AMDKGE_OPT_ADAM) return set_error(AMDKGE_EINVAL, "unknown optimizer kind");
+    if (opt->kind < AMDKGE_OPT_SGD || opt->kind > AMDKGE_OPT_ADAMAX) return set_error(AMDKGE_EINVAL, "unknown optimizer kind");
     if (opt->iteration < 1) return set_error(AMDKGE_EINVAL, "optimizer iteration is 1-based");
     if (opt->reg_lambda != 0.f && opt->reg_p < 1) return set_error(AMDKGE_EINVAL, "regulariser p must be >= 1");
     return AMDKGE_OK;

@@ -1,7 +1,7 @@
 // Dense optimizer sweep fused with the whole-table LP regulariser and the gradient-buffer reset.
 // Replaces OptimizerWrapper.minimize -> Keras *legacy* apply_gradients
 // (/root/reference/ampligraph/latent_features/optimizers.py:136-168; update rules live in the
-// third-party tensorflow==2.15 wheel, keras/optimizers/legacy/{adam,adagrad,gradient_descent}.py)
+// third-party tensorflow==2.15 wheel, keras/optimizers/legacy/{adam,adagrad,gradient_descent,rmsprop,adadelta,adamax}.py)
 // and LP_regularizer (regularizers.py:35-37).  Non-lazy like the reference: every row's slots
 // decay and every row moves each step.  HBM-bound: reads x,m,v,g and writes x,m,v,g(=0), 16 B/lane.
 #include "kge_opt.h"
@@ -30,8 +30,8 @@ extern "C" int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad,
     if (n_elems < 0) return set_error(AMDKGE_EINVAL, "opt_step: n_elems must be >= 0");
     if (n_elems == 0) return AMDKGE_OK;
     if (!d_x || !d_grad) return set_error(AMDKGE_EINVAL, "opt_step: NULL table / gradient pointer");
-    if (opt->kind != AMDKGE_OPT_SGD && !d_slot0) return set_error(AMDKGE_EINVAL, "opt_step: optimizer slot 0 is NULL");
-    if (opt->kind == AMDKGE_OPT_ADAM && !d_slot1) return set_error(AMDKGE_EINVAL, "opt_step: Adam slot 1 (v) is NULL");
+    if (opt_nslots(opt->kind) >= 1 && !d_slot0) return set_error(AMDKGE_EINVAL, "opt_step: optimizer slot 0 is NULL");
+    if (opt_nslots(opt->kind) == 2 && !d_slot1) return set_error(AMDKGE_EINVAL, "opt_step: optimizer slot 1 is NULL");
     if ((((uintptr_t)d_x | (uintptr_t)d_grad | (uintptr_t)d_slot0 | (uintptr_t)d_slot1) & 15) != 0)
         return set_error(AMDKGE_EINVAL, "opt_step: buffers must be 16-byte aligned");
     OptArgs a{};
@@ -41,8 +41,8 @@ extern "C" int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad,
     unsigned grid = (unsigned)((n4 + 255) / 256);
     if (grid > 2048) grid = 2048;   // 256 CUs x 8 blocks, grid-stride beyond
     hipStream_t st = (hipStream_t)stream;
-    if (opt->kind == AMDKGE_OPT_ADAM) hipLaunchKernelGGL(opt_kernel<AMDKGE_OPT_ADAM>, dim3(grid), dim3(256), 0, st, a);
-    else if (opt->kind == AMDKGE_OPT_ADAGRAD) hipLaunchKernelGGL(opt_kernel<AMDKGE_OPT_ADAGRAD>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(opt_kernel<AMDKGE_OPT_SGD>, dim3(grid), dim3(256), 0, st, a);
+#define KGE_OPT_LAUNCH(KIND) hipLaunchKernelGGL(opt_kernel<KIND>, dim3(grid), dim3(256), 0, st, a)
+    KGE_OPT_DISPATCH(opt->kind, KGE_OPT_LAUNCH)
+#undef KGE_OPT_LAUNCH
     return check_launch("opt_step");
 }

@@ -36,6 +36,7 @@
 #define KGE_FAST_ROTATE 1
 
 #include "kge_opt.h"
+#include <type_traits>
 #include "kge_train_kernel.h"
 
 namespace kge {
@@ -88,9 +89,9 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         // relation table: ordinary dense sweep (its gradient was completed by the forward kernel's atomics)
         const int64_t first = (int64_t)(tile - a.n_tiles) * TILE_THREADS + tid, stride = (int64_t)a.rel_blocks * TILE_THREADS;
         float racc;
-        if (a.rel_opt.kind == AMDKGE_OPT_ADAM) racc = opt_sweep<AMDKGE_OPT_ADAM>(a.rel_opt, first, stride);
-        else if (a.rel_opt.kind == AMDKGE_OPT_ADAGRAD) racc = opt_sweep<AMDKGE_OPT_ADAGRAD>(a.rel_opt, first, stride);
-        else racc = opt_sweep<AMDKGE_OPT_SGD>(a.rel_opt, first, stride);
+#define KGE_REL_SWEEP(KIND) racc = opt_sweep<KIND>(a.rel_opt, first, stride)
+        KGE_OPT_DISPATCH(a.rel_opt.kind, KGE_REL_SWEEP)
+#undef KGE_REL_SWEEP
         if (a.rel_opt.reg_loss && a.rel_opt.lam != 0.f) {
             const float w = wave_sum(racc);
             if (lane == 0) atomicAdd(a.rel_opt.reg_loss, (double)a.rel_opt.lam * (double)w);
@@ -242,7 +243,10 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     }
 
     // ---- flush: the tile's rows leave LDS exactly once ------------------------------------------------
+    // (the optimizer kind is dispatched once, outside the row loop: one compiled flush loop per update rule)
     float reg_acc = 0.f;
+    auto flush = [&](auto kind_c) {
+    constexpr int KIND = decltype(kind_c)::value;
     for (int r = grp; r < nrow; r += G) {
         const float* arow = acc + (size_t)r * a.K;
 #pragma unroll
@@ -264,26 +268,20 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                 }
                 float4* xp = reinterpret_cast<float4*>(a.x + off);
                 float4 x = *xp, m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
-                if (a.opt.kind == AMDKGE_OPT_ADAM) {
-                    m = *reinterpret_cast<float4*>(a.s0 + off);
-                    v = *reinterpret_cast<float4*>(a.s1 + off);
-                    opt_elem<AMDKGE_OPT_ADAM>(a.opt, x.x, g.x, m.x, v.x, reg_acc); opt_elem<AMDKGE_OPT_ADAM>(a.opt, x.y, g.y, m.y, v.y, reg_acc);
-                    opt_elem<AMDKGE_OPT_ADAM>(a.opt, x.z, g.z, m.z, v.z, reg_acc); opt_elem<AMDKGE_OPT_ADAM>(a.opt, x.w, g.w, m.w, v.w, reg_acc);
-                    *reinterpret_cast<float4*>(a.s0 + off) = m;
-                    *reinterpret_cast<float4*>(a.s1 + off) = v;
-                } else if (a.opt.kind == AMDKGE_OPT_ADAGRAD) {
-                    m = *reinterpret_cast<float4*>(a.s0 + off);
-                    opt_elem<AMDKGE_OPT_ADAGRAD>(a.opt, x.x, g.x, m.x, v.x, reg_acc); opt_elem<AMDKGE_OPT_ADAGRAD>(a.opt, x.y, g.y, m.y, v.y, reg_acc);
-                    opt_elem<AMDKGE_OPT_ADAGRAD>(a.opt, x.z, g.z, m.z, v.z, reg_acc); opt_elem<AMDKGE_OPT_ADAGRAD>(a.opt, x.w, g.w, m.w, v.w, reg_acc);
-                    *reinterpret_cast<float4*>(a.s0 + off) = m;
-                } else {
-                    opt_elem<AMDKGE_OPT_SGD>(a.opt, x.x, g.x, m.x, v.x, reg_acc); opt_elem<AMDKGE_OPT_SGD>(a.opt, x.y, g.y, m.y, v.y, reg_acc);
-                    opt_elem<AMDKGE_OPT_SGD>(a.opt, x.z, g.z, m.z, v.z, reg_acc); opt_elem<AMDKGE_OPT_SGD>(a.opt, x.w, g.w, m.w, v.w, reg_acc);
-                }
+                if constexpr (opt_nslots(KIND) >= 1) m = *reinterpret_cast<float4*>(a.s0 + off);
+                if constexpr (opt_nslots(KIND) == 2) v = *reinterpret_cast<float4*>(a.s1 + off);
+                opt_elem<KIND>(a.opt, x.x, g.x, m.x, v.x, reg_acc); opt_elem<KIND>(a.opt, x.y, g.y, m.y, v.y, reg_acc);
+                opt_elem<KIND>(a.opt, x.z, g.z, m.z, v.z, reg_acc); opt_elem<KIND>(a.opt, x.w, g.w, m.w, v.w, reg_acc);
+                if constexpr (opt_nslots(KIND) >= 1) *reinterpret_cast<float4*>(a.s0 + off) = m;
+                if constexpr (opt_nslots(KIND) == 2) *reinterpret_cast<float4*>(a.s1 + off) = v;
                 *xp = x;
             }
         }
     }
+    };
+#define KGE_FLUSH(KIND) flush(std::integral_constant<int, KIND>{})
+    KGE_OPT_DISPATCH(a.opt.kind, KGE_FLUSH)
+#undef KGE_FLUSH
     if (a.apply_update && a.reg_loss && a.opt.lam != 0.f) {
         const float w = wave_sum(reg_acc);
         if (lane == 0) atomicAdd(a.reg_loss, (double)a.opt.lam * (double)w);
@@ -443,10 +441,10 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     if (!make_plan(m, B, eta, p))
         return set_error(AMDKGE_EUNSUPPORTED, "train_step_tiled: shape not supported (k % 4 != 0, k > 2048 or eta too large); use amdkge_train_fwdbwd + amdkge_opt_step");
     if (apply_update) {
-        if (opt->kind != AMDKGE_OPT_SGD && !d_ent_slot0) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 0 is NULL");
-        if (opt->kind == AMDKGE_OPT_ADAM && !d_ent_slot1) return set_error(AMDKGE_EINVAL, "train_step_tiled: Adam slot 1 (v) is NULL");
+        if (opt_nslots(opt->kind) >= 1 && !d_ent_slot0) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 0 is NULL");
+        if (opt_nslots(opt->kind) == 2 && !d_ent_slot1) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 1 is NULL");
     }
-    const bool d_rel_slot_ok = (opt->kind == AMDKGE_OPT_SGD || d_rel_slot0) && (opt->kind != AMDKGE_OPT_ADAM || d_rel_slot1);
+    const bool d_rel_slot_ok = (opt_nslots(opt->kind) < 1 || d_rel_slot0) && (opt_nslots(opt->kind) < 2 || d_rel_slot1);
     if (apply_update && !d_rel_slot_ok && (d_rel_slot0 || d_rel_slot1))
         return set_error(AMDKGE_EINVAL, "train_step_tiled: relation optimizer slots incomplete for this optimizer");
     if (B > 0 && !d_triples) return set_error(AMDKGE_EINVAL, "train_step_tiled: null triples");

@@ -84,8 +84,7 @@ class KgeEngine:
         self.g_ent = self.g_flat[:ne].view_as(self.ent)
         self.g_rel = self.g_flat[off:off + nr].view_as(self.rel)
         self.slots, self.slot_flat = {}, {}
-        names = {"adam": ("m", "v"), "adagrad": ("a",), "sgd": ()}[optimizer]
-        for nme in names:   # Keras legacy Adagrad initial_accumulator_value = 0.1
+        for nme in _ffi.OPT_SLOTS[optimizer]:   # Keras legacy Adagrad initial_accumulator_value = 0.1
             fl = self._flat(fill=0.1 if nme == "a" else 0.0)
             self.slot_flat[nme] = fl
             self.slots[nme + "_e"] = fl[:ne].view_as(self.ent)
@@ -106,12 +105,11 @@ class KgeEngine:
             _ptr(neg_override), _ptr(self.g_ent), _ptr(self.g_rel), C.c_void_p(self.loss_acc.data_ptr()),
             _ptr(pos_scores), _ptr(neg_scores), _stream()))
 
-    def _slots_of(self, names):
-        if self.opt_kind == "adam":
-            return self.slots[names[0]], self.slots[names[1]]
-        if self.opt_kind == "adagrad":
-            return self.slots[names[2]], None
-        return None, None
+    def _slots_of(self, table):
+        """(slot0, slot1) tensors of table "e" | "r" in the ABI's slot order (None where the optimizer has none)."""
+        names = _ffi.OPT_SLOTS[self.opt_kind]
+        got = [self.slots[f"{nme}_{table}"] for nme in names]
+        return (got + [None, None])[:2]
 
     def tiled_supported(self, B, eta):
         """True when the owner-computes step (amdkge_train_step_tiled) covers this shape."""
@@ -133,8 +131,8 @@ class KgeEngine:
             self._twork = torch.zeros(need, dtype=torch.uint8, device=self.device)
         if sample_range is None:
             sample_range = self.n_ents
-        s0, s1 = self._slots_of(("m_e", "v_e", "a_e"))
-        r0, r1 = self._slots_of(("m_r", "v_r", "a_r"))
+        s0, s1 = self._slots_of("e")
+        r0, r1 = self._slots_of("r")
         opt_desc.reg_lambda = float(reg_e)
         try:
             check(self.lib.amdkge_train_step_tiled(
@@ -153,16 +151,11 @@ class KgeEngine:
         sweep to the first rows_e rows (row-sharded mode: the rows behind them are fetched copies of remote
         rows); reg_slots = loss_acc slots receiving the entity / relation regulariser values."""
         n_e = self.ent.numel() if rows_e is None else int(rows_e) * self.K
-        for x, g, names, lam, n_el, slot in ((self.ent, self.g_ent, ("m_e", "v_e", "a_e"), reg_e, n_e, reg_slots[0]),
-                                             (self.rel, self.g_rel, ("m_r", "v_r", "a_r"), reg_r, self.rel.numel(), reg_slots[1])):
+        for x, g, table, lam, n_el, slot in ((self.ent, self.g_ent, "e", reg_e, n_e, reg_slots[0]),
+                                             (self.rel, self.g_rel, "r", reg_r, self.rel.numel(), reg_slots[1])):
             reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(slot))
             opt_desc.reg_lambda = float(lam)
-            if self.opt_kind == "adam":
-                s0, s1 = self.slots[names[0]], self.slots[names[1]]
-            elif self.opt_kind == "adagrad":
-                s0, s1 = self.slots[names[2]], None
-            else:
-                s0 = s1 = None
+            s0, s1 = self._slots_of(table)
             check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(x), _ptr(g), _ptr(s0), _ptr(s1),
                                            n_el, reg_ptr, _stream()))
 
@@ -178,7 +171,7 @@ class KgeEngine:
         if b > a:
             segs.append((a, b, reg_r))
         reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(reg_slot))
-        names = {"adam": ("m", "v"), "adagrad": ("a",), "sgd": ()}[self.opt_kind]
+        names = _ffi.OPT_SLOTS[self.opt_kind]
         for a, b, lam in segs:
             opt_desc.reg_lambda = float(lam)
             sl = [self.slot_flat[n][a:b] for n in names] + [None, None]

@@ -1,27 +1,49 @@
 """Optimizer surface (/root/reference/ampligraph/latent_features/optimizers.py:255-291).  The reference
 wraps a Keras *legacy* optimizer; here an Optimizer carries the hyper-parameters of the same update
-rule and the dense sweep runs in HIP (ampligraph_amd/csrc/kge_opt.hip).  Supported: adam, adagrad, sgd
-(the three the hot path names); defaults are Keras legacy's (epsilon 1e-7, Adagrad accumulator 0.1)."""
+rule and the dense sweep runs in HIP (ampligraph_amd/csrc/kge_opt.hip).  Supported by name, like the reference's lookup in
+the Keras legacy namespace (:57-67): adam, adagrad, sgd (+ momentum / nesterov), rmsprop (+ momentum), adadelta, adamax, with
+Keras legacy defaults (epsilon 1e-7, Adagrad accumulator 0.1, rho 0.9 / 0.95).  Not supported (three state tensors per table
+or scalar schedules): amsgrad, centered RMSprop, Nadam, Ftrl -- rejected with ValueError."""
 from .. import _ffi
 
 
 class OptimizerWrapper:
-    def __init__(self, name, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, **unused):
+    """name: the Keras name ("sgd", "rmsprop", ...).  `kind` is the update rule the kernels run ("momentum" for SGD with
+    momentum, "rmsprop_mom" for RMSprop with momentum): it also names the optimizer-state layout of engine / checkpoints."""
+
+    def __init__(self, name, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, momentum=0.0, nesterov=False,
+                 rho=None, amsgrad=False, centered=False, **unused):
         name = name.lower()
-        if name not in _ffi.OPTIMIZERS:
+        if name not in ("sgd", "adagrad", "adam", "rmsprop", "adadelta", "adamax") or name.endswith("_mom"):
             raise ValueError("Could not interpret optimizer identifier: ", name)
-        self.name = name
+        if amsgrad or centered:
+            raise ValueError("amsgrad / centered RMSprop keep three state tensors per table: not supported")
+        self.keras_name = name
         self.learning_rate = float(learning_rate)
         self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+        self.momentum, self.nesterov = float(momentum), bool(nesterov)
+        self.rho = float(rho) if rho is not None else (0.95 if name == "adadelta" else 0.9)
+        self.name = name   # update rule ("kind"): what engine.prepare_training / the kernels are given
+        if name == "sgd" and self.momentum != 0.0:
+            self.name = "momentum"
+        elif name == "rmsprop" and self.momentum != 0.0:
+            self.name = "rmsprop_mom"
         self.iterations = 0
 
     def to_ffi(self, iteration, reg_p=2):
-        return _ffi.Opt(_ffi.OPTIMIZERS[self.name], int(reg_p), self.learning_rate, self.beta_1, self.beta_2,
-                        self.epsilon, 0.0, int(iteration))
+        b1, b2 = self.beta_1, self.beta_2
+        if self.name == "momentum":
+            b1, b2 = self.momentum, (1.0 if self.nesterov else 0.0)
+        elif self.name in ("rmsprop", "rmsprop_mom"):
+            b1, b2 = self.rho, self.momentum
+        elif self.name == "adadelta":
+            b1, b2 = self.rho, 0.0
+        return _ffi.Opt(_ffi.OPTIMIZERS[self.name], int(reg_p), self.learning_rate, b1, b2, self.epsilon, 0.0, int(iteration))
 
     def get_config(self):
-        return {"name": self.name, "learning_rate": self.learning_rate, "beta_1": self.beta_1,
-                "beta_2": self.beta_2, "epsilon": self.epsilon}
+        return {"name": self.keras_name, "learning_rate": self.learning_rate, "beta_1": self.beta_1,
+                "beta_2": self.beta_2, "epsilon": self.epsilon, "momentum": self.momentum, "nesterov": self.nesterov,
+                "rho": self.rho}
 
 
 def get(identifier, hyperparams=None):
@@ -33,7 +55,8 @@ def get(identifier, hyperparams=None):
         return OptimizerWrapper(identifier, learning_rate=lr, **hyperparams)
     # duck-typed Keras-like optimizer object: class name + learning_rate attribute
     name = type(identifier).__name__.lower()
-    if name in _ffi.OPTIMIZERS and hasattr(identifier, "learning_rate"):
-        cfg = {k: getattr(identifier, k) for k in ("beta_1", "beta_2", "epsilon") if hasattr(identifier, k)}
+    if name in ("sgd", "adagrad", "adam", "rmsprop", "adadelta", "adamax") and hasattr(identifier, "learning_rate"):
+        cfg = {k: getattr(identifier, k) for k in ("beta_1", "beta_2", "epsilon", "momentum", "nesterov", "rho", "amsgrad",
+                                                   "centered") if hasattr(identifier, k)}
         return OptimizerWrapper(name, learning_rate=float(identifier.learning_rate), **cfg)
     raise ValueError("Could not interpret optimizer identifier: ", identifier)

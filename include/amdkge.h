@@ -41,7 +41,14 @@ enum { AMDKGE_TRANSE = 0, AMDKGE_DISTMULT = 1, AMDKGE_COMPLEX = 2, AMDKGE_HOLE =
 enum { AMDKGE_LOSS_PAIRWISE = 0, AMDKGE_LOSS_NLL = 1, AMDKGE_LOSS_ABSOLUTE_MARGIN = 2,
        AMDKGE_LOSS_SELF_ADVERSARIAL = 3, AMDKGE_LOSS_MULTICLASS_NLL = 4 };
 /* optimizer -- latent_features/optimizers.py:255-291 (Keras *legacy* update rules) */
-enum { AMDKGE_OPT_SGD = 0, AMDKGE_OPT_ADAGRAD = 1, AMDKGE_OPT_ADAM = 2 };
+/* Keras legacy update rules (tensorflow==2.15, keras/optimizers/legacy/<name>.py; reached from optimizers.py:57-67,279-287, which
+ * accepts any legacy optimizer by name).  Slots used: SGD 0; ADAGRAD, MOMENTUM, RMSPROP 1; ADAM, RMSPROP_MOM, ADADELTA, ADAMAX 2. */
+enum { AMDKGE_OPT_SGD = 0, AMDKGE_OPT_ADAGRAD = 1, AMDKGE_OPT_ADAM = 2,
+       AMDKGE_OPT_MOMENTUM = 3,      /* SGD(momentum=beta1, nesterov = beta2 != 0): a = a*mom - lr*g; x += nesterov ? a*mom - lr*g : a */
+       AMDKGE_OPT_RMSPROP = 4,       /* rho = beta1: r += (g^2 - r)(1-rho); x -= lr*g / (sqrt(r) + eps) */
+       AMDKGE_OPT_RMSPROP_MOM = 5,   /* rho = beta1, momentum = beta2: r as above; mom = mom*momentum + lr*g / sqrt(r + eps); x -= mom */
+       AMDKGE_OPT_ADADELTA = 6,      /* rho = beta1: a = a*rho + g^2(1-rho); u = sqrt(d + eps) / sqrt(a + eps) * g; x -= lr*u; d = d*rho + u^2(1-rho) */
+       AMDKGE_OPT_ADAMAX = 7 };      /* m += (g-m)(1-beta1); u = max(beta2*u, |g|); x -= lr/(1-beta1^t) * m / (u + eps) */
 /* corrupt side bit mask -- ScoringBasedEmbeddingModel.evaluate(corrupt_side=...) :1516 */
 enum { AMDKGE_SIDE_S = 1, AMDKGE_SIDE_O = 2 };
 /* ranking_strategy -- AbstractScoringLayer.get_ranks(comparison_type=...) :165 */
@@ -79,7 +86,7 @@ typedef struct amdkge_opt {
     int32_t kind;           /* AMDKGE_OPT_* */
     int32_t reg_p;          /* LP regulariser power p (>=1); ignored when reg_lambda == 0 */
     float lr;
-    float beta1, beta2;     /* Adam */
+    float beta1, beta2;     /* Adam / Adamax betas; other kinds: see the AMDKGE_OPT_* enum */
     float epsilon;          /* Adam / Adagrad (Keras legacy default 1e-7) */
     float reg_lambda;       /* 0 = no regulariser */
     int64_t iteration;      /* t = optimizer.iterations + 1 of this step (1-based) */
@@ -134,7 +141,8 @@ int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* loss,
  * whole-table LP regulariser (regularizers.py:35-37): one dense sweep over `n_elems` floats of a
  * table.  grad_total = d_grad + lambda*p*|x|^(p-1)*sign(x); updates d_x and the slots in place,
  * zeroes d_grad, and adds lambda*sum|x|^p (pre-update x) to *d_reg_loss (double, may be NULL).
- *   Adam:    d_slot0 = m, d_slot1 = v;  Adagrad: d_slot0 = accumulator;  SGD: no slots. */
+ *   Adam:    d_slot0 = m, d_slot1 = v;  Adagrad: d_slot0 = accumulator;  SGD: no slots;  the other kinds: slot order as
+ *   written in the AMDKGE_OPT_* enum (first state variable = d_slot0). */
 int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_slot0, float* d_slot1,
                     int64_t n_elems, double* d_reg_loss, void* stream);
 

@@ -420,20 +420,24 @@ def glorot_uniform(rows, cols, rng):
 # ----------------------------------------------------------------------------
 # a17/a18/a19: one training step with dense Keras-legacy optimizer semantics
 # ----------------------------------------------------------------------------
+# optimizer state tensors per table ("kind" = update rule: SGD with momentum is "momentum", RMSprop with momentum "rmsprop_mom")
+OPT_SLOTS = {"sgd": (), "adagrad": ("a",), "adam": ("m", "v"), "momentum": ("mom",), "rmsprop": ("rms",),
+             "rmsprop_mom": ("rms", "mom"), "adadelta": ("acc", "dacc"), "adamax": ("m", "u")}
+
+
 class TrainState:
-    def __init__(self, ent, rel, optimizer="adam", lr=1e-3):
+    def __init__(self, ent, rel, optimizer="adam", lr=1e-3, **hp):
+        """hp: momentum, nesterov, rho, beta_1, beta_2, epsilon (Keras legacy defaults when absent)."""
         self.ent = np.array(ent, dtype=F32)
         self.rel = np.array(rel, dtype=F32)
         self.optimizer = optimizer
         self.lr = lr
+        self.hp = dict(hp)
         self.iterations = 0
-        if optimizer == "adam":
-            self.slots = {"m_e": np.zeros_like(self.ent), "v_e": np.zeros_like(self.ent),
-                          "m_r": np.zeros_like(self.rel), "v_r": np.zeros_like(self.rel)}
-        elif optimizer == "adagrad":
-            self.slots = {"a_e": np.full_like(self.ent, 0.1), "a_r": np.full_like(self.rel, 0.1)}
-        else:
-            self.slots = {}
+        self.slots = {}
+        for nme in OPT_SLOTS[optimizer]:   # Keras legacy Adagrad: initial_accumulator_value = 0.1
+            for tab, arr in (("e", self.ent), ("r", self.rel)):
+                self.slots[f"{nme}_{tab}"] = np.full_like(arr, 0.1) if nme == "a" else np.zeros_like(arr)
 
 
 def focus_transform(x, weight, non_linearity):
@@ -498,30 +502,75 @@ def dense_gradients(model, ent, rel, pos, negs, eta, loss_name, loss_params=None
     return F32(total), Ge, Gr, (sp, sn, per)
 
 
-def apply_optimizer(state, Ge, Gr, beta1=0.9, beta2=0.999, eps=1e-7):
-    """Keras *legacy* update rules (tensorflow==2.15 keras/optimizers/legacy; third-party,
-    not vendored in /root/reference -- parity unpinned).  Dense over all rows, i.e. the
-    non-lazy behaviour of optimizer_v2 Adam._resource_apply_sparse: every row's m,v decay
-    and every row moves each step.  Reached from optimizers.py:166-168."""
+def apply_optimizer(state, Ge, Gr, beta1=None, beta2=None, eps=None):
+    """Keras *legacy* update rules (tensorflow==2.15 keras/optimizers/legacy/{adam,adagrad,gradient_descent,rmsprop,
+    adadelta,adamax}.py and the fused kernels they call, core/kernels/training_ops.cc; third-party, not vendored in
+    /root/reference -- parity unpinned).  Dense over all rows, i.e. the non-lazy behaviour of optimizer_v2
+    Adam._resource_apply_sparse: every row's state decays and every row moves each step.  Reached from optimizers.py:166-168
+    (any legacy optimizer name is accepted there, :57-67)."""
+    hp = getattr(state, "hp", {})
+    b1 = float(hp.get("beta_1", 0.9) if beta1 is None else beta1)
+    b2 = float(hp.get("beta_2", 0.999) if beta2 is None else beta2)
+    beta1, beta2 = F32(b1), F32(b2)
+    eps = F32(hp.get("epsilon", 1e-7) if eps is None else eps)
     state.iterations += 1
     t = state.iterations
     lr = F32(state.lr)
-    ge, gr = Ge.astype(F32), Gr.astype(F32)
-    if state.optimizer == "adam":
-        lr_t = F32(float(lr) * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
-        for x, g, mk, vk in ((state.ent, ge, "m_e", "v_e"), (state.rel, gr, "m_r", "v_r")):
-            m, v = state.slots[mk], state.slots[vk]
-            m[...] = m * F32(beta1) + g * F32(1 - beta1)
-            v[...] = v * F32(beta2) + (g * g) * F32(1 - beta2)
-            x -= (lr_t * m) / (np.sqrt(v) + F32(eps))
-    elif state.optimizer == "adagrad":
-        for x, g, ak in ((state.ent, ge, "a_e"), (state.rel, gr, "a_r")):
-            a = state.slots[ak]
+    kind = state.optimizer
+    tabs = ((state.ent, Ge.astype(F32), "e"), (state.rel, Gr.astype(F32), "r"))
+    sl = lambda nme, tab: state.slots[f"{nme}_{tab}"]   # noqa: E731
+    if kind == "adam":
+        lr_t = F32(float(lr) * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t))
+        # one_minus_beta_t = 1 - beta_t is formed from the fp32 hyper-parameter tensors (adam.py _prepare_local)
+        omb1, omb2 = F32(1) - beta1, F32(1) - beta2
+        for x, g, tab in tabs:
+            m, v = sl("m", tab), sl("v", tab)
+            m[...] = m * beta1 + g * omb1
+            v[...] = v * beta2 + (g * g) * omb2
+            x -= (lr_t * m) / (np.sqrt(v) + eps)
+    elif kind == "adagrad":
+        for x, g, tab in tabs:
+            a = sl("a", tab)
             a += g * g
-            x -= lr * g / (np.sqrt(a) + F32(eps))
-    elif state.optimizer == "sgd":
-        state.ent -= lr * ge
-        state.rel -= lr * gr
+            x -= lr * g / (np.sqrt(a) + eps)
+    elif kind == "sgd":
+        for x, g, tab in tabs:
+            x -= lr * g
+    elif kind == "momentum":      # ResourceApplyKerasMomentum
+        mom, nesterov = F32(hp.get("momentum", 0.9)), bool(hp.get("nesterov", False))
+        for x, g, tab in tabs:
+            a = sl("mom", tab)
+            a[...] = a * mom - lr * g
+            x += (a * mom - lr * g) if nesterov else a
+    elif kind in ("rmsprop", "rmsprop_mom"):
+        rho = F32(hp.get("rho", 0.9))
+        omr = F32(1.0 - float(rho))
+        for x, g, tab in tabs:
+            r = sl("rms", tab)
+            r += (g * g - r) * omr
+            if kind == "rmsprop":   # RMSprop._resource_apply_dense without momentum: epsilon outside the root
+                x -= lr * g / (np.sqrt(r) + eps)
+            else:                   # ResourceApplyRMSProp: epsilon inside the root
+                mo = sl("mom", tab)
+                mo[...] = mo * F32(hp.get("momentum", 0.9)) + (lr * g) / np.sqrt(r + eps)
+                x -= mo
+    elif kind == "adadelta":      # ResourceApplyAdadelta
+        rho = F32(hp.get("rho", 0.95))
+        omr = F32(1.0 - float(rho))
+        for x, g, tab in tabs:
+            a, d = sl("acc", tab), sl("dacc", tab)
+            a[...] = a * rho + (g * g) * omr
+            u = np.sqrt(d + eps) * (F32(1.0) / np.sqrt(a + eps)) * g
+            x -= u * lr
+            d[...] = d * rho + (u * u) * omr
+    elif kind == "adamax":        # ResourceApplyAdaMax
+        lr_t = F32(float(lr) / (1.0 - float(beta1) ** t))
+        omb1 = F32(1.0 - float(beta1))
+        for x, g, tab in tabs:
+            m, u = sl("m", tab), sl("u", tab)
+            m += (g - m) * omb1
+            u[...] = np.maximum(beta2 * u, np.abs(g))
+            x -= lr_t * m / (u + eps)
     else:
         raise ValueError(state.optimizer)
 

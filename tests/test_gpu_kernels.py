@@ -281,7 +281,7 @@ def test_tiled_overflow_buckets_and_duplicates(gpu_lib, model, pos_atomic):
 
 
 @pytest.mark.parametrize("pos_atomic", [False, True])
-@pytest.mark.parametrize("opt", ["adam", "adagrad", "sgd"])
+@pytest.mark.parametrize("opt", ["adam", "adagrad", "sgd", "sgd+momentum", "rmsprop", "rmsprop+momentum", "adadelta", "adamax"])
 @pytest.mark.parametrize("model,reg", [("ComplEx", None), ("DistMult", (2, 1e-3)), ("RotatE", (3, 1e-2)), ("TransE", None)])
 def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg, pos_atomic):
     """Whole owner-computes steps (tables + slots updated from LDS) == oracle train_step, 3 steps."""
@@ -289,15 +289,17 @@ def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg, pos_atomic):
 
     N, R, k, B, eta = 150, 4, 12, 200, 4
     eng, ent, rel = make_engine(model, k, N, R, scale=0.5)
+    w, mk = make_optimizer(opt.split("+")[0], {"momentum": 0.7} if "+" in opt else {})
+    opt = w.name
     eng.prepare_training(opt)
-    st = O.TrainState(ent, rel, opt, 1e-2)
+    st = mk(ent, rel)
     rng = np.random.default_rng(6)
     oreg = None if reg is None else dict(p=reg[0], lam_e=reg[1], lam_r=reg[1])
     lam = reg[1] if reg else 0.0
     for t in range(1, 4):
         X = rand_triples(rng, B, N, R)
         eng.loss_acc.zero_()
-        d = _ffi.Opt(_ffi.OPTIMIZERS[opt], reg[0] if reg else 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, t)
+        d = w.to_ffi(t, reg[0] if reg else 2)
         eng.train_step_tiled(dev(X), eta, loss_desc("self_adversarial"), d, 77, t, reg_e=lam, reg_r=lam, pos_atomic=pos_atomic)
         assert float(eng.g_rel.abs().max()) == 0.0   # relation gradient consumed by the fused / trailing sweep
         assert float(eng.g_ent.abs().max()) == 0.0   # the positives' own rows were folded in and reset by the tiles
@@ -311,29 +313,46 @@ def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg, pos_atomic):
         cr = np.abs(r - st.rel) <= 1e-5 + 1e-4 * np.abs(st.rel)
         assert ce.mean() > 0.995 and cr.mean() > 0.99, (opt, model, t, ce.mean(), cr.mean())
         assert np.abs(e - st.ent).max() < 2.5e-2   # a sign flip of a ~0 gradient moves Adam by at most 2*lr
-        names = {"adam": ("m_e", "v_e"), "adagrad": ("a_e",), "sgd": ()}[opt]
-        for nme in names + tuple(n.replace("_e", "_r") for n in names):
-            assert np.allclose(eng.slots[nme].cpu().numpy(), st.slots[nme], rtol=1e-3, atol=1e-6), (nme, t)
+        for nme in st.slots:
+            # RMSprop-with-momentum's lr*g/sqrt(r + eps) is as ill-conditioned at g ~ 0 as Adam's update: bulk comparison
+            ok = np.isclose(eng.slots[nme].cpu().numpy(), st.slots[nme], rtol=1e-3, atol=1e-6)
+            assert ok.mean() > (0.99 if opt == "rmsprop_mom" and nme.startswith("mom") else 0.9999), (nme, t, ok.mean())
 
 
 # -------------------------------------------------------------------------------- optimizer (a17/a18)
-@pytest.mark.parametrize("opt", ["adam", "adagrad", "sgd"])
+OPT_SPECS = [("adam", {}), ("adagrad", {}), ("sgd", {}), ("sgd", {"momentum": 0.9}), ("sgd", {"momentum": 0.8, "nesterov": True}),
+             ("rmsprop", {}), ("rmsprop", {"momentum": 0.5, "rho": 0.8}), ("adadelta", {}), ("adamax", {}),
+             ("adam", {"beta_1": 0.8, "beta_2": 0.99, "epsilon": 1e-6})]
+
+
+def make_optimizer(name, hp, lr=1e-2):
+    """(product OptimizerWrapper, oracle TrainState factory) for one Keras optimizer spec."""
+    from ampligraph_amd.latent_features import optimizers
+
+    w = optimizers.get(name, dict(hp, learning_rate=lr))
+    return w, (lambda ent, rel: O.TrainState(ent, rel, w.name, lr, **hp))
+
+
+@pytest.mark.parametrize("name,hp", OPT_SPECS)
 @pytest.mark.parametrize("reg", [None, (2, 1e-3), (3, 1e-2)])
-def test_opt_step_parity(gpu_lib, opt, reg):
+def test_opt_step_parity(gpu_lib, name, hp, reg):
+    """amdkge_opt_step == the oracle's Keras-legacy rules for every supported optimizer (descriptor built by the product's
+    OptimizerWrapper.to_ffi, so the hyper-parameter mapping is covered), tables AND state tensors, 4 steps."""
     from ampligraph_amd import _ffi
 
     N, R, k = 123, 3, 9   # 123*9 is not a multiple of 4: exercises the scalar tail
     eng, ent, rel = make_engine("DistMult", k, N, R, scale=0.5)
-    eng.prepare_training(opt)
-    st = O.TrainState(ent, rel, opt, 1e-2)
+    w, mk = make_optimizer(name, hp)
+    eng.prepare_training(w.name)
+    st = mk(ent, rel)
     rng = np.random.default_rng(5)
-    for t in range(1, 4):
+    for t in range(1, 5):
         Ge = rng.normal(size=ent.shape) * (rng.random(size=ent.shape) < 0.3)
         Gr = rng.normal(size=rel.shape)
         eng.g_ent.copy_(dev(Ge.astype(np.float32)))
         eng.g_rel.copy_(dev(Gr.astype(np.float32)))
         eng.loss_acc.zero_()
-        d = _ffi.Opt(_ffi.OPTIMIZERS[opt], reg[0] if reg else 2, 1e-2, 0.9, 0.999, 1e-7, 0.0, t)
+        d = w.to_ffi(t, reg[0] if reg else 2)
         lam = reg[1] if reg else 0.0
         reg_loss = 0.0
         Ge32, Gr32 = Ge.astype(np.float32).astype(np.float64), Gr.astype(np.float32).astype(np.float64)
@@ -346,11 +365,19 @@ def test_opt_step_parity(gpu_lib, opt, reg):
         O.apply_optimizer(st, Ge32, Gr32)
         torch.cuda.synchronize()
         e, r = eng.get_tables()
-        assert np.abs(e - st.ent).max() <= 2e-6 * max(1.0, np.abs(st.ent).max()), (opt, t)
+        assert np.abs(e - st.ent).max() <= 2e-6 * max(1.0, np.abs(st.ent).max()), (name, t)
         assert np.abs(r - st.rel).max() <= 2e-6 * max(1.0, np.abs(st.rel).max())
         assert float(eng.g_ent.abs().max()) == 0.0 and float(eng.g_rel.abs().max()) == 0.0  # gradient reset
+        assert set(eng.slots) == set(st.slots) and len(st.slots) == 2 * len(_ffi.OPT_SLOTS[w.name])
+        for nme, ref in st.slots.items():
+            # (with a regulariser the test forms its gradient term in fp64, the kernel in fp32)
+            assert np.allclose(eng.slots[nme].cpu().numpy(), ref, rtol=2e-5 if reg else 2e-6, atol=2e-7 * np.abs(ref).max()), (name, nme, t)
         if reg:
             assert abs(float(eng.loss_acc[1]) - reg_loss) <= 1e-5 * reg_loss
+    with pytest.raises(ValueError):
+        make_optimizer("adam", {"amsgrad": True})
+    with pytest.raises(ValueError):
+        make_optimizer("nadam", {})
 
 
 # -------------------------------------------------------------------------------- ranks (a9-a11)

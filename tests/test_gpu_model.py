@@ -42,7 +42,8 @@ def oracle_replay(model, X, k, eta, loss, opt, lr, batch_size, epochs, seed, reg
 
 @pytest.mark.parametrize("model,loss,opt", [("ComplEx", "self_adversarial", "adam"), ("TransE", "pairwise", "sgd"),
                                             ("DistMult", "multiclass_nll", "adagrad"), ("RotatE", "nll", "adam"),
-                                            ("HolE", "absolute_margin", "adam")])
+                                            ("HolE", "absolute_margin", "adam"), ("DistMult", "nll", "rmsprop"),
+                                            ("ComplEx", "self_adversarial", "adamax"), ("TransE", "pairwise", "adadelta")])
 def test_fit_matches_oracle(gpu_lib, model, loss, opt):
     from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel
 
