@@ -59,9 +59,14 @@ class ScoringModelBase:
         return ini
 
     def _get_optimizer(self):
+        """compat/models.py:153-178.  The 1.x name "momentum" (docstring :75-83; Keras has no optimizer of that name)
+        is SGD with momentum (default 0.9)."""
         prm = dict(self.optimizer_params)
         lr = prm.pop("lr", 0.001)
-        return optimizers.get(self.optimizer, dict(prm, learning_rate=lr))
+        name = self.optimizer
+        if name == "momentum":
+            name, prm = "sgd", dict(prm, momentum=prm.get("momentum", 0.9))
+        return optimizers.get(name, dict(prm, learning_rate=lr))
 
     # -- 1.x surface -----------------------------------------------------------------------------------------------
     def is_fit(self):
