@@ -98,3 +98,15 @@ def test_row_source_equals_whole_table_draw():
     assert np.array_equal(RowSource(arr, (6, 10), 0, 0).rows(2, 5), arr[2:5])
     with pytest.raises(ValueError):
         RowSource(arr, (7, 10), 0, 0)
+
+
+def test_load_from_csv(tmp_path):
+    """datasets.load_from_csv: strings, duplicates dropped in first-seen order, optional reciprocal relations
+    (reference datasets.py:142-170,173-240)."""
+    from ampligraph_amd.datasets import load_from_csv
+
+    (tmp_path / "d.csv").write_text("a,y,b\nb,y,a\na,y,b\na,z,c\n")
+    X = load_from_csv(str(tmp_path), "d.csv", sep=",")
+    assert X.tolist() == [["a", "y", "b"], ["b", "y", "a"], ["a", "z", "c"]]
+    Xr = load_from_csv(str(tmp_path), "d.csv", sep=",", add_reciprocal_rels=True)
+    assert Xr.shape == (6, 3) and Xr[3].tolist() == ["b", "y_reciprocal", "a"] and Xr[5].tolist() == ["c", "z_reciprocal", "a"]
