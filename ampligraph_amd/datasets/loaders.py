@@ -14,10 +14,8 @@ def _drop_duplicate_rows(X):
 
 
 def add_reciprocal_relations(X):
-    X = np.asarray(X)
-    rec = X.copy()
-    rec[:, 0], rec[:, 2] = X[:, 2], X[:, 0]
-    rec[:, 1] = np.char.add(X[:, 1].astype(str), "_reciprocal")
+    X = np.asarray(X).astype(str)
+    rec = np.stack([X[:, 2], np.char.add(X[:, 1], "_reciprocal"), X[:, 0]], 1)   # numpy widens the string dtype
     return np.concatenate([X.astype(rec.dtype), rec], 0)
 
 
