@@ -312,7 +312,16 @@ class ScoringBasedEmbeddingModel:
                 fp = self.focusE_params
                 if fp["stop_epoch"] > 0:
                     fp["structural_wt"] = max(1.0 - epoch / fp["stop_epoch"], 0.001)
-            for step in range(steps):
+            first = 0
+            if (epoch == int(initial_epoch) and getattr(loop, "auto_tune", False) and getattr(loop, "world", 1) > 1
+                    and focus_dev is None and steps >= 24):
+                # AMDKGE_DP_MERGE=auto: the first steps of this epoch are run under each gradient-merge schedule and the
+                # fastest is kept (StepLoop.tune_merge; every schedule computes the same update).  The epoch's reported
+                # loss then covers the remaining steps only.
+                base = epoch * steps
+                first = loop.tune_merge(lambda s_: train[(s_ - base) * batch_size:(s_ - base + 1) * batch_size], base)
+                loop.auto_tune = False
+            for step in range(first, steps):
                 b0 = step * batch_size
                 if focus_dev is not None:
                     focus = (focus_dev[b0:b0 + batch_size], self.focusE_params["structural_wt"], self.focusE_params["non_linearity"])

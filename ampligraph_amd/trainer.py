@@ -64,7 +64,8 @@ class StepLoop:
                       m / v effectively sharded), all_to_all of the updated parameter slices (every rank's slice to every
                       peer).  Same bytes on the wire as an all-reduce, but point-to-point on every link at once instead of
                       a ring that is bound by one link.
-          "allreduce": one all-reduce of the flat gradient, every rank sweeps everything (AMDKGE_DP_MERGE=allreduce)."""
+          "allreduce": one all-reduce of the flat gradient, every rank sweeps everything (AMDKGE_DP_MERGE=allreduce);
+          "auto"     : measured on the first steps (tune_merge; AMDKGE_DP_MERGE=auto)."""
         self.engine = engine
         self.eta = int(eta)
         self.loss_ffi = loss.to_ffi()
@@ -77,8 +78,12 @@ class StepLoop:
         self.rank = dist.get_rank() if dist is not None else 0
         if merge is None:
             merge = os.environ.get("AMDKGE_DP_MERGE", "sharded")
+        # "auto": start with the sharded merge and let the caller run tune_merge() on the first steps (fit() does)
+        self.auto_tune = merge == "auto"
+        if self.auto_tune:
+            merge = "sharded"
         if merge not in ("sharded", "allreduce"):
-            raise ValueError("merge must be 'sharded' or 'allreduce'")
+            raise ValueError("merge must be 'sharded', 'allreduce' or 'auto'")
         self.merge = merge if hasattr(engine, "opt_step_flat") else "allreduce"
         self.merge_report = None
         self.collectives = os.environ.get("AMDKGE_DP_GATHER", "alltoall")   # sharded merge: "alltoall" | "native"

@@ -742,3 +742,36 @@ def test_row_sharded_focuse_calibrate_subset_checkpoint(gpu_lib, tmp_path):
         assert np.allclose(hist, h1.history["loss"][2:], rtol=2e-4)
         assert (np.abs(emb - e1) <= 1e-5 + 1e-3 * np.abs(e1)).mean() > 0.995
 
+
+
+def test_dp_fit_with_measured_merge_schedule(gpu_lib, monkeypatch):
+    """AMDKGE_DP_MERGE=auto: fit() spends the first steps of the first epoch on StepLoop.tune_merge (every candidate schedule
+    computes the same update), keeps one, and ends with the tables of the single-GPU fit."""
+    from threaded_dist import ThreadedWorld
+
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers
+
+    X = toy_graph(n=1600, N=60, R=4)
+    k, eta, bs, epochs = 8, 3, 64, 2   # 25 steps per epoch: enough for 3 candidates x (1 + 4) steps
+
+    def make(dist=None):
+        m = ScoringBasedEmbeddingModel(eta=eta, k=k, scoring_type="ComplEx", seed=2)
+        m._dist_override = dist
+        m.compile(optimizer=optimizers.get("adam", {"learning_rate": 1e-2}), loss="nll")
+        m.fit(X, batch_size=bs, epochs=epochs, verbose=False)
+        return m
+
+    m1 = make()
+    e1, r1 = m1._engine.get_tables()
+    monkeypatch.setenv("AMDKGE_DP_MERGE", "auto")
+
+    def body(dist):
+        m = make(dist)
+        assert m._loop.merge_report is not None and len(m._loop.merge_report) == 3 and not m._loop.auto_tune
+        ed, rd = m._engine.get_tables()
+        assert np.mean(np.abs(ed - e1) <= 1e-5 + 1e-3 * np.abs(e1)) > 0.995 and np.abs(rd - r1).max() < 2.5e-2
+        assert np.allclose(m.history.history["loss"][1], m1.history.history["loss"][1], rtol=2e-4)   # second epoch: all steps
+        return float(np.abs(ed).sum())
+
+    a, b = ThreadedWorld(2).run(body)
+    assert a == b
