@@ -92,7 +92,7 @@ class OracleEngine:
         self.state.ent = self._p[:ne].reshape(self.ent0.shape)          # numpy views: the oracle updates in place
         self.state.rel = self._p[self._off:self._off + nr].reshape(self.rel0.shape)
         self._slot_flat = {}
-        for key in sorted({k[0] for k in self.state.slots}):
+        for key in sorted({k.rsplit("_", 1)[0] for k in self.state.slots}):
             f = flat_of(self.state.slots[key + "_e"], self.state.slots[key + "_r"], fill=0.1 if key == "a" else 0.0)
             self._slot_flat[key] = f
             self.state.slots[key + "_e"] = f[:ne].reshape(self.ent0.shape)
@@ -179,6 +179,14 @@ class OracleEngine:
                     xx[rows:] = 0.0   # scratch rows carry no regulariser
                 self.loss_acc[slot] += lam * float((np.abs(xx) ** opt.reg_p).sum())
                 G += lam * opt.reg_p * np.abs(xx) ** (opt.reg_p - 1) * np.sign(xx)
-        O.apply_optimizer(self.state, Ge, Gr, opt.beta1, opt.beta2, opt.epsilon)
+        kind = self.state.optimizer   # the descriptor's beta1 / beta2 carry other hyper-parameters for the non-Adam rules
+        if kind in ("adam", "adamax", "adagrad", "sgd"):
+            O.apply_optimizer(self.state, Ge, Gr, opt.beta1, opt.beta2, opt.epsilon)
+        else:
+            self.state.hp = {"momentum": {"momentum": opt.beta1, "nesterov": opt.beta2 != 0.0},
+                             "rmsprop": {"rho": opt.beta1}, "rmsprop_mom": {"rho": opt.beta1, "momentum": opt.beta2},
+                             "adadelta": {"rho": opt.beta1}}[kind]
+            self.state.hp["epsilon"] = opt.epsilon
+            O.apply_optimizer(self.state, Ge, Gr)
         self.g_ent.zero_()
         self.g_rel.zero_()

@@ -31,7 +31,7 @@ def _problem():
     return ent, rel, X, k
 
 
-def _run(world, rank, port, out, tiled=False, flat=False):
+def _run(world, rank, port, out, tiled=False, flat=False, opt=("adam", {})):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_backend import OracleEngine
@@ -45,7 +45,7 @@ def _run(world, rank, port, out, tiled=False, flat=False):
         d = dist
     ent, rel, X, k = _problem()
     eng = OracleEngine("ComplEx", k, ent, rel, tiled=tiled, flat=flat)
-    loop = StepLoop(eng, 3, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}),
+    loop = StepLoop(eng, 3, loss_functions.get("self_adversarial"), optimizers.get(opt[0], dict(opt[1], learning_rate=1e-2)),
                     regularizers.get("LP", {"p": 2, "lambda": 1e-3}), seed=5, dist=d)
     Xt = torch.as_tensor(X)
     loop.reset_loss()
@@ -103,8 +103,20 @@ def test_two_ranks_equal_one_rank(tmp_path, tiled, flat):
     assert (calls[:, 1] == 0).all() and set(calls[:, 2]) == {37, 27} and set(calls[:, 0]) == {18, 13}
 
 
-def _run_spawn(rank, world, port, out, tiled=False, flat=False):
-    _run(world, rank, port, out, tiled, flat)
+def _run_spawn(rank, world, port, out, tiled=False, flat=False, opt=("adam", {})):
+    _run(world, rank, port, out, tiled, flat, opt)
+
+
+@pytest.mark.parametrize("opt", [("rmsprop", {"momentum": 0.5}), ("sgd", {"momentum": 0.9, "nesterov": True}), ("adadelta", {})])
+def test_two_ranks_equal_one_rank_other_optimizers(tmp_path, opt):
+    """The sharded-optimizer merge with the other update rules (one / two state tensors, hyper-parameters carried in the
+    descriptor's beta fields): 2 ranks == 1 rank."""
+    single, multi = str(tmp_path / "single.npz"), str(tmp_path / "multi.npz")
+    _run(1, 0, 0, single, True, True, opt)
+    mp.spawn(_run_spawn, args=(2, _free_port(), multi, True, True, opt), nprocs=2, join=True)
+    a, b = np.load(single), np.load(multi)
+    assert np.abs(a["ent"] - b["ent"]).max() < 5e-6 and np.abs(a["rel"] - b["rel"]).max() < 5e-6
+    assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5 * abs(float(a["loss"]))
 
 
 def test_three_ranks_fall_back_to_allreduce(tmp_path):
