@@ -53,6 +53,14 @@ class Opt(C.Structure):
                 ("beta2", C.c_float), ("epsilon", C.c_float), ("reg_lambda", C.c_float), ("iteration", C.c_int64)]
 
 
+class SessionConfig(C.Structure):
+    _fields_ = [("model", Model), ("loss", Loss), ("opt", Opt), ("rel_reg_lambda", C.c_float), ("eta", C.c_int32),
+                ("seed", C.c_uint64), ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+TABLES = {"ent": 0, "rel": 1, "ent_slot0": 2, "ent_slot1": 3, "rel_slot0": 4, "rel_slot1": 5}
+CORRUPT_SIDES = {"s": 1, "o": 2, "s,o": 3, "s+o": 4}
+
 P = C.c_void_p
 I64 = C.c_int64
 I32 = C.c_int32
@@ -86,6 +94,13 @@ SIGNATURES = {
     "amdkge_rank_filter": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, P, P, P, I64, I64, P, P, P]),
     "amdkge_rank_compose": (C.c_int, [P, P, I64, I32, P, I64, P]),
     "amdkge_filter_ranges": (C.c_int, [P, P, I64, P, I64, I32, I64, I64, P, P, P]),
+    "amdkge_session_create": (C.c_int, [C.POINTER(SessionConfig), C.POINTER(P)]),
+    "amdkge_session_destroy": (None, [P]),
+    "amdkge_session_set_rows": (C.c_int, [P, I32, I64, I64, P]),
+    "amdkge_session_get_rows": (C.c_int, [P, I32, P, I64, I64, P]),
+    "amdkge_session_train_step": (C.c_int, [P, P, I64, P, C.POINTER(C.c_double)]),
+    "amdkge_session_score": (C.c_int, [P, P, I64, P]),
+    "amdkge_session_rank": (C.c_int, [P, P, I64, P, P, P, P, P, I64, I32, I32, P]),
 }
 
 _lib = None

@@ -1,0 +1,291 @@
+// Session layer of the C ABI (include/amdkge.h): an opaque handle that owns the HBM-resident state of one model and
+// drives the device-pointer entry points with HOST buffers in and out, so that a host without torch (the reference's
+// numpy-level Python through ctypes) can train, score and rank.  Pure composition: every computation is one of the entry
+// points of the other translation units.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kge_opt.h"
+
+using namespace kge;
+
+struct amdkge_session {
+    amdkge_session_config cfg;
+    int K = 0;
+    hipStream_t st = nullptr;
+    float* tab[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // AMDKGE_TABLE_* order
+    float* g_ent = nullptr;
+    float* g_rel = nullptr;
+    double* acc = nullptr;          // [data loss, regulariser loss]
+    void* twork = nullptr;          // owner-computes workspace (zero-filled when (re)allocated)
+    int64_t twork_bytes = 0;
+    void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // growable scratch
+    int64_t buf_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t step = 0;
+    int64_t iteration = 0;
+};
+
+namespace {
+
+#define KGE_HIP(call, what) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return set_error_hip(e_, what); } while (0)
+#define KGE_RC(call) do { const int rc_ = (call); if (rc_ != AMDKGE_OK) return rc_; } while (0)
+
+int64_t table_rows(const amdkge_session* s, int t) { return (t == AMDKGE_TABLE_ENT || t == AMDKGE_TABLE_ENT_SLOT0 || t == AMDKGE_TABLE_ENT_SLOT1) ? s->cfg.model.n_ents : s->cfg.model.n_rels; }
+
+// scratch slot `i` with at least `bytes` bytes (contents undefined)
+int scratch(amdkge_session* s, int i, int64_t bytes, void** out) {
+    if (bytes > s->buf_bytes[i]) {
+        if (s->buf[i]) KGE_HIP(hipFree(s->buf[i]), "hipFree(scratch)");
+        s->buf[i] = nullptr; s->buf_bytes[i] = 0;
+        KGE_HIP(hipMalloc(&s->buf[i], (size_t)bytes), "hipMalloc(scratch)");
+        s->buf_bytes[i] = bytes;
+    }
+    *out = s->buf[i];
+    return AMDKGE_OK;
+}
+
+int upload(amdkge_session* s, int slot, const void* host, int64_t bytes, void** d) {
+    KGE_RC(scratch(s, slot, bytes > 0 ? bytes : 16, d));
+    if (bytes > 0) KGE_HIP(hipMemcpyAsync(*d, host, (size_t)bytes, hipMemcpyHostToDevice, s->st), "hipMemcpyAsync(H2D)");
+    return AMDKGE_OK;
+}
+
+__global__ void gather_rows_kernel(const float* src, const int32_t* ids, int64_t n, int K, float* dst) {
+    const int64_t r = blockIdx.x;
+    const float* row = src + (int64_t)ids[r] * K;
+    for (int c = threadIdx.x; c < K; c += blockDim.x) dst[r * K + c] = row[c];
+}
+
+}  // namespace
+
+extern "C" void amdkge_session_destroy(amdkge_session* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->cfg.device);
+    if (s->st) (void)hipStreamSynchronize(s->st);
+    for (float* p : s->tab) if (p) (void)hipFree(p);
+    if (s->g_ent) (void)hipFree(s->g_ent);
+    if (s->g_rel) (void)hipFree(s->g_rel);
+    if (s->acc) (void)hipFree(s->acc);
+    if (s->twork) (void)hipFree(s->twork);
+    for (void* p : s->buf) if (p) (void)hipFree(p);
+    if (s->st) (void)hipStreamDestroy(s->st);
+    delete s;
+}
+
+extern "C" int amdkge_session_create(const amdkge_session_config* cfg, amdkge_session** out) {
+    if (!cfg || !out) return set_error(AMDKGE_EINVAL, "session_create: NULL argument");
+    *out = nullptr;
+    KGE_RC(validate_model(&cfg->model));
+    if (cfg->loss.kind < 0 || cfg->loss.kind > AMDKGE_LOSS_MULTICLASS_NLL) return set_error(AMDKGE_EINVAL, "session_create: unknown loss kind");
+    amdkge_opt o = cfg->opt;
+    o.iteration = 1;
+    KGE_RC(validate_opt(&o));
+    if (cfg->eta < 1) return set_error(AMDKGE_EINVAL, "session_create: eta must be >= 1");
+    KGE_HIP(hipSetDevice(cfg->device), "hipSetDevice");
+    amdkge_session* s = new amdkge_session();
+    s->cfg = *cfg;
+    s->cfg.loss.d_focus_w = nullptr;
+    s->K = amdkge_internal_k(cfg->model.scoring_type, cfg->model.k);
+    const int64_t ne = cfg->model.n_ents * (int64_t)s->K, nr = cfg->model.n_rels * (int64_t)s->K;
+    const int nslots = opt_nslots(cfg->opt.kind);
+    auto fail = [&](int rc) { amdkge_session_destroy(s); return rc; };
+    hipError_t e = hipStreamCreate(&s->st);
+    if (e != hipSuccess) return fail(set_error_hip(e, "hipStreamCreate"));
+    auto alloc = [&](float** p, int64_t n, float fill) -> int {
+        hipError_t e2 = hipMalloc((void**)p, (size_t)n * sizeof(float));
+        if (e2 != hipSuccess) return set_error_hip(e2, "hipMalloc(table)");
+        uint32_t bits; memcpy(&bits, &fill, 4);
+        e2 = hipMemsetD32Async((hipDeviceptr_t)*p, (int)bits, (size_t)n, s->st);
+        return e2 == hipSuccess ? AMDKGE_OK : set_error_hip(e2, "hipMemsetD32Async");
+    };
+    // Keras legacy Adagrad starts its accumulator at 0.1; every other state tensor at 0
+    const float fill0 = cfg->opt.kind == AMDKGE_OPT_ADAGRAD ? 0.1f : 0.f;
+    int rc = alloc(&s->tab[AMDKGE_TABLE_ENT], ne, 0.f);
+    if (!rc) rc = alloc(&s->tab[AMDKGE_TABLE_REL], nr, 0.f);
+    if (!rc) rc = alloc(&s->g_ent, ne, 0.f);
+    if (!rc) rc = alloc(&s->g_rel, nr, 0.f);
+    if (!rc && nslots >= 1) rc = alloc(&s->tab[AMDKGE_TABLE_ENT_SLOT0], ne, fill0);
+    if (!rc && nslots >= 1) rc = alloc(&s->tab[AMDKGE_TABLE_REL_SLOT0], nr, fill0);
+    if (!rc && nslots == 2) rc = alloc(&s->tab[AMDKGE_TABLE_ENT_SLOT1], ne, 0.f);
+    if (!rc && nslots == 2) rc = alloc(&s->tab[AMDKGE_TABLE_REL_SLOT1], nr, 0.f);
+    if (rc) return fail(rc);
+    e = hipMalloc((void**)&s->acc, 2 * sizeof(double));
+    if (e != hipSuccess) return fail(set_error_hip(e, "hipMalloc(acc)"));
+    e = hipStreamSynchronize(s->st);
+    if (e != hipSuccess) return fail(set_error_hip(e, "hipStreamSynchronize"));
+    *out = s;
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_set_rows(amdkge_session* s, int32_t table, int64_t row0, int64_t nrows, const float* host) {
+    if (!s || table < 0 || table > 5 || !s->tab[table]) return set_error(AMDKGE_EINVAL, "session_set_rows: no such table (optimizer without that state tensor?)");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > table_rows(s, table)) return set_error(AMDKGE_EINVAL, "session_set_rows: rows outside the table");
+    if (nrows == 0) return AMDKGE_OK;
+    if (!host) return set_error(AMDKGE_EINVAL, "session_set_rows: NULL host buffer");
+    KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+    KGE_HIP(hipMemcpyAsync(s->tab[table] + row0 * s->K, host, (size_t)nrows * s->K * sizeof(float), hipMemcpyHostToDevice, s->st), "hipMemcpyAsync(H2D)");
+    KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_get_rows(amdkge_session* s, int32_t table, const int32_t* ids, int64_t row0, int64_t nrows, float* host) {
+    if (!s || table < 0 || table > 5 || !s->tab[table]) return set_error(AMDKGE_EINVAL, "session_get_rows: no such table (optimizer without that state tensor?)");
+    if (nrows < 0) return set_error(AMDKGE_EINVAL, "session_get_rows: nrows must be >= 0");
+    if (nrows == 0) return AMDKGE_OK;
+    if (!host) return set_error(AMDKGE_EINVAL, "session_get_rows: NULL host buffer");
+    KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+    const float* src;
+    if (ids) {
+        const int64_t rows = table_rows(s, table);
+        for (int64_t i = 0; i < nrows; ++i)
+            if (ids[i] < 0 || ids[i] >= rows) return set_error(AMDKGE_EINVAL, "session_get_rows: row id outside the table");
+        void *d_ids, *d_tmp;
+        KGE_RC(upload(s, 0, ids, nrows * (int64_t)sizeof(int32_t), &d_ids));
+        KGE_RC(scratch(s, 1, nrows * s->K * (int64_t)sizeof(float), &d_tmp));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nrows), dim3(256), 0, s->st, s->tab[table], (const int32_t*)d_ids, nrows, s->K, (float*)d_tmp);
+        KGE_RC(check_launch("gather_rows"));
+        src = (const float*)d_tmp;
+    } else {
+        if (row0 < 0 || row0 + nrows > table_rows(s, table)) return set_error(AMDKGE_EINVAL, "session_get_rows: rows outside the table");
+        src = s->tab[table] + row0 * s->K;
+    }
+    KGE_HIP(hipMemcpyAsync(host, src, (size_t)nrows * s->K * sizeof(float), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
+    KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_train_step(amdkge_session* s, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out) {
+    if (!s || B < 0) return set_error(AMDKGE_EINVAL, "session_train_step: bad arguments");
+    if (loss_out) *loss_out = 0.0;
+    if (B == 0) return AMDKGE_OK;   // (the reference never produces an empty batch; nothing happens, no step is counted)
+    if (!triples) return set_error(AMDKGE_EINVAL, "session_train_step: NULL triples");
+    if (focus_w && !s->cfg.loss.focus_nonlinearity) return set_error(AMDKGE_EINVAL, "session_train_step: FocusE weights given but the session's loss has focus_nonlinearity == 0");
+    KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+    const amdkge_model* m = &s->cfg.model;
+    void *d_tri, *d_fw = nullptr;
+    KGE_RC(upload(s, 0, triples, B * 3 * (int64_t)sizeof(int32_t), &d_tri));
+    amdkge_loss loss = s->cfg.loss;
+    if (focus_w) { KGE_RC(upload(s, 1, focus_w, B * (int64_t)sizeof(float), &d_fw)); loss.d_focus_w = (const float*)d_fw; }
+    else { loss.focus_nonlinearity = AMDKGE_FOCUS_OFF; loss.d_focus_w = nullptr; }
+    amdkge_opt opt = s->cfg.opt;
+    opt.iteration = s->iteration + 1;
+    KGE_HIP(hipMemsetAsync(s->acc, 0, 2 * sizeof(double), s->st), "hipMemsetAsync");
+    const int64_t need = amdkge_train_tiled_workspace_bytes(m, B, s->cfg.eta);
+    if (need > 0) {   // owner-computes kernel pair: the complete step
+        if (need > s->twork_bytes) {
+            if (s->twork) KGE_HIP(hipFree(s->twork), "hipFree(twork)");
+            s->twork = nullptr; s->twork_bytes = 0;
+            KGE_HIP(hipMalloc(&s->twork, (size_t)need), "hipMalloc(twork)");
+            KGE_HIP(hipMemsetAsync(s->twork, 0, (size_t)need, s->st), "hipMemsetAsync(twork)");
+            s->twork_bytes = need;
+        }
+        const int rc = amdkge_train_step_tiled(m, &loss, &opt, s->tab[0], s->tab[1], s->tab[2], s->tab[3], s->tab[4], s->tab[5],
+                                               s->cfg.rel_reg_lambda, (const int32_t*)d_tri, B, s->cfg.eta, 0, m->n_ents, s->cfg.seed,
+                                               s->step, 0, 0, nullptr, s->g_ent, s->g_rel, 1, s->cfg.flags, s->acc, s->acc + 1,
+                                               nullptr, nullptr, s->twork, s->st);
+        if (rc != AMDKGE_OK) {   // bookkeeping may be dirty after a failed launch: start from a fresh zeroed buffer next time
+            (void)hipFree(s->twork); s->twork = nullptr; s->twork_bytes = 0;
+            return rc;
+        }
+    } else {          // shapes the pair does not cover: atomic forward/backward + dense sweeps
+        KGE_RC(amdkge_train_fwdbwd(m, &loss, s->tab[0], s->tab[1], (const int32_t*)d_tri, B, s->cfg.eta, 0, m->n_ents, s->cfg.seed,
+                                   s->step, 0, 0, nullptr, s->g_ent, s->g_rel, s->acc, nullptr, nullptr, s->st));
+        KGE_RC(amdkge_opt_step(&opt, s->tab[0], s->g_ent, s->tab[2], s->tab[3], m->n_ents * (int64_t)s->K, s->acc + 1, s->st));
+        amdkge_opt orel = opt;
+        orel.reg_lambda = s->cfg.rel_reg_lambda;
+        KGE_RC(amdkge_opt_step(&orel, s->tab[1], s->g_rel, s->tab[4], s->tab[5], m->n_rels * (int64_t)s->K, s->acc + 1, s->st));
+    }
+    double h[2] = {0.0, 0.0};
+    KGE_HIP(hipMemcpyAsync(h, s->acc, sizeof(h), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
+    KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+    s->step += 1;
+    s->iteration += 1;
+    if (loss_out) *loss_out = h[0] + h[1];
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_score(amdkge_session* s, const int32_t* triples, int64_t n, float* scores_out) {
+    if (!s || n < 0) return set_error(AMDKGE_EINVAL, "session_score: bad arguments");
+    if (n == 0) return AMDKGE_OK;
+    if (!triples || !scores_out) return set_error(AMDKGE_EINVAL, "session_score: NULL buffer");
+    KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+    void *d_tri, *d_sc;
+    KGE_RC(upload(s, 0, triples, n * 3 * (int64_t)sizeof(int32_t), &d_tri));
+    KGE_RC(scratch(s, 1, n * (int64_t)sizeof(float), &d_sc));
+    KGE_RC(amdkge_score(&s->cfg.model, s->tab[0], s->tab[1], (const int32_t*)d_tri, n, (float*)d_sc, s->st));
+    KGE_HIP(hipMemcpyAsync(scores_out, d_sc, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
+    KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_rank(amdkge_session* s, const int32_t* triples, int64_t n, const int64_t* fs_off, const int32_t* fs_ids,
+                                   const int64_t* fo_off, const int32_t* fo_ids, const int32_t* ent_subset, int64_t n_subset,
+                                   int32_t corrupt_side, int32_t strategy, int32_t* ranks_out) {
+    if (!s || n < 0 || corrupt_side < AMDKGE_CORRUPT_S || corrupt_side > AMDKGE_CORRUPT_S_PLUS_O)
+        return set_error(AMDKGE_EINVAL, "session_rank: bad arguments (corrupt_side must be AMDKGE_CORRUPT_*)");
+    if (strategy < 0 || strategy > 2) return set_error(AMDKGE_EINVAL, "session_rank: unknown ranking strategy");
+    if (n == 0) return AMDKGE_OK;
+    if (!triples || !ranks_out) return set_error(AMDKGE_EINVAL, "session_rank: NULL buffer");
+    if ((fs_off && !fs_ids && fs_off[n] > 0) || (fo_off && !fo_ids && fo_off[n] > 0)) return set_error(AMDKGE_EINVAL, "session_rank: filter offsets without ids");
+    if (n_subset < 0 || (n_subset > 0 && !ent_subset)) return set_error(AMDKGE_EINVAL, "session_rank: bad entities subset");
+    KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+    const amdkge_model* m = &s->cfg.model;
+    void *d_tri, *d_work, *d_counts, *d_sub, *d_ranks, *d_off = nullptr, *d_ids = nullptr, *d_sel = nullptr;
+    KGE_RC(upload(s, 0, triples, n * 3 * (int64_t)sizeof(int32_t), &d_tri));
+    KGE_RC(scratch(s, 1, amdkge_rank_workspace_bytes(m, n), &d_work));
+    KGE_RC(scratch(s, 2, n * 3 * (int64_t)sizeof(int32_t), &d_counts));   // counts [n,2] + sub [n]
+    d_sub = (int32_t*)d_counts + 2 * n;
+    KGE_RC(scratch(s, 3, n * 2 * (int64_t)sizeof(int32_t), &d_ranks));
+    const int32_t* d_ent_ids = nullptr;
+    const int32_t* d_subset_pos = nullptr;
+    int64_t ent_hi = m->n_ents;
+    if (n_subset > 0) {   // entities_subset: candidate list + id -> position table (last wins, ScoringBasedEmbeddingModel.py:1639-1643)
+        std::vector<int32_t> pos((size_t)m->n_ents, -1);
+        for (int64_t i = 0; i < n_subset; ++i) {
+            if (ent_subset[i] < 0 || ent_subset[i] >= m->n_ents) return set_error(AMDKGE_EINVAL, "session_rank: subset id outside the entity table");
+            pos[(size_t)ent_subset[i]] = (int32_t)i;
+        }
+        KGE_RC(scratch(s, 6, (n_subset + m->n_ents) * (int64_t)sizeof(int32_t), &d_sel));
+        KGE_HIP(hipMemcpyAsync(d_sel, ent_subset, (size_t)n_subset * sizeof(int32_t), hipMemcpyHostToDevice, s->st), "hipMemcpyAsync(H2D)");
+        KGE_HIP(hipMemcpyAsync((int32_t*)d_sel + n_subset, pos.data(), (size_t)m->n_ents * sizeof(int32_t), hipMemcpyHostToDevice, s->st), "hipMemcpyAsync(H2D)");
+        KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");   // `pos` leaves scope below
+        d_ent_ids = (const int32_t*)d_sel;
+        d_subset_pos = (const int32_t*)d_sel + n_subset;
+        ent_hi = n_subset;
+    }
+    const bool two_cols = corrupt_side == AMDKGE_CORRUPT_S_O;
+    int col = 0;
+    for (int side = AMDKGE_SIDE_S; side <= AMDKGE_SIDE_O; ++side) {
+        const bool want = (side == AMDKGE_SIDE_S) ? (corrupt_side != AMDKGE_CORRUPT_O) : (corrupt_side != AMDKGE_CORRUPT_S);
+        if (!want) continue;
+        const int64_t* off = (side == AMDKGE_SIDE_S) ? fs_off : fo_off;
+        const int32_t* ids = (side == AMDKGE_SIDE_S) ? fs_ids : fo_ids;
+        KGE_HIP(hipMemsetAsync(d_counts, 0, (size_t)n * 3 * sizeof(int32_t), s->st), "hipMemsetAsync");
+        KGE_RC(amdkge_rank_counts(m, s->tab[0], s->tab[1], (const int32_t*)d_tri, n, side, d_ent_ids, 0, ent_hi, (int32_t*)d_counts, d_work, s->st));
+        const int32_t* sub = nullptr;
+        if (off) {
+            if (off[0] < 0) return set_error(AMDKGE_EINVAL, "session_rank: negative filter offset");
+            for (int64_t i = 0; i < n; ++i)
+                if (off[i + 1] < off[i]) return set_error(AMDKGE_EINVAL, "session_rank: filter offsets must be non-decreasing");
+            KGE_RC(upload(s, 4, off, (n + 1) * (int64_t)sizeof(int64_t), &d_off));
+            KGE_RC(upload(s, 5, ids, off[n] * (int64_t)sizeof(int32_t), &d_ids));
+            KGE_RC(amdkge_rank_filter(m, s->tab[0], s->tab[1], (const int32_t*)d_tri, n, side, (const int64_t*)d_off, (const int64_t*)d_off + 1,
+                                      (const int32_t*)d_ids, d_subset_pos, 0, ent_hi, (int32_t*)d_sub, d_work, s->st));
+            sub = (const int32_t*)d_sub;
+        }
+        KGE_RC(amdkge_rank_compose((const int32_t*)d_counts, sub, n, strategy, (int32_t*)d_ranks + (two_cols ? col : col * n), two_cols ? 2 : 1, s->st));
+        ++col;
+    }
+    if (corrupt_side == AMDKGE_CORRUPT_S_PLUS_O) {   // the two 0-based sides are summed, then +1 (:1459-1463,1684)
+        std::vector<int32_t> h((size_t)2 * n);
+        KGE_HIP(hipMemcpyAsync(h.data(), d_ranks, (size_t)2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
+        KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+        for (int64_t i = 0; i < n; ++i) ranks_out[i] = h[(size_t)i] + h[(size_t)(n + i)] - 1;
+        return AMDKGE_OK;
+    }
+    KGE_HIP(hipMemcpyAsync(ranks_out, d_ranks, (size_t)n * (two_cols ? 2 : 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
+    KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+    return AMDKGE_OK;
+}

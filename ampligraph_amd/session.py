@@ -1,0 +1,102 @@
+"""numpy-in / numpy-out driver of the library's session layer (include/amdkge.h, amdkge_session_*): the whole model lives
+behind one opaque handle inside libamdkge (tables, optimizer state, scratch, stream); this class only marshals numpy
+arrays.  It is what a host WITHOUT torch would write against the C ABI (option B) -- the drop-in class
+ampligraph_amd.latent_features.ScoringBasedEmbeddingModel keeps its device-resident path through engine.KgeEngine.
+
+    s = Session("ComplEx", k=200, n_ents=N, n_rels=R, eta=20, loss=loss_functions.get("self_adversarial"),
+                optimizer=optimizers.get("adam"), seed=0)
+    s.set_rows("ent", ent0); s.set_rows("rel", rel0)
+    loss = s.train_step(triples_int32)          # one batch of ScoringBasedEmbeddingModel.train_step (:370-429)
+    scores = s.score(triples_int32)             # predict (:1694-1734)
+    ranks = s.rank(test, filters_s=(off, ids), filters_o=(off, ids), corrupt_side="s,o")   # evaluate (:1516-1692)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
+
+
+class Session:
+    def __init__(self, scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer=None, rel_regularizer=None, seed=0,
+                 device=0, pos_atomic=False, focus_nonlinearity=None):
+        self.lib = _ffi.lib()
+        self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], int(k)))
+        self.n_ents, self.n_rels = int(n_ents), int(n_rels)
+        cfg = _ffi.SessionConfig()
+        cfg.model = _ffi.Model(_ffi.SCORING_TYPES[scoring_type], int(k), self.n_ents, self.n_rels, self.n_rels, 0)
+        cfg.loss = loss.to_ffi()
+        if focus_nonlinearity is not None:
+            cfg.loss.focus_nonlinearity = _ffi.FOCUS_NONLINEARITY[focus_nonlinearity]
+        cfg.opt = optimizer.to_ffi(1, regularizer.p if regularizer is not None else 2)
+        cfg.opt.reg_lambda = regularizer.lam if regularizer is not None else 0.0
+        rr = rel_regularizer if rel_regularizer is not None else regularizer
+        cfg.rel_reg_lambda = rr.lam if rr is not None else 0.0
+        cfg.eta, cfg.seed, cfg.device, cfg.flags = int(eta), int(seed), int(device), 1 if pos_atomic else 0
+        self._h = C.c_void_p()
+        check(self.lib.amdkge_session_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.amdkge_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_rows(self, table, values, row0=0):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        if v.ndim != 2 or v.shape[1] != self.K:
+            raise ValueError(f"rows must have {self.K} floats")
+        check(self.lib.amdkge_session_set_rows(self._h, _ffi.TABLES[table], int(row0), int(v.shape[0]), _p(v)))
+
+    def get_rows(self, table, ids=None, row0=0, nrows=None):
+        if ids is not None:
+            ids = _i32(ids)
+            out = np.empty((ids.shape[0], self.K), dtype=np.float32)
+            check(self.lib.amdkge_session_get_rows(self._h, _ffi.TABLES[table], _p(ids), 0, int(ids.shape[0]), _p(out)))
+            return out
+        if nrows is None:
+            nrows = (self.n_ents if table.startswith("ent") else self.n_rels) - int(row0)
+        out = np.empty((int(nrows), self.K), dtype=np.float32)
+        check(self.lib.amdkge_session_get_rows(self._h, _ffi.TABLES[table], None, int(row0), int(nrows), _p(out)))
+        return out
+
+    def train_step(self, triples, focus_w=None):
+        t = _i32(triples)
+        fw = np.ascontiguousarray(focus_w, dtype=np.float32) if focus_w is not None else None
+        loss = C.c_double(0.0)
+        check(self.lib.amdkge_session_train_step(self._h, _p(t), int(t.shape[0]), _p(fw), C.byref(loss)))
+        return float(loss.value)
+
+    def score(self, triples):
+        t = _i32(triples)
+        out = np.empty(t.shape[0], dtype=np.float32)
+        check(self.lib.amdkge_session_score(self._h, _p(t), int(t.shape[0]), _p(out)))
+        return out
+
+    def rank(self, triples, filters_s=None, filters_o=None, entities_subset=None, corrupt_side="s,o", ranking_strategy="worst"):
+        """filters_*: None or (offsets int64 [n+1], ids int32) CSR over the test triples (FilterIndex ranges work after
+        np.concatenate; see datasets/filters.py).  Returns int32 (n, 1|2) like evaluate()."""
+        t = _i32(triples)
+        n = int(t.shape[0])
+        fs = fo = (None, None)
+        if filters_s is not None:
+            fs = (np.ascontiguousarray(filters_s[0], dtype=np.int64), _i32(filters_s[1]))
+        if filters_o is not None:
+            fo = (np.ascontiguousarray(filters_o[0], dtype=np.int64), _i32(filters_o[1]))
+        sub = _i32(entities_subset) if entities_subset is not None and len(entities_subset) else None
+        cols = 2 if corrupt_side == "s,o" else 1
+        out = np.empty((n, cols), dtype=np.int32)
+        check(self.lib.amdkge_session_rank(self._h, _p(t), n, _p(fs[0]), _p(fs[1]), _p(fo[0]), _p(fo[1]), _p(sub),
+                                           int(sub.shape[0]) if sub is not None else 0, _ffi.CORRUPT_SIDES[corrupt_side],
+                                           _ffi.RANK_STRATEGY[ranking_strategy], _p(out)))
+        return out

@@ -229,6 +229,54 @@ int amdkge_filter_ranges(const int64_t* d_keys, const int64_t* d_start, int64_t 
 int amdkge_rank_compose(const int32_t* d_counts, const int32_t* d_sub, int64_t n, int32_t strategy,
                         int32_t* d_ranks, int64_t rank_stride, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Session layer: HOST pointers in, HOST pointers out.  One opaque handle owns the HBM-resident state of a model (both
+ * tables, their gradient buffers, the optimizer state, every scratch buffer, one HIP stream) and drives the entry points
+ * above, so a host without torch -- the reference's own numpy-level Python, through ctypes -- can train, score and rank:
+ *   amdkge_session_create      <-> ScoringBasedEmbeddingModel.__init__ + compile + build (ScoringBasedEmbeddingModel.py:100-187,1145-1216)
+ *   amdkge_session_set/get_rows<-> EmbeddingLookupLayer weights, get_embeddings (:2214-2277), save/load_weights (:1046-1143)
+ *   amdkge_session_train_step  <-> one train_step of fit() on one batch (:370-429)
+ *   amdkge_session_score       <-> predict (:1694-1734)
+ *   amdkge_session_rank        <-> evaluate: make_test_function + get_ranks (:1387-1465,1684; AbstractScoringLayer.py:156-422)
+ * Calls are synchronous (results are in the host buffers on return); a handle is used by one host thread at a time; the
+ * caller owns every host pointer, the library owns all device memory.  Errors: return codes + amdkge_last_error(). */
+typedef struct amdkge_session amdkge_session;
+
+typedef struct amdkge_session_config {
+    amdkge_model model;
+    amdkge_loss loss;          /* d_focus_w is ignored here (FocusE weights are passed per step) */
+    amdkge_opt opt;            /* iteration is ignored (the session counts); reg_lambda = lambda of the ENTITY table */
+    float rel_reg_lambda;      /* lambda of the relation table (same p as the entity table) */
+    int32_t eta;               /* corruptions per positive */
+    uint64_t seed;             /* negatives: Philox key; step counter = number of train steps done so far */
+    int32_t device;            /* HIP device ordinal */
+    int32_t flags;             /* AMDKGE_TILED_POS_ATOMIC for skewed graphs, else 0 */
+} amdkge_session_config;
+
+enum { AMDKGE_TABLE_ENT = 0, AMDKGE_TABLE_REL = 1, AMDKGE_TABLE_ENT_SLOT0 = 2, AMDKGE_TABLE_ENT_SLOT1 = 3,
+       AMDKGE_TABLE_REL_SLOT0 = 4, AMDKGE_TABLE_REL_SLOT1 = 5 };
+enum { AMDKGE_CORRUPT_S = 1, AMDKGE_CORRUPT_O = 2, AMDKGE_CORRUPT_S_O = 3 /* "s,o": two columns */,
+       AMDKGE_CORRUPT_S_PLUS_O = 4 /* "s+o": one column, ScoringBasedEmbeddingModel.py:1459-1463 */ };
+
+/* Tables start at zero (optimizer state at the Keras initial values); fill them with amdkge_session_set_rows. */
+int amdkge_session_create(const amdkge_session_config* cfg, amdkge_session** out);
+void amdkge_session_destroy(amdkge_session* s);
+/* rows [row0, row0 + nrows) of a table <- host fp32 [nrows, internal_k] */
+int amdkge_session_set_rows(amdkge_session* s, int32_t table, int64_t row0, int64_t nrows, const float* host);
+/* host fp32 [nrows, internal_k] <- rows ids[0..nrows) (ids != NULL) or rows [row0, row0 + nrows) */
+int amdkge_session_get_rows(amdkge_session* s, int32_t table, const int32_t* ids, int64_t row0, int64_t nrows, float* host);
+/* One training step on B positives (host int32 [B,3]); focus_w: NULL or host fp32 [B] (FocusE, needs
+ * cfg.loss.focus_nonlinearity); *loss_out (may be NULL) = data loss + regulariser terms of this batch. */
+int amdkge_session_train_step(amdkge_session* s, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out);
+int amdkge_session_score(amdkge_session* s, const int32_t* triples, int64_t n, float* scores_out);
+/* Ranks of n test triples.  Filters: CSR over the test triples, fs_off / fo_off host int64 [n + 1] into fs_ids / fo_ids
+ * (true subjects / objects of each triple; NULL offsets = unfiltered side).  ent_subset: NULL or n_subset entity ids
+ * (entities_subset).  ranks_out: host int32 [n, 2] for AMDKGE_CORRUPT_S_O, else [n]. */
+int amdkge_session_rank(amdkge_session* s, const int32_t* triples, int64_t n,
+                        const int64_t* fs_off, const int32_t* fs_ids, const int64_t* fo_off, const int32_t* fo_ids,
+                        const int32_t* ent_subset, int64_t n_subset, int32_t corrupt_side, int32_t strategy,
+                        int32_t* ranks_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,14 @@ def test_abi_argument_validation_without_gpu():
     assert lib.amdkge_rank_compose(None, None, 3, 7, None, 1, None) == -1                # unknown strategy
     assert lib.amdkge_filter_ranges(None, None, 0, None, 5, 3, 10, 2, None, None, None) == -1   # bad side
     assert lib.amdkge_filter_ranges(None, None, 0, None, 0, 1, 10, 2, None, None, None) == 0    # empty batch
+    import ctypes as C
+    assert lib.amdkge_session_create(None, None) == -1
+    bad = _ffi.SessionConfig()                                                                   # zeroed: k = 0
+    h = C.c_void_p()
+    assert lib.amdkge_session_create(C.byref(bad), C.byref(h)) == -1 and not h.value
+    assert lib.amdkge_session_train_step(None, None, 3, None, None) == -1
+    assert lib.amdkge_session_rank(None, None, 3, None, None, None, None, None, 0, 3, 0, None) == -1
+    lib.amdkge_session_destroy(None)                                                             # no-op
     o = _ffi.Opt(2, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 0)
     assert lib.amdkge_opt_step(ctypes.byref(o), None, None, None, None, 0, None, None) == -1   # iteration is 1-based
     o = _ffi.Opt(2, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 1)

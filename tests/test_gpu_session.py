@@ -1,0 +1,69 @@
+"""The session layer of the C ABI (amdkge_session_*, host pointers in / out, all device state behind one handle) driven
+with numpy only, against the oracle: what a host without torch gets from libamdkge."""
+import numpy as np
+import pytest
+
+from oracle import kge_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(lists):
+    off = np.zeros(len(lists) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    ids = np.concatenate(lists).astype(np.int32) if off[-1] else np.zeros(0, dtype=np.int32)
+    return off, ids
+
+
+@pytest.mark.parametrize("model,k,opt", [("ComplEx", 8, "adam"), ("DistMult", 7, "adagrad"), ("TransE", 12, "sgd"),
+                                         ("RotatE", 8, "rmsprop")])
+def test_session_train_score_rank_against_oracle(gpu_lib, model, k, opt):
+    from ampligraph_amd.latent_features import loss_functions, optimizers, regularizers
+    from ampligraph_amd.session import Session
+
+    rng = np.random.default_rng(7)
+    N, R, B, eta, seed = 90, 4, 150, 5, 11
+    K = O.internal_k(model, k)
+    ent = (rng.normal(size=(N, K)) * 0.3).astype(np.float32)
+    rel = (rng.normal(size=(R, K)) * 0.3).astype(np.float32)
+    X = np.stack([rng.integers(0, N, 3 * B), rng.integers(0, R, 3 * B), rng.integers(0, N, 3 * B)], 1).astype(np.int32)
+    reg = regularizers.get("LP", {"p": 2, "lambda": 1e-3})
+    s = Session(model, k, N, R, eta, loss_functions.get("nll"), optimizers.get(opt, {"learning_rate": 1e-2}), reg, seed=seed)
+    if opt == "adagrad":   # Keras legacy initial accumulator
+        assert np.all(s.get_rows("ent_slot0", row0=3, nrows=2) == np.float32(0.1))
+    with pytest.raises(Exception):
+        s.get_rows("ent_slot1" if opt != "adam" else "ent_slot0", ids=[N])   # no such state tensor / row outside the table
+    s.set_rows("ent", ent)
+    s.set_rows("rel", rel)
+    assert np.array_equal(s.get_rows("ent", ids=[5, 0, 5]), ent[[5, 0, 5]]) and np.array_equal(s.get_rows("rel"), rel)
+    st = O.TrainState(ent, rel, opt, 1e-2)
+    for t in range(3):
+        xb = X[t * B:(t + 1) * B]
+        got = s.train_step(xb)
+        ref = float(O.train_step(st, model, xb, eta, "nll", seed, t, max_rel_size=R, reg=dict(p=2, lam_e=1e-3, lam_r=1e-3)))
+        assert abs(got - ref) <= 2e-5 * abs(ref), (t, got, ref)
+    e, r = s.get_rows("ent"), s.get_rows("rel")
+    assert np.mean(np.abs(e - st.ent) <= 1e-5 + 1e-3 * np.abs(st.ent)) > 0.995 and np.abs(e - st.ent).max() < 2.5e-2
+    assert np.mean(np.abs(r - st.rel) <= 1e-5 + 1e-3 * np.abs(st.rel)) > 0.99
+    # predict
+    T = X[:40]
+    ref_sc = O.compute_scores(model, *O.lookup(e, r, T.astype(np.int64)), max_rel_size=R)
+    assert np.allclose(s.score(T), ref_sc, rtol=1e-5, atol=1e-5 * np.abs(ref_sc).max())
+    assert s.score(T[:0]).shape == (0,)
+    # evaluate: filtered, both sides / s+o / one side / subset, against the oracle on the session's own tables
+    fs, fo = O.filter_sets(T, [X])
+    ref = O.evaluate_ranks(model, e, r, T, fs, fo, "s,o", "worst", max_rel_size=R)
+    got = s.rank(T, _csr(fs), _csr(fo), corrupt_side="s,o")
+    assert got.shape == (40, 2) and (np.abs(got - ref) <= 1).mean() > 0.97
+    both = s.rank(T, _csr(fs), _csr(fo), corrupt_side="s+o")
+    assert both.shape == (40, 1) and np.array_equal(both[:, 0], got[:, 0] + got[:, 1] - 1)
+    assert np.array_equal(s.rank(T, None, _csr(fo), corrupt_side="o")[:, 0], got[:, 1])
+    unf = s.rank(T, corrupt_side="s", ranking_strategy="best")
+    ref_unf = O.evaluate_ranks(model, e, r, T, None, None, "s", "best", max_rel_size=R)
+    assert unf.shape == (40, 1) and (np.abs(unf - ref_unf.reshape(40, -1)) <= 1).mean() > 0.97
+    sub = np.array([3, 17, 40, 41, 3, 88], dtype=np.int32)
+    rs = s.rank(T, _csr(fs), _csr(fo), entities_subset=sub, corrupt_side="s,o")
+    ref_sub = O.evaluate_ranks(model, e, r, T, fs, fo, "s,o", "worst", entities_subset=sub, max_rel_size=R)
+    assert rs.max() <= len(sub) + 1 and rs.min() >= 1 and (np.abs(rs - ref_sub) <= 1).mean() > 0.97
+    s.close()
+    s.close()   # idempotent
