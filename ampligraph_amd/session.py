@@ -50,7 +50,11 @@ class Session:
             self.lib.amdkge_session_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: the library handle may already be gone
+            pass
 
     def set_rows(self, table, values, row0=0):
         v = np.ascontiguousarray(values, dtype=np.float32)
