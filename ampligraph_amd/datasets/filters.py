@@ -47,13 +47,13 @@ class FilterIndex:
         t = np.asarray(triples)[:, :3].astype(np.int64)
         return self._ranges(self.sp_keys, self.sp_start, t[:, 0] * self.n_rels + t[:, 1])
 
-    def device_filter(self, device, triples_dev, side, engine=None):
+    def device_filter(self, engine, triples_dev, side):
         """(lo, hi, ids) device tensors for amdkge_rank_filter: the range lookup of subject_ranges / object_ranges done on
-        `device` (keys, starts and ids are uploaded once per index and kept), so an evaluate() call does no per-triple
-        host work.  triples_dev: (n,3) int32 device tensor; side "s" | "o"; engine: KgeEngine whose amdkge_filter_ranges
-        kernel does the search (None: torch.searchsorted, used by the CPU tests)."""
+        the engine's device by amdkge_filter_ranges (keys, starts and ids are uploaded once per index and kept), so an
+        evaluate() call does no per-triple host work.  triples_dev: (n,3) int32 device tensor; side "s" | "o"."""
         import torch
 
+        device = engine.device
         cache = self.__dict__.setdefault("_dev", {})
         if cache.get("device") != str(device):
             cache.clear()
@@ -63,23 +63,10 @@ class FilterIndex:
             for nm in ("s_ids", "o_ids"):
                 a = getattr(self, nm)
                 cache[nm] = torch.as_tensor(a if a.size else np.zeros(1, np.int32)).to(device)
-        if engine is not None:
-            keys, start, ids = (cache["po_keys"], cache["po_start"], cache["s_ids"]) if side == "s" else \
-                (cache["sp_keys"], cache["sp_start"], cache["o_ids"])
-            lo, hi = engine.filter_ranges(keys, start, triples_dev, 1 if side == "s" else 2, self.n_ents, self.n_rels)
-            return lo, hi, ids
-        t = triples_dev.to(torch.int64)
-        if side == "s":
-            keys, start, ids, q = cache["po_keys"], cache["po_start"], cache["s_ids"], t[:, 1] * self.n_ents + t[:, 2]
-        else:
-            keys, start, ids, q = cache["sp_keys"], cache["sp_start"], cache["o_ids"], t[:, 0] * self.n_rels + t[:, 1]
-        if keys.numel() == 0:
-            z = torch.zeros(q.shape[0], dtype=torch.int64, device=q.device)
-            return z, z.clone(), ids
-        pos = torch.searchsorted(keys, q).clamp_(max=keys.numel() - 1)
-        hit = keys[pos] == q
-        zero = torch.zeros((), dtype=torch.int64, device=q.device)
-        return torch.where(hit, start[pos], zero), torch.where(hit, start[pos + 1], zero), ids
+        keys, start, ids = (cache["po_keys"], cache["po_start"], cache["s_ids"]) if side == "s" else \
+            (cache["sp_keys"], cache["sp_start"], cache["o_ids"])
+        lo, hi = engine.filter_ranges(keys, start, triples_dev, 1 if side == "s" else 2, self.n_ents, self.n_rels)
+        return lo, hi, ids
 
     def as_lists(self, triples):
         """Materialise per-triple id arrays (what the reference yields as a RaggedTensor); tests only."""

@@ -446,7 +446,7 @@ class ScoringBasedEmbeddingModel:
         for c0 in range(0, n, CH):
             xs = Xd[c0:c0 + CH]
             for col, sd in enumerate(sides):
-                flt = fi.device_filter(dev, xs, sd, eng) if fi is not None else None   # range lookup on the device
+                flt = fi.device_filter(eng, xs, sd) if fi is not None else None   # range lookup on the device
                 eng.rank_side(xs, _ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, ranking_strategy, flt, ent_ids,
                               subset_pos, out=ranks[c0:c0 + CH, col], out_stride=len(sides))
         r = ranks.cpu().numpy()
@@ -501,7 +501,7 @@ class ScoringBasedEmbeddingModel:
         Xd = torch.as_tensor(Xi).to(dev)
         for c0 in range(0, n, CH):
             for col, sd in enumerate(sides):
-                flt = fi.device_filter(dev, Xd[c0:c0 + CH], sd, eng) if fi is not None else None
+                flt = fi.device_filter(eng, Xd[c0:c0 + CH], sd) if fi is not None else None
                 counts, sub = sharded_rank_counts(eng, self._spec, d, Xd[c0:c0 + CH],
                                                   _ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, flt, subset)
                 eng.compose_ranks(counts, sub, ranking_strategy, out=ranks[c0:c0 + CH, col], out_stride=len(sides))

@@ -635,7 +635,5 @@ def test_filter_ranges_kernel_equals_host_lookup(gpu_lib):
     for fi in (FilterIndex([X], N, R), FilterIndex([X[:1]], N, R), FilterIndex([], N, R)):
         for sd, fn in (("s", fi.subject_ranges), ("o", fi.object_ranges)):
             lo, hi = fn(T)
-            l2, h2, ids = fi.device_filter(eng.device, dev(T), sd, eng)
+            l2, h2, ids = fi.device_filter(eng, dev(T), sd)
             assert np.array_equal(lo, l2.cpu().numpy()) and np.array_equal(hi, h2.cpu().numpy()), sd
-            l3, h3, _ = fi.device_filter(eng.device, dev(T), sd)   # torch fallback agrees too
-            assert np.array_equal(lo, l3.cpu().numpy()) and np.array_equal(hi, h3.cpu().numpy()), sd

@@ -110,3 +110,32 @@ def test_load_from_csv(tmp_path):
     assert X.tolist() == [["a", "y", "b"], ["b", "y", "a"], ["a", "z", "c"]]
     Xr = load_from_csv(str(tmp_path), "d.csv", sep=",", add_reciprocal_rels=True)
     assert Xr.shape == (6, 3) and Xr[3].tolist() == ["b", "y_reciprocal", "a"] and Xr[5].tolist() == ["c", "z_reciprocal", "a"]
+
+
+def test_device_filter_plumbing_with_a_stub_engine():
+    """FilterIndex.device_filter hands the engine the sorted key / start arrays of the right side and returns its ranges with
+    the matching id array (the kernel itself, amdkge_filter_ranges, is tested on the GPU): stub engine doing the search in numpy."""
+    import torch
+
+    class StubEngine:
+        device = torch.device("cpu")
+
+        def filter_ranges(self, keys, start, triples, side, n_ents, n_rels):
+            t = triples.numpy().astype(np.int64)
+            q = t[:, 1] * n_ents + t[:, 2] if side == 1 else t[:, 0] * n_rels + t[:, 1]
+            k, s = keys.numpy(), start.numpy()
+            pos = np.minimum(np.searchsorted(k, q), max(0, k.size - 1))
+            hit = (k[pos] == q) if k.size else np.zeros(len(q), bool)
+            return torch.as_tensor(np.where(hit, s[pos], 0)), torch.as_tensor(np.where(hit, s[np.minimum(pos + 1, s.size - 1)], 0))
+
+    rng = np.random.default_rng(4)
+    N, R = 40, 3
+    X = np.stack([rng.integers(0, N, 400), rng.integers(0, R, 400), rng.integers(0, N, 400)], 1).astype(np.int32)
+    T = np.stack([rng.integers(0, N, 90), rng.integers(0, R, 90), rng.integers(0, N, 90)], 1).astype(np.int32)
+    fi = FilterIndex([X], N, R)
+    eng = StubEngine()
+    for sd, fn, ids in (("s", fi.subject_ranges, fi.s_ids), ("o", fi.object_ranges, fi.o_ids)):
+        lo, hi = fn(T)
+        l2, h2, got_ids = fi.device_filter(eng, torch.as_tensor(T), sd)
+        assert np.array_equal(lo, l2.numpy()) and np.array_equal(hi, h2.numpy()) and np.array_equal(got_ids.numpy(), ids)
+    assert fi.device_filter(eng, torch.as_tensor(T), "s")[2] is fi.device_filter(eng, torch.as_tensor(T), "s")[2]   # cached upload
