@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -118,3 +119,33 @@ def test_product_has_no_oracle_or_cpu_fallback():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(d, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_compat_argument_mapping_and_session_without_gpu():
+    """1.x adapter: argument mapping that needs no engine; the session layer fails loudly (error code + message, no crash,
+    no fallback) when there is no GPU to create it on."""
+    import torch
+
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.compat import ComplEx, TransE, evaluate_performance
+    from ampligraph_amd.latent_features import loss_functions, optimizers
+
+    m = ComplEx(k=10, eta=3, batches_count=7, optimizer="momentum", optimizer_params={"lr": 0.05},
+                initializer="uniform", initializer_params={"low": -0.1, "high": 0.1})
+    o = m._get_optimizer()
+    assert (o.name, o.keras_name, o.momentum, o.learning_rate) == ("momentum", "sgd", 0.9, 0.05)
+    ini = m._get_initializer()
+    x = ini((50, 4), np.random.default_rng(0))
+    assert x.shape == (50, 4) and -0.1 <= x.min() and x.max() <= 0.1
+    assert TransE(initializer="xavier", initializer_params={"uniform": True})._get_initializer() == "glorot_uniform"
+    assert TransE()._get_initializer() == "glorot_normal"
+    const = TransE(initializer="constant", initializer_params={"entity": np.ones((3, 2)), "relation": np.zeros((1, 2))})._get_initializer()
+    assert np.array_equal(const[0]((3, 2), None), np.ones((3, 2), np.float32))
+    assert m.get_hyperparameter_dict()["batches_count"] == 7 and not m.is_fit()
+    with pytest.raises(AssertionError):
+        evaluate_performance(np.zeros((1, 3)), m, corrupt_side="x")
+    if not torch.cuda.is_available():
+        from ampligraph_amd.session import Session
+
+        with pytest.raises(_ffi.AmdKgeError):
+            Session("ComplEx", 8, 10, 2, 3, loss_functions.get("nll"), optimizers.get("adam"))
