@@ -139,3 +139,60 @@ def test_device_filter_plumbing_with_a_stub_engine():
         l2, h2, got_ids = fi.device_filter(eng, torch.as_tensor(T), sd)
         assert np.array_equal(lo, l2.numpy()) and np.array_equal(hi, h2.numpy()) and np.array_equal(got_ids.numpy(), ids)
     assert fi.device_filter(eng, torch.as_tensor(T), "s")[2] is fi.device_filter(eng, torch.as_tensor(T), "s")[2]   # cached upload
+
+
+def test_select_best_model_ranking_with_a_stub_model():
+    """evaluation.select_best_model_ranking (reference protocol.py:447-933): grid and random search, selection on the odd
+    validation rows, failing combinations recorded and skipped, retraining for the early-stopping epoch count, test metrics.
+    The model is a stub whose ranks depend on its hyper-parameters (the real class is exercised by the GPU tests)."""
+    from ampligraph_amd.evaluation import select_best_model_ranking
+
+    log = []
+
+    class Stub:
+        def __init__(self, eta, k, scoring_type, seed=0):
+            self.eta, self.k, self.scoring_type = eta, k, scoring_type
+
+        def compile(self, loss, optimizer, entity_relation_regularizer, entity_relation_initializer):
+            self.lr, self.loss, self.reg = optimizer.learning_rate, loss.name, entity_relation_regularizer
+            if self.k == 13:
+                raise RuntimeError("unlucky k")
+
+        def fit(self, X, batch_size, epochs, **kw):
+            log.append(("fit", self.k, self.eta, len(X), epochs, kw.get("validation_data") is None or len(kw["validation_data"])))
+
+            class H:
+                history = {"loss": [1.0] * min(epochs, 7)}
+            return H
+
+        def evaluate(self, X, use_filter, entities_subset=None, corrupt_side="s,o", verbose=False):
+            log.append(("eval", self.k, len(X), sorted(use_filter) if use_filter else use_filter))
+            base = 1 + abs(self.k - 20) + (0 if self.eta == 2 else 3)      # best: k=20, eta=2
+            return np.full((len(X), 2), base, dtype=np.int32)
+
+    rng = np.random.default_rng(0)
+    Xtr, Xva, Xte = (rng.integers(0, 9, (n, 3)).astype(str) for n in (50, 11, 7))
+    grid = {"k": [10, 13, 20], "eta": [1, 2], "epochs": 30, "optimizer_params": {"learning_rate": [0.1, 0.01]},
+            "loss": "nll", "regularizer": "LP", "regularizer_params": {"p": 3, "lambda": 1e-4}}
+    best, params, mrr, ranks, test_eval, hist = select_best_model_ranking(
+        "ComplEx", Xtr, Xva, Xte, grid, early_stopping_params={"check_interval": 5}, retrain_best_model=True, _model_factory=Stub)
+    assert len(hist) == 12 and sum("exception" in h["results"] for h in hist) == 4       # k = 13 fails in compile, 4 times
+    assert (params["k"], params["eta"], params["early_stopping_epoch"]) == (20, 2, 7) and mrr == 1.0
+    assert best.k == 20 and best.reg.p == 3 and ranks.shape == (7, 2) and test_eval["mrr"] == 1.0 and test_eval["hits_1"] == 1.0
+    fits = [e for e in log if e[0] == "fit"]
+    assert fits[0][3] == 50 and fits[0][5] == 6                 # early stopping validates on the even rows of X_valid
+    assert fits[-1][3] == 50 + 6 and fits[-1][4] == 7 and fits[-1][5] is True   # retrained on train + valid, 7 epochs, no validation
+    evals = [e for e in log if e[0] == "eval"]
+    assert evals[0][2] == 5 and evals[0][3] == ["test", "train", "valid"] and evals[-1][2] == 7   # odd rows select; X_test last
+    # random search: min(max_combinations, size of the list grid) distinct draws (callables count as one choice, as in the
+    # reference's total_combinations), reproducible by seed
+    runs = []
+    for _ in range(2):
+        out = select_best_model_ranking("ComplEx", Xtr, Xva, Xte, {"k": [10, 20, 30, 40], "eta": lambda: int(np.random.randint(1, 4))},
+                                        max_combinations=5, param_grid_random_seed=3, use_test_for_selection=True,
+                                        early_stopping=False, use_filter=False, _model_factory=Stub)
+        runs.append([h["model_params"] for h in out[5]])
+    assert runs[0] == runs[1] and len(runs[0]) == 4 and len({(p["k"], p["eta"]) for p in runs[0]}) == 4
+    # nothing trainable: NaN metrics, no model
+    none = select_best_model_ranking("ComplEx", Xtr, Xva, Xte, {"k": 13}, _model_factory=Stub)
+    assert none[0] is None and np.isnan(none[4]["mrr"]) and len(none[5]) == 1
