@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AMDKGE_LIB") or os.path.join(_HERE, "lib", "libamdkge.so")   # AMDKGE_LIB: development builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums of include/amdkge.h
 SCORING_TYPES = {"TransE": 0, "DistMult": 1, "ComplEx": 2, "HolE": 3, "RotatE": 4}
@@ -40,7 +40,7 @@ class AmdKgeError(RuntimeError):
 
 class Model(C.Structure):
     _fields_ = [("scoring_type", C.c_int32), ("k", C.c_int32), ("n_ents", C.c_int64), ("n_rels", C.c_int64),
-                ("max_rel_size", C.c_int32), ("reserved", C.c_int32)]
+                ("max_rel_size", C.c_int32), ("k_pad", C.c_int32)]
 
 
 class Loss(C.Structure):
@@ -79,6 +79,11 @@ SIGNATURES = {
     "amdkge_dev_memset": (C.c_int, [P, C.c_int, U64, P]),
     "amdkge_stream_sync": (C.c_int, [P]),
     "amdkge_internal_k": (C.c_int, [C.c_int, C.c_int]),
+    "amdkge_padded_k": (C.c_int, [C.c_int]),
+    "amdkge_row_floats": (C.c_int, [C.POINTER(Model)]),
+    "amdkge_pack_rows": (C.c_int, [C.POINTER(Model), P, I64, P, P]),
+    "amdkge_unpack_rows": (C.c_int, [C.POINTER(Model), P, I64, P, P]),
+    "amdkge_set_rank_kernel": (C.c_int, [C.c_int]),
     "amdkge_score": (C.c_int, [C.POINTER(Model), P, P, P, I64, P, P]),
     "amdkge_platt_step": (C.c_int, [P, I64, P, I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, P, P]),
     "amdkge_sample_corruptions": (C.c_int, [P, I64, I32, I64, I64, U64, U64, I64, I64, P, P]),

@@ -89,3 +89,47 @@ extern "C" int amdkge_internal_k(int scoring_type, int k) {
     if (scoring_type < AMDKGE_TRANSE || scoring_type > AMDKGE_ROTATE || k <= 0) return set_error(AMDKGE_EINVAL, "internal_k: bad arguments");
     return internal_k_of(scoring_type, k);
 }
+
+extern "C" int amdkge_padded_k(int k) { return k <= 0 ? set_error(AMDKGE_EINVAL, "padded_k: k must be positive") : ((k + 3) & ~3); }
+
+extern "C" int amdkge_row_floats(const amdkge_model* m) {
+    if (int rc = validate_model(m)) return rc;
+    return row_floats(m);
+}
+
+namespace kge {
+
+// dense [n, NC * k] <-> stored [n, NC * ks] rows; one workgroup per row, halves copied unit for unit, padding zeroed
+template <bool PACK>
+__global__ __launch_bounds__(256) void repack_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int nc, int k, int ks) {
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const float* s = src + r * (int64_t)(nc * (PACK ? k : ks));
+        float* d = dst + r * (int64_t)(nc * (PACK ? ks : k));
+        for (int h = 0; h < nc; ++h) {
+            if (PACK) { for (int c = threadIdx.x; c < ks; c += blockDim.x) d[h * ks + c] = c < k ? s[h * k + c] : 0.f; }
+            else { for (int c = threadIdx.x; c < k; c += blockDim.x) d[h * k + c] = s[h * ks + c]; }
+        }
+    }
+}
+
+template <bool PACK>
+static int repack(const amdkge_model* m, const float* src, int64_t n, float* dst, void* stream, const char* what) {
+    if (int rc = validate_model(m)) return rc;
+    if (n < 0) return set_error(AMDKGE_EINVAL, "pack/unpack_rows: n must be >= 0");
+    if (n == 0) return AMDKGE_OK;
+    if (!src || !dst) return set_error(AMDKGE_EINVAL, "pack/unpack_rows: NULL pointer");
+    const int nc = internal_k_of(m->scoring_type, 1);
+    const unsigned grid = (unsigned)(n < 65535 * 16 ? n : 65535 * 16);
+    hipLaunchKernelGGL(repack_rows_kernel<PACK>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, n, nc, m->k, stored_k(m));
+    return check_launch(what);
+}
+
+}  // namespace kge
+
+extern "C" int amdkge_pack_rows(const amdkge_model* m, const float* d_dense, int64_t n, float* d_stored, void* stream) {
+    return repack<true>(m, d_dense, n, d_stored, stream, "pack_rows");
+}
+
+extern "C" int amdkge_unpack_rows(const amdkge_model* m, const float* d_stored, int64_t n, float* d_dense, void* stream) {
+    return repack<false>(m, d_stored, n, d_dense, stream, "unpack_rows");
+}

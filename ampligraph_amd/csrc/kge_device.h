@@ -176,11 +176,15 @@ __device__ __forceinline__ float score_unit(const float (&s)[ModelTraits<MODEL>:
 
 // g * d(score)/d(s,p,o) for one unit.  `g` already contains score_sign*score_scale.
 // RotatE: dp[0] is d/d(phi) (the caller divides by phase_div once at the end), dp[1] = 0.
+// pad1: 0 for a live unit, 1 for a PADDING unit of the stored row layout (include/amdkge.h).  Only RotatE uses it: a
+// padding unit has s = o = 0, hence modulus 0 and g / 0 * 0 = NaN; adding pad1 to the modulus makes its gradient the
+// exact zero it must be, while a live unit's modulus is unchanged bit for bit (m + 0.0f == m, NaN for a true m == 0 as
+// in the reference).  Every other model's padding units give exact zeros on their own.
 template <int MODEL>
 __device__ __forceinline__ void grad_unit(const float (&s)[ModelTraits<MODEL>::NC], const float (&p)[ModelTraits<MODEL>::NC],
                                           const float (&o)[ModelTraits<MODEL>::NC], float g,
                                           float (&ds)[ModelTraits<MODEL>::NC], float (&dp)[ModelTraits<MODEL>::NC],
-                                          float (&dd)[ModelTraits<MODEL>::NC]) {
+                                          float (&dd)[ModelTraits<MODEL>::NC], float pad1 = 0.f) {
     if constexpr (MODEL == AMDKGE_TRANSE) {
         const float d = s[0] + p[0] - o[0];
         const float sg = (d > 0.f) ? g : ((d < 0.f) ? -g : 0.f);  // g*sign(d), sign(0)=0 ; g carries the minus
@@ -195,7 +199,7 @@ __device__ __forceinline__ void grad_unit(const float (&s)[ModelTraits<MODEL>::N
         const float c = p[0], sn = p[1];
         const float re = s[0] * c - s[1] * sn - o[0];
         const float im = s[0] * sn + s[1] * c - o[1];
-        const float m = KGE_SQRT(re * re + im * im);
+        const float m = KGE_SQRT(re * re + im * im) + pad1;
         const float gm = KGE_DIV(g, m);  // no epsilon: m == 0 -> NaN exactly like the reference (RotatE.py:102-104)
         ds[0] = gm * (re * c + im * sn);
         ds[1] = gm * (-re * sn + im * c);

@@ -19,12 +19,17 @@ inline int validate_model(const amdkge_model* m) {
     if (m->scoring_type < AMDKGE_TRANSE || m->scoring_type > AMDKGE_ROTATE)
         return set_error(AMDKGE_EINVAL, "unknown scoring_type (expected TransE/DistMult/ComplEx/HolE/RotatE)");
     if (m->k <= 0) return set_error(AMDKGE_EINVAL, "k must be positive");
+    if (m->k_pad != 0 && m->k_pad < m->k) return set_error(AMDKGE_EINVAL, "k_pad must be 0 (dense rows) or >= k");
     if (m->n_ents <= 0 || m->n_rels <= 0)
         return set_error(AMDKGE_EINVAL, "entity / relation table sizes must be positive (model not built?)");
     if (m->n_ents > 0x7FFFFFFFll || m->n_rels > 0x7FFFFFFFll)
         return set_error(AMDKGE_EINVAL, "row ids are int32: tables are limited to 2^31-1 rows");
     return AMDKGE_OK;
 }
+
+// units per half AS STORED (include/amdkge.h "STORED row layout") and floats per stored row
+inline int stored_k(const amdkge_model* m) { return m->k_pad > 0 ? m->k_pad : m->k; }
+inline int row_floats(const amdkge_model* m) { return internal_k_of(m->scoring_type, stored_k(m)); }
 
 inline ModelConst model_const(const amdkge_model* m) {
     ModelConst mc;

@@ -85,10 +85,13 @@ __host__ __device__ inline int mode_of(int model, int side) {
 
 inline RankGeom geom_of(const amdkge_model* m, int side) {
     RankGeom g{};
-    g.K = internal_k_of(m->scoring_type, m->k);
+    // stored layout (include/amdkge.h): the zero padding units add exact zeros to every accumulation chain (fmaf(0, 0, acc),
+    // acc + |0|, acc + sqrt(0)), so the chains of a padded and of a dense table produce the same bits
+    const int ks = stored_k(m);
+    g.K = row_floats(m);
     const int mode = mode_of(m->scoring_type, side);
     if (mode == MODE_DOT || mode == MODE_L1 || mode == MODE_L1_SUB) { g.U = g.K; g.eplane = 0; g.qplane = 0; g.QW = g.K; }
-    else { g.U = m->k; g.eplane = m->k; g.qplane = m->k; g.QW = (mode == MODE_ROT_S ? 4 : 2) * m->k; }
+    else { g.U = ks; g.eplane = ks; g.qplane = ks; g.QW = (mode == MODE_ROT_S ? 4 : 2) * ks; }
     g.sgn = (side == AMDKGE_SIDE_S) ? 1.f : -1.f;
     return g;
 }
@@ -820,7 +823,7 @@ static int run_prep(const amdkge_model* m, const float* d_ent, const float* d_re
                     int side, const RankGeom& g, const Workspace& w, hipStream_t st) {
     const ModelConst mc = model_const(m);
     const unsigned grid = (unsigned)((n + 3) / 4);
-#define KGE_PREP(M) hipLaunchKernelGGL((rank_prep_kernel<M>), dim3(grid), dim3(256), 0, st, d_ent, d_rel, d_triples, n, m->k, g.K, side, g.QW, mc, w.Q, w.qpos)
+#define KGE_PREP(M) hipLaunchKernelGGL((rank_prep_kernel<M>), dim3(grid), dim3(256), 0, st, d_ent, d_rel, d_triples, n, stored_k(m), g.K, side, g.QW, mc, w.Q, w.qpos)
     switch (m->scoring_type) {
         case AMDKGE_TRANSE: KGE_PREP(AMDKGE_TRANSE); break;
         case AMDKGE_DISTMULT: KGE_PREP(AMDKGE_DISTMULT); break;
@@ -836,9 +839,17 @@ static int run_prep(const amdkge_model* m, const float* d_ent, const float* d_re
 
 using namespace kge;
 
+static int g_rank_kernel = 0;
+
+extern "C" int amdkge_set_rank_kernel(int which) {
+    if (which < 0 || which > 2) return set_error(AMDKGE_EINVAL, "set_rank_kernel: 0 = automatic, 1 = VALU tile kernel, 2 = first MFMA kernel");
+    g_rank_kernel = which;
+    return AMDKGE_OK;
+}
+
 extern "C" int64_t amdkge_rank_workspace_bytes(const amdkge_model* m, int64_t n) {
     if (validate_model(m) != AMDKGE_OK || n < 0) return -1;
-    const int64_t qw = (m->scoring_type == AMDKGE_ROTATE) ? 4ll * m->k : internal_k_of(m->scoring_type, m->k);
+    const int64_t qw = (m->scoring_type == AMDKGE_ROTATE) ? 4ll * stored_k(m) : row_floats(m);
     return 1024 + ((n * 4 + 255) / 256) * 256 + n * qw * 4;
 }
 
@@ -862,8 +873,8 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
     a.ent_lo = ent_lo; a.ent_hi = ent_hi; a.g = g; a.sgn_scale = mc.score_sign * mc.score_scale;
     const bool v4 = (g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
     const int mode = mode_of(m->scoring_type, side);
-    const char* force = getenv("AMDKGE_RANK_PATH");   // development: "valu" forces the VALU tile kernel, "mfma0" the first MFMA kernel
-    const bool mfma = (mode == MODE_DOT) && !(force && force[0] == 'v');
+    const int force = g_rank_kernel;   // amdkge_set_rank_kernel (tests): 1 forces the VALU tile kernel, 2 the first MFMA kernel
+    const bool mfma = (mode == MODE_DOT) && force != 1;
     const int qt = mfma ? MQ : QT, et_ = mfma ? ME : ET;
     const int64_t qtiles = (n + qt - 1) / qt;
     const int64_t etiles = (ent_hi - ent_lo + et_ - 1) / et_;
@@ -890,7 +901,6 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
         }
         if (!mfma) break;
     }
-    if (const char* tp = getenv("AMDKGE_RANK_TP")) { if (atoi(tp) > 0) tiles_per = atoi(tp); }   // development knob
     if (best_cost < 0) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: entity range too large for one launch; split [ent_lo, ent_hi)");
     int64_t splits;
     a.ent_per_block = (int)(tiles_per * et_);
@@ -909,7 +919,7 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
         const int64_t nblk = 8 * ((qtiles + 7) / 8) * splits;
         if (nblk > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch; split the triples or the entity range");
         const dim3 grid1((unsigned)nblk);
-        const bool pipe = !(force && force[0] == 'm');   // development: AMDKGE_RANK_PATH=mfma0 keeps the first MFMA kernel
+        const bool pipe = force != 2;
         if (v4 && pipe) hipLaunchKernelGGL(rank_count_mfma_pipe_kernel, grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         else if (v4) hipLaunchKernelGGL((rank_count_mfma_kernel<true>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         else hipLaunchKernelGGL((rank_count_mfma_kernel<false>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);

@@ -50,14 +50,15 @@ static int launch_score(const float* ent, const float* rel, const int32_t* tr, i
 
 int score_dispatch(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples, int64_t n,
                    float* d_scores, hipStream_t st) {
-    const int K = internal_k_of(m->scoring_type, m->k);
+    // stored layout: padding units score exactly 0 in every model (RotatE: sqrt(0)), so the kernels just see ks units
+    const int ks = stored_k(m), K = row_floats(m);
     const ModelConst mc = model_const(m);
     switch (m->scoring_type) {
-        case AMDKGE_TRANSE: return launch_score<AMDKGE_TRANSE>(d_ent, d_rel, d_triples, n, m->k, K, mc, d_scores, st);
-        case AMDKGE_DISTMULT: return launch_score<AMDKGE_DISTMULT>(d_ent, d_rel, d_triples, n, m->k, K, mc, d_scores, st);
+        case AMDKGE_TRANSE: return launch_score<AMDKGE_TRANSE>(d_ent, d_rel, d_triples, n, ks, K, mc, d_scores, st);
+        case AMDKGE_DISTMULT: return launch_score<AMDKGE_DISTMULT>(d_ent, d_rel, d_triples, n, ks, K, mc, d_scores, st);
         case AMDKGE_COMPLEX:
-        case AMDKGE_HOLE: return launch_score<AMDKGE_COMPLEX>(d_ent, d_rel, d_triples, n, m->k, K, mc, d_scores, st);
-        default: return launch_score<AMDKGE_ROTATE>(d_ent, d_rel, d_triples, n, m->k, K, mc, d_scores, st);
+        case AMDKGE_HOLE: return launch_score<AMDKGE_COMPLEX>(d_ent, d_rel, d_triples, n, ks, K, mc, d_scores, st);
+        default: return launch_score<AMDKGE_ROTATE>(d_ent, d_rel, d_triples, n, ks, K, mc, d_scores, st);
     }
 }
 

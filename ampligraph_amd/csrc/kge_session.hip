@@ -2,6 +2,7 @@
 // drives the device-pointer entry points with HOST buffers in and out, so that a host without torch (the reference's
 // numpy-level Python through ctypes) can train, score and rank.  Pure composition: every computation is one of the entry
 // points of the other translation units.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -12,8 +13,9 @@
 using namespace kge;
 
 struct amdkge_session {
-    amdkge_session_config cfg;
-    int K = 0;
+    amdkge_session_config cfg;   // cfg.model.k_pad = amdkge_padded_k(k): the session owns the tables and stores them padded
+    int K = 0;                   // floats per DENSE row (what the host hands over and gets back)
+    int Ks = 0;                  // floats per STORED row
     hipStream_t st = nullptr;
     float* tab[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // AMDKGE_TABLE_* order
     float* g_ent = nullptr;
@@ -52,6 +54,19 @@ int upload(amdkge_session* s, int slot, const void* host, int64_t bytes, void** 
     return AMDKGE_OK;
 }
 
+// ids arrive from the host: an out-of-range id would become an out-of-bounds gather (or a scatter into the gradient
+// tables) on the device, so they are checked here, O(n) on host memory, before anything is uploaded
+int check_triples(const amdkge_session* s, const int32_t* t, int64_t n, const char* who) {
+    const int64_t ne = s->cfg.model.n_ents, nr = s->cfg.model.n_rels;
+    for (int64_t i = 0; i < n; ++i)
+        if (t[3 * i] < 0 || t[3 * i] >= ne || t[3 * i + 2] < 0 || t[3 * i + 2] >= ne || t[3 * i + 1] < 0 || t[3 * i + 1] >= nr) {
+            static thread_local char msg[160];
+            snprintf(msg, sizeof(msg), "%s: triple %lld has an entity / relation id outside the tables", who, (long long)i);
+            return set_error(AMDKGE_EINVAL, msg);
+        }
+    return AMDKGE_OK;
+}
+
 __global__ void gather_rows_kernel(const float* src, const int32_t* ids, int64_t n, int K, float* dst) {
     const int64_t r = blockIdx.x;
     const float* row = src + (int64_t)ids[r] * K;
@@ -87,8 +102,10 @@ extern "C" int amdkge_session_create(const amdkge_session_config* cfg, amdkge_se
     amdkge_session* s = new amdkge_session();
     s->cfg = *cfg;
     s->cfg.loss.d_focus_w = nullptr;
+    s->cfg.model.k_pad = amdkge_padded_k(cfg->model.k);   // every k gets the 16-byte kernels; hosts only ever see dense rows
     s->K = amdkge_internal_k(cfg->model.scoring_type, cfg->model.k);
-    const int64_t ne = cfg->model.n_ents * (int64_t)s->K, nr = cfg->model.n_rels * (int64_t)s->K;
+    s->Ks = row_floats(&s->cfg.model);
+    const int64_t ne = cfg->model.n_ents * (int64_t)s->Ks, nr = cfg->model.n_rels * (int64_t)s->Ks;
     const int nslots = opt_nslots(cfg->opt.kind);
     auto fail = [&](int rc) { amdkge_session_destroy(s); return rc; };
     hipError_t e = hipStreamCreate(&s->st);
@@ -125,7 +142,9 @@ extern "C" int amdkge_session_set_rows(amdkge_session* s, int32_t table, int64_t
     if (nrows == 0) return AMDKGE_OK;
     if (!host) return set_error(AMDKGE_EINVAL, "session_set_rows: NULL host buffer");
     KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
-    KGE_HIP(hipMemcpyAsync(s->tab[table] + row0 * s->K, host, (size_t)nrows * s->K * sizeof(float), hipMemcpyHostToDevice, s->st), "hipMemcpyAsync(H2D)");
+    void* d_dense;
+    KGE_RC(upload(s, 1, host, nrows * s->K * (int64_t)sizeof(float), &d_dense));
+    KGE_RC(amdkge_pack_rows(&s->cfg.model, (const float*)d_dense, nrows, s->tab[table] + row0 * s->Ks, s->st));
     KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
     return AMDKGE_OK;
 }
@@ -143,15 +162,18 @@ extern "C" int amdkge_session_get_rows(amdkge_session* s, int32_t table, const i
             if (ids[i] < 0 || ids[i] >= rows) return set_error(AMDKGE_EINVAL, "session_get_rows: row id outside the table");
         void *d_ids, *d_tmp;
         KGE_RC(upload(s, 0, ids, nrows * (int64_t)sizeof(int32_t), &d_ids));
-        KGE_RC(scratch(s, 1, nrows * s->K * (int64_t)sizeof(float), &d_tmp));
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nrows), dim3(256), 0, s->st, s->tab[table], (const int32_t*)d_ids, nrows, s->K, (float*)d_tmp);
+        KGE_RC(scratch(s, 1, nrows * s->Ks * (int64_t)sizeof(float), &d_tmp));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nrows), dim3(256), 0, s->st, s->tab[table], (const int32_t*)d_ids, nrows, s->Ks, (float*)d_tmp);
         KGE_RC(check_launch("gather_rows"));
         src = (const float*)d_tmp;
     } else {
         if (row0 < 0 || row0 + nrows > table_rows(s, table)) return set_error(AMDKGE_EINVAL, "session_get_rows: rows outside the table");
-        src = s->tab[table] + row0 * s->K;
+        src = s->tab[table] + row0 * s->Ks;
     }
-    KGE_HIP(hipMemcpyAsync(host, src, (size_t)nrows * s->K * sizeof(float), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
+    void* d_dense;
+    KGE_RC(scratch(s, 7, nrows * s->K * (int64_t)sizeof(float), &d_dense));
+    KGE_RC(amdkge_unpack_rows(&s->cfg.model, src, nrows, (float*)d_dense, s->st));
+    KGE_HIP(hipMemcpyAsync(host, d_dense, (size_t)nrows * s->K * sizeof(float), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
     KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
     return AMDKGE_OK;
 }
@@ -162,6 +184,7 @@ extern "C" int amdkge_session_train_step(amdkge_session* s, const int32_t* tripl
     if (B == 0) return AMDKGE_OK;   // (the reference never produces an empty batch; nothing happens, no step is counted)
     if (!triples) return set_error(AMDKGE_EINVAL, "session_train_step: NULL triples");
     if (focus_w && !s->cfg.loss.focus_nonlinearity) return set_error(AMDKGE_EINVAL, "session_train_step: FocusE weights given but the session's loss has focus_nonlinearity == 0");
+    KGE_RC(check_triples(s, triples, B, "session_train_step"));
     KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
     const amdkge_model* m = &s->cfg.model;
     void *d_tri, *d_fw = nullptr;
@@ -192,10 +215,10 @@ extern "C" int amdkge_session_train_step(amdkge_session* s, const int32_t* tripl
     } else {          // shapes the pair does not cover: atomic forward/backward + dense sweeps
         KGE_RC(amdkge_train_fwdbwd(m, &loss, s->tab[0], s->tab[1], (const int32_t*)d_tri, B, s->cfg.eta, 0, m->n_ents, s->cfg.seed,
                                    s->step, 0, 0, nullptr, s->g_ent, s->g_rel, s->acc, nullptr, nullptr, s->st));
-        KGE_RC(amdkge_opt_step(&opt, s->tab[0], s->g_ent, s->tab[2], s->tab[3], m->n_ents * (int64_t)s->K, s->acc + 1, s->st));
+        KGE_RC(amdkge_opt_step(&opt, s->tab[0], s->g_ent, s->tab[2], s->tab[3], m->n_ents * (int64_t)s->Ks, s->acc + 1, s->st));
         amdkge_opt orel = opt;
         orel.reg_lambda = s->cfg.rel_reg_lambda;
-        KGE_RC(amdkge_opt_step(&orel, s->tab[1], s->g_rel, s->tab[4], s->tab[5], m->n_rels * (int64_t)s->K, s->acc + 1, s->st));
+        KGE_RC(amdkge_opt_step(&orel, s->tab[1], s->g_rel, s->tab[4], s->tab[5], m->n_rels * (int64_t)s->Ks, s->acc + 1, s->st));
     }
     double h[2] = {0.0, 0.0};
     KGE_HIP(hipMemcpyAsync(h, s->acc, sizeof(h), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
@@ -210,6 +233,7 @@ extern "C" int amdkge_session_score(amdkge_session* s, const int32_t* triples, i
     if (!s || n < 0) return set_error(AMDKGE_EINVAL, "session_score: bad arguments");
     if (n == 0) return AMDKGE_OK;
     if (!triples || !scores_out) return set_error(AMDKGE_EINVAL, "session_score: NULL buffer");
+    KGE_RC(check_triples(s, triples, n, "session_score"));
     KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
     void *d_tri, *d_sc;
     KGE_RC(upload(s, 0, triples, n * 3 * (int64_t)sizeof(int32_t), &d_tri));
@@ -230,6 +254,7 @@ extern "C" int amdkge_session_rank(amdkge_session* s, const int32_t* triples, in
     if (!triples || !ranks_out) return set_error(AMDKGE_EINVAL, "session_rank: NULL buffer");
     if ((fs_off && !fs_ids && fs_off[n] > 0) || (fo_off && !fo_ids && fo_off[n] > 0)) return set_error(AMDKGE_EINVAL, "session_rank: filter offsets without ids");
     if (n_subset < 0 || (n_subset > 0 && !ent_subset)) return set_error(AMDKGE_EINVAL, "session_rank: bad entities subset");
+    KGE_RC(check_triples(s, triples, n, "session_rank"));
     KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
     const amdkge_model* m = &s->cfg.model;
     void *d_tri, *d_work, *d_counts, *d_sub, *d_ranks, *d_off = nullptr, *d_ids = nullptr, *d_sel = nullptr;
@@ -269,6 +294,8 @@ extern "C" int amdkge_session_rank(amdkge_session* s, const int32_t* triples, in
             if (off[0] < 0) return set_error(AMDKGE_EINVAL, "session_rank: negative filter offset");
             for (int64_t i = 0; i < n; ++i)
                 if (off[i + 1] < off[i]) return set_error(AMDKGE_EINVAL, "session_rank: filter offsets must be non-decreasing");
+            for (int64_t f = 0; f < off[n]; ++f)
+                if (ids[f] < 0 || ids[f] >= m->n_ents) return set_error(AMDKGE_EINVAL, "session_rank: filter id outside the entity table");
             KGE_RC(upload(s, 4, off, (n + 1) * (int64_t)sizeof(int64_t), &d_off));
             KGE_RC(upload(s, 5, ids, off[n] * (int64_t)sizeof(int32_t), &d_ids));
             KGE_RC(amdkge_rank_filter(m, s->tab[0], s->tab[1], (const int32_t*)d_tri, n, side, (const int64_t*)d_off, (const int64_t*)d_off + 1,

@@ -79,7 +79,7 @@ template <int MODEL>
 static int launch_train_m(TrainArgs& a, hipStream_t st) {
     const int units = a.k;  // units per row: k floats (real models) or k complex pairs
     // 16-byte loads + LDS-transposed scatter when one wave covers the row with <= 2 quads per lane
-    if (units % 4 == 0 && units <= 512 && !(a.dbg & 16)) { a.nq = units / 4; return launch_train_w<MODEL, 4, 1>(a, a.nq <= 64 ? 1 : 2, st); }
+    if (units % 4 == 0 && units <= 512 && !KGE_DBG(a, 16)) { a.nq = units / 4; return launch_train_w<MODEL, 4, 1>(a, a.nq <= 64 ? 1 : 2, st); }
     a.nq = units;
     return launch_train_mv<MODEL, 1>(a, st);
 }
@@ -122,12 +122,14 @@ extern "C" int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* los
     a.ent = d_ent; a.rel = d_rel; a.triples = d_triples; a.neg_override = d_neg_override;
     a.g_ent = d_grad_ent; a.g_rel = d_grad_rel; a.loss_sum = d_loss_sum;
     a.pos_scores = d_pos_scores; a.neg_scores = d_neg_scores;
-    a.B = B; a.eta = eta; a.k = m->k; a.K = internal_k_of(m->scoring_type, m->k);
+    a.B = B; a.eta = eta; a.k = stored_k(m); a.K = row_floats(m); a.k_live = m->k;
     a.sc = SampleCfg{sample_base, (uint32_t)sample_range, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step,
                      (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
     a.mc = model_const(m);
     a.loss = *loss;
+#ifdef KGE_ABLATE
     { const char* e = getenv("AMDKGE_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+#endif
     hipStream_t st = (hipStream_t)stream;
     switch (m->scoring_type) {
         case AMDKGE_TRANSE: return launch_train_m<AMDKGE_TRANSE>(a, st);

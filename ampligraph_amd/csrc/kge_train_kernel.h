@@ -27,8 +27,9 @@ struct TrainArgs {
     float* neg_scores;
     int64_t B;
     int eta;
-    int k;       // user k (units per half for complex models)
-    int K;       // floats per row
+    int k;       // units per half AS STORED (k_pad of the model descriptor, or k for dense rows)
+    int K;       // floats per stored row
+    int k_live;  // the model's k: units >= k_live of a half are zero padding (only RotatE's gradient needs to know)
     int nq;      // quads per row ( = units / VEC )
     SampleCfg sc;
     ModelConst mc;
@@ -40,8 +41,17 @@ struct TrainArgs {
     StageEntry* st_ovf;      // overflow of full buckets
     int* st_counters;        // [(n_tiles + 1) * 32] bucket fill counts (128-byte stride), last = overflow count
     int st_tile_rows, st_n_tiles, st_cap, st_ovf_cap;
-    int dbg;     // development ablation flags (env AMDKGE_DEBUG): 1 no neg-row atomics, 2 no s/p/o atomics, 4 no pass 2, 8 workgroup-scope atomics, 32 no bucket appends, 64 no staged-row stores
+#ifdef KGE_ABLATE
+    int dbg;     // development ablation build only (make EXTRA=-DKGE_ABLATE, env AMDKGE_DEBUG): 1 no neg-row atomics, 2 no s/p/o atomics, 4 no pass 2, 32 no bucket appends, 64 no staged-row stores
+#endif
 };
+
+// ablation switches exist only in development builds; the release library cannot skip work
+#ifdef KGE_ABLATE
+#define KGE_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define KGE_DBG(a, bit) false
+#endif
 
 __device__ __forceinline__ float log_sigmoid(float x) {
     // -softplus(-x), stable on both tails
@@ -390,13 +400,19 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
         for (int u = 0; u < VEC; ++u) prep_rel<MODEL>(a.mc, p[c][u]);
     }
+    // RotatE on a padded row layout: 1 for the zero-padding units behind k_live (see grad_unit); folds away elsewhere
+    float pad1[CH][VEC];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) pad1[c][u] = (MODEL == AMDKGE_ROTATE && qoff[c] + u >= a.k_live) ? 1.f : 0.f;
     if constexpr (STAGE) {
         // side rows for the owner kernel.  Trilinear models: d(score)/d(replaced row) does not depend on the
         // replaced row, so the owner only needs g * A (A = d/do (s,p)) or g * B (B = d/ds (p,o)).
         // TransE / RotatE: copies of s and o (the owner recomputes grad_unit with its own row).
         static_assert(!STAGE || VEC == 4, "staging uses the 16-byte layout");
         constexpr bool TRILINEAR = (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
-        if (active && !(a.dbg & 64)) {
+        if (active && !KGE_DBG(a, 64)) {
             float* qa = a.stage_rows + ((int64_t)i * 4 + 2) * a.K;
             float* qb = a.stage_rows + ((int64_t)i * 4 + 3) * a.K;
 #pragma unroll
@@ -671,7 +687,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     if (ts == 0) sh_loss[slot] = active ? (double)per : 0.0;
     if constexpr (STAGE) {
         // one entry per row gradient that lands in the entity table, into the bucket of the owning tile
-        if (active && !(a.dbg & 32))
+        if (active && !KGE_DBG(a, 32))
             for (int j = ts; j < eta + (a.pos_atomic ? 0 : 2); j += TS) {
                 uint32_t dest, role;
                 float g;
@@ -697,7 +713,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
         for (int u = 0; u < VEC; ++u) {
             float ds[NC], dp[NC], dd[NC];
-            grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], dP * sgn_scale, ds, dp, dd);
+            grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], dP * sgn_scale, ds, dp, dd, pad1[c][u]);
 #pragma unroll
             for (int h = 0; h < NC; ++h) { gs[c][u][h] = ds[h]; gp[c][u][h] = dp[h]; go[c][u][h] = dd[h]; }
         }
@@ -769,8 +785,8 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 for (int h = 0; h < NC; ++h) { go[c][u][h] += dd[h]; gp[c][u][h] += dp[h]; }
             }
     }
-    const bool do_neg_atomics = active && !(a.dbg & 1);
-    for (int j0 = 0; j0 < ((ONEPASS || (a.dbg & 4)) ? 0 : eta); j0 += PF) {
+    const bool do_neg_atomics = active && !KGE_DBG(a, 1);
+    for (int j0 = 0; j0 < ((ONEPASS || KGE_DBG(a, 4)) ? 0 : eta); j0 += PF) {
         float e[PF][CH][VEC][NC];
         int keepv[PF];
         int64_t erv[PF];
@@ -794,11 +810,11 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 for (int u = 0; u < VEC; ++u) {
                     float ds[NC], dp[NC], dd[NC];
                     if (keepv[f]) {   // (s, p, e): object replaced
-                        grad_unit<MODEL>(s[c][u], p[c][u], e[f][c][u], g, ds, dp, dd);
+                        grad_unit<MODEL>(s[c][u], p[c][u], e[f][c][u], g, ds, dp, dd, pad1[c][u]);
 #pragma unroll
                         for (int h = 0; h < NC; ++h) { gs[c][u][h] += ds[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = dd[h]; }
                     } else {          // (e, p, o): subject replaced
-                        grad_unit<MODEL>(e[f][c][u], p[c][u], o[c][u], g, ds, dp, dd);
+                        grad_unit<MODEL>(e[f][c][u], p[c][u], o[c][u], g, ds, dp, dd, pad1[c][u]);
 #pragma unroll
                         for (int h = 0; h < NC; ++h) { go[c][u][h] += dd[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = ds[h]; }
                     }
@@ -824,7 +840,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         // batch, which piles thousands of entries onto one row of one tile and onto one bucket counter (measured 4x
         // slower steps on a zipf graph); the host then sets pos_atomic and these 2 rows per positive take the atomic
         // row-add into the dense gradient buffer instead (+15 us at C2), which the owner folds in when it flushes.
-        if (active && !(a.dbg & 64)) {
+        if (active && !KGE_DBG(a, 64)) {
             if (a.pos_atomic) {
                 emit_row(a.g_ent + (int64_t)ps * a.K, gs, a.K, 1.f);
                 emit_row(a.g_ent + (int64_t)po * a.K, go, a.K, 1.f);
@@ -842,12 +858,12 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 }
             }
         }
-        if (active && !(a.dbg & 2)) {
+        if (active && !KGE_DBG(a, 2)) {
             // relation rows: few and hot -> atomic row-add into the dense relation gradient (swept by kge_opt.hip)
             if constexpr (MODEL == AMDKGE_ROTATE) emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.k, 1.f / a.mc.phase_div);
             else emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.K, 1.f);
         }
-    } else if (active && !(a.dbg & 2)) {
+    } else if (active && !KGE_DBG(a, 2)) {
         emit_row(a.g_ent + (int64_t)ps * a.K, gs, a.K, 1.f);
         emit_row(a.g_ent + (int64_t)po * a.K, go, a.K, 1.f);
         if constexpr (MODEL == AMDKGE_ROTATE) {

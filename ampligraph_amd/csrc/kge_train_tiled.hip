@@ -62,7 +62,8 @@ struct TileArgs {
     OptArgs rel_opt;          // fused relation-table sweep (rel_blocks > 0): blocks [n_tiles, n_tiles + rel_blocks)
     int rel_blocks;
     int64_t n_rows;
-    int k, K, nq;
+    int k, K, nq;             // stored half width, floats per stored row, quads per half
+    int k_live;               // the model's k (RotatE: units behind it are zero padding, see grad_unit)
     int tile_rows, n_tiles, cap, ovf_cap;
     int gw;                   // waves that share one row (1: a wave covers the row; 4 / 8: long rows are split over a group of
                               // waves, each lane one quad), rows are owned by wave GROUPS: TILE_WAVES / gw owners per tile
@@ -178,8 +179,9 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                         p[h] = (&pv[c][h < NX ? h : 0].x)[u]; e[h] = (&ev[c][h < NX ? h : 0].x)[u]; sd[h] = (&v[c][h].x)[u];
                     }
                     if constexpr (MODEL != AMDKGE_ROTATE) prep_rel<MODEL>(a.mc, p);
-                    if (role == 0) grad_unit<MODEL>(sd, p, e, g, ds, dp, dd);
-                    else grad_unit<MODEL>(e, p, sd, g, ds, dp, dd);
+                    const float pad1 = (MODEL == AMDKGE_ROTATE && qoff[c] + u >= a.k_live) ? 1.f : 0.f;
+                    if (role == 0) grad_unit<MODEL>(sd, p, e, g, ds, dp, dd, pad1);
+                    else grad_unit<MODEL>(e, p, sd, g, ds, dp, dd, pad1);
 #pragma unroll
                     for (int h = 0; h < NC; ++h) (&out[c][h].x)[u] = (role == 0) ? dd[h] : ds[h];
                 }
@@ -324,18 +326,16 @@ static int pick_tile_rows(int64_t n_rows, int K) {
     int fit = (int)(budget / ((size_t)K * 4));
     if (fit < 1) return 0;
     if (fit > 4096) fit = 4096;
-    int64_t m0 = 1;
-    if (const char* e = getenv("AMDKGE_TILE_M")) m0 = atoi(e) > 0 ? atoi(e) : 1;   // development: more, smaller tiles
-    for (int64_t m = m0;; ++m) {   // smallest number of block waves m whose tile size fits
+    for (int64_t m = 1;; ++m) {   // smallest number of block waves m whose tile size fits
         const int64_t r = (n_rows + 256 * m - 1) / (256 * m);
         if (r <= fit) return (int)(r < 1 ? 1 : r);
     }
 }
 
 static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p) {
-    const int K = internal_k_of(m->scoring_type, m->k);
-    if (m->k % 4 != 0 || m->k > 2048) return false;   // 16-byte layout; one wave (k <= 512) or one workgroup (k <= 2048) per positive
-    if ((m->k <= 512 ? (size_t)4 * slot_lds_bytes(eta, 1) + 32 + 16 * (size_t)K : slot_lds_bytes(eta, 4) + 8 + 4 * (size_t)K) > 150 * 1024) return false;
+    const int ks = stored_k(m), K = row_floats(m);
+    if (ks % 4 != 0 || ks > 2048) return false;   // 16-byte layout; one wave (k <= 512) or one workgroup (k <= 2048) per positive
+    if ((ks <= 512 ? (size_t)4 * slot_lds_bytes(eta, 1) + 32 + 16 * (size_t)K : slot_lds_bytes(eta, 4) + 8 + 4 * (size_t)K) > 150 * 1024) return false;
     p.tile_rows = pick_tile_rows(m->n_ents, K);
     if (p.tile_rows < 1) return false;
     p.n_tiles = (int)((m->n_ents + p.tile_rows - 1) / p.tile_rows);
@@ -439,7 +439,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     if (B < 0 || B >= (1ll << 30) || eta < 1) return set_error(AMDKGE_EINVAL, "train_step_tiled: B must be in [0, 2^30) and eta >= 1");
     TiledPlan p;
     if (!make_plan(m, B, eta, p))
-        return set_error(AMDKGE_EUNSUPPORTED, "train_step_tiled: shape not supported (k % 4 != 0, k > 2048 or eta too large); use amdkge_train_fwdbwd + amdkge_opt_step");
+        return set_error(AMDKGE_EUNSUPPORTED, "train_step_tiled: shape not supported (stored half width not a multiple of 4 -- set k_pad = amdkge_padded_k(k) --, > 2048, or eta too large); use amdkge_train_fwdbwd + amdkge_opt_step");
     if (apply_update) {
         if (opt_nslots(opt->kind) >= 1 && !d_ent_slot0) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 0 is NULL");
         if (opt_nslots(opt->kind) == 2 && !d_ent_slot1) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 1 is NULL");
@@ -450,7 +450,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     if (B > 0 && !d_triples) return set_error(AMDKGE_EINVAL, "train_step_tiled: null triples");
     if (!d_neg_override && (sample_range <= 0 || sample_range > 0xFFFFFFFFll || sample_base < 0 || sample_base + sample_range > m->n_ents))
         return set_error(AMDKGE_EINVAL, "train_step_tiled: sampling range outside the entity table");
-    const int K = internal_k_of(m->scoring_type, m->k);
+    const int ks = stored_k(m), K = row_floats(m);
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
     int* counters = (int*)(w + p.off_cnt);
@@ -462,19 +462,21 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     TrainArgs f{};
     f.ent = d_ent; f.rel = d_rel; f.triples = d_triples; f.neg_override = d_neg_override;
     f.g_ent = d_grad_ent; f.g_rel = d_grad_rel; f.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; f.loss_sum = d_loss_sum; f.pos_scores = d_pos_scores; f.neg_scores = d_neg_scores;
-    f.B = B; f.eta = eta; f.k = m->k; f.K = K; f.nq = m->k / 4;
+    f.B = B; f.eta = eta; f.k = ks; f.K = K; f.k_live = m->k; f.nq = ks / 4;
     f.sc = SampleCfg{sample_base, (uint32_t)sample_range, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step,
                      (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
     f.mc = model_const(m); f.loss = *loss;
     f.stage_rows = stage_rows; f.st_lists = lists; f.st_ovf = ovf; f.st_counters = counters;
     f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap;
+#ifdef KGE_ABLATE
     { const char* e = getenv("AMDKGE_DEBUG"); f.dbg = e ? atoi(e) : 0; }
+#endif
 
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
     te.rel_cs = rel_cs;
     te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
-    te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = m->k; te.K = K; te.nq = m->k / 4;
+    te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = ks; te.K = K; te.k_live = m->k; te.nq = ks / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;
     fill_opt_args(te.opt, opt);
     // Whole step in two launches when nothing in the tile pass reads the live relation table (trilinear models)
@@ -496,8 +498,8 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     // regulariser exactly like the dense path does
     int rc;
     if (m->scoring_type == AMDKGE_ROTATE && B > 0) {
-        const int64_t nel = (int64_t)m->n_rels * m->k;
-        hipLaunchKernelGGL(rel_phase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, d_rel, (int64_t)m->n_rels, m->k, K, f.mc, rel_cs);
+        const int64_t nel = (int64_t)m->n_rels * ks;
+        hipLaunchKernelGGL(rel_phase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, d_rel, (int64_t)m->n_rels, ks, K, f.mc, rel_cs);
         if ((rc = check_launch("rel_phase"))) return rc;
     }
     switch (m->scoring_type) {

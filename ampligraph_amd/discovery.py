@@ -87,8 +87,9 @@ def find_nearest_neighbours(kge_model, entities, n_neighbors=10, entities_subset
         all_neighbors = ix.get_indexes(cand, "e", "ind2raw")
     assert n_neighbors < len(all_neighbors), "n_neighbors must be less than the number of entities being fit!"
     tab = kge_model._entity_table()
-    E = tab[torch.as_tensor(cand).to(tab.device)]
-    Q = tab[torch.as_tensor(np.asarray(ix.get_indexes(np.asarray(entities), "e"), dtype=np.int64)).to(tab.device)]
+    unpack = kge_model._engine.unpack
+    E = unpack(tab[torch.as_tensor(cand).to(tab.device)])
+    Q = unpack(tab[torch.as_tensor(np.asarray(ix.get_indexes(np.asarray(entities), "e"), dtype=np.int64)).to(tab.device)])
     if metric in ("euclidean", "l2", "minkowski"):
         d = torch.cdist(Q.double(), E.double()).float()
     elif metric == "cosine":

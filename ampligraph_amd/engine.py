@@ -22,7 +22,11 @@ def _stream():
 
 
 class KgeEngine:
-    def __init__(self, scoring_type, k, n_ents, n_rels, max_rel_size=None, device=None):
+    def __init__(self, scoring_type, k, n_ents, n_rels, max_rel_size=None, device=None, pad=True):
+        """pad=True (the product's setting): tables are STORED with each half padded to a multiple of 4 units
+        (include/amdkge.h "STORED row layout"), which gives every k the 16-byte kernels; `ent`, `rel`, the gradient
+        buffers and the optimizer slots then have `Ks` floats per row, of which the dense `K` are live.  pack() /
+        unpack() convert; set_tables() / get_tables() speak the dense layout.  pad=False keeps dense rows (tests)."""
         if scoring_type not in _ffi.SCORING_TYPES:
             raise ValueError(f"unknown scoring_type {scoring_type!r}")
         self.lib = _ffi.lib()  # raises when the HIP library is absent: no fallback path exists
@@ -34,17 +38,19 @@ class KgeEngine:
         self.n_ents = int(n_ents)
         self.n_rels = int(n_rels)
         self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], self.k))
+        self.ks = int(self.lib.amdkge_padded_k(self.k)) if pad else self.k
         self.model = _ffi.Model(_ffi.SCORING_TYPES[scoring_type], self.k, self.n_ents, self.n_rels,
-                                int(max_rel_size) if max_rel_size else 0, 0)
+                                int(max_rel_size) if max_rel_size else 0, self.ks)
+        self.Ks = int(self.lib.amdkge_row_floats(C.byref(self.model)))
         # Both tables live in ONE flat allocation (entity rows first, relation rows on a 256-byte boundary behind them),
         # and so do their gradients and every optimizer slot: the multi-GPU step can then treat "all parameters" as one
         # vector (single all-reduce, or slice-wise reduce-scatter / sharded sweep / all-gather).
-        ne, nr = self.n_ents * self.K, self.n_rels * self.K
+        ne, nr = self.n_ents * self.Ks, self.n_rels * self.Ks
         self._ne, self._nr = ne, nr
         self._off = (ne + 63) // 64 * 64
         self.p_flat = self._flat()
-        self.ent = self.p_flat[:ne].view(self.n_ents, self.K)
-        self.rel = self.p_flat[self._off:self._off + nr].view(self.n_rels, self.K)
+        self.ent = self.p_flat[:ne].view(self.n_ents, self.Ks)
+        self.rel = self.p_flat[self._off:self._off + nr].view(self.n_rels, self.Ks)
         self.g_flat = None
         self.slot_flat = {}
         self.g_ent = None
@@ -63,16 +69,39 @@ class KgeEngine:
         return torch.full((n,), float(fill), dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ tables
+    def pack(self, dense, out=None):
+        """dense rows [n, K] (device tensor or anything np.asarray takes) -> stored rows [n, Ks] (amdkge_pack_rows)."""
+        if not torch.is_tensor(dense):
+            dense = torch.as_tensor(np.ascontiguousarray(dense, dtype=np.float32))
+        dense = dense.to(self.device, torch.float32).contiguous()
+        if dense.ndim != 2 or int(dense.shape[1]) != self.K:
+            raise ValueError(f"rows must have {self.K} floats, got shape {tuple(dense.shape)}")
+        n = int(dense.shape[0])
+        if out is None:
+            out = torch.empty(n, self.Ks, dtype=torch.float32, device=self.device)
+        if tuple(out.shape) != (n, self.Ks) or not out.is_contiguous():
+            raise ValueError("pack: output must be a contiguous [n, Ks] tensor")
+        check(self.lib.amdkge_pack_rows(C.byref(self.model), _ptr(dense), n, _ptr(out), _stream()))
+        return out
+
+    def unpack(self, stored):
+        """stored rows [n, Ks] (device tensor) -> dense rows [n, K] (amdkge_unpack_rows)."""
+        stored = stored.contiguous()
+        n = int(stored.shape[0])
+        out = torch.empty(n, self.K, dtype=torch.float32, device=self.device)
+        check(self.lib.amdkge_unpack_rows(C.byref(self.model), _ptr(stored), n, _ptr(out), _stream()))
+        return out
+
     def set_tables(self, ent, rel):
-        ent = torch.as_tensor(np.ascontiguousarray(ent, dtype=np.float32))
-        rel = torch.as_tensor(np.ascontiguousarray(rel, dtype=np.float32))
+        """Dense [n_ents, K] / [n_rels, K] tables (the reference's layout) -> HBM."""
+        ent, rel = np.asarray(ent), np.asarray(rel)
         if tuple(ent.shape) != (self.n_ents, self.K) or tuple(rel.shape) != (self.n_rels, self.K):
             raise ValueError(f"table shapes must be {(self.n_ents, self.K)} and {(self.n_rels, self.K)}")
-        self.ent.copy_(ent)
-        self.rel.copy_(rel)
+        self.pack(ent, out=self.ent)
+        self.pack(rel, out=self.rel)
 
     def get_tables(self):
-        return self.ent.cpu().numpy(), self.rel.cpu().numpy()
+        return self.unpack(self.ent).cpu().numpy(), self.unpack(self.rel).cpu().numpy()
 
     # ------------------------------------------------------------------ training
     def prepare_training(self, optimizer="adam"):
@@ -150,7 +179,7 @@ class KgeEngine:
         """Dense sweep over both tables (optimizer + regulariser + gradient reset).  rows_e limits the entity
         sweep to the first rows_e rows (row-sharded mode: the rows behind them are fetched copies of remote
         rows); reg_slots = loss_acc slots receiving the entity / relation regulariser values."""
-        n_e = self.ent.numel() if rows_e is None else int(rows_e) * self.K
+        n_e = self.ent.numel() if rows_e is None else int(rows_e) * self.Ks
         for x, g, table, lam, n_el, slot in ((self.ent, self.g_ent, "e", reg_e, n_e, reg_slots[0]),
                                              (self.rel, self.g_rel, "r", reg_r, self.rel.numel(), reg_slots[1])):
             reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(slot))

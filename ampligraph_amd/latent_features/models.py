@@ -166,21 +166,20 @@ class ScoringBasedEmbeddingModel:
         else:
             self._engine = KgeEngine(self.scoring_type, self.k, n_ents, n_rels, max_rel_size=n_rels)
         self._upload_rows(self._engine.ent, ent_rows, lo, hi)
-        self._engine.rel.copy_(torch.as_tensor(np.ascontiguousarray(rel, dtype=np.float32)))
+        self._engine.pack(rel, out=self._engine.rel)
         self._full_ent = None
 
-    @staticmethod
-    def _upload_rows(dst, rows, lo, hi, chunk_elems=1 << 24):
-        """dst[0 : hi-lo] <- rows(lo, hi), in host chunks of <= chunk_elems floats (C5 shards do not fit host RAM twice)."""
-        import torch
-
-        step = max(1, chunk_elems // int(dst.shape[1]))
+    def _upload_rows(self, dst, rows, lo, hi, chunk_elems=1 << 24):
+        """dst[0 : hi-lo] <- rows(lo, hi) (dense rows, packed into the engine's stored layout), in host chunks of
+        <= chunk_elems floats (C5 shards do not fit host RAM twice)."""
+        eng = self._engine
+        step = max(1, chunk_elems // eng.K)
         for r0 in range(int(lo), int(hi), step):
             r1 = min(int(hi), r0 + step)
             blk = np.ascontiguousarray(rows(r0, r1), dtype=np.float32)
-            if blk.shape != (r1 - r0, int(dst.shape[1])):
-                raise ValueError(f"table rows have shape {blk.shape}, expected {(r1 - r0, int(dst.shape[1]))}")
-            dst[r0 - lo:r1 - lo].copy_(torch.as_tensor(blk))
+            if blk.shape != (r1 - r0, eng.K):
+                raise ValueError(f"table rows have shape {blk.shape}, expected {(r1 - r0, eng.K)}")
+            eng.pack(blk, out=dst[r0 - lo:r1 - lo])
 
     def _dist(self):
         if self._dist_override is not None:
@@ -203,14 +202,15 @@ class ScoringBasedEmbeddingModel:
         return loop
 
     def _entity_table(self):
-        """(N, K) entity table as a device tensor (row-sharded mode: gathered once and cached until the next fit)."""
+        """(N, Ks) entity table in the engine's STORED layout as a device tensor (row-sharded mode: gathered once and
+        cached until the next fit); engine.unpack() gives dense rows."""
         if self._spec is None:
             return self._engine.ent
         if self._full_ent is None:
             import torch
 
             sp, eng = self._spec, self._engine
-            mine = torch.zeros(sp.rows_per, eng.K, dtype=eng.ent.dtype, device=eng.ent.device)
+            mine = torch.zeros(sp.rows_per, eng.Ks, dtype=eng.ent.dtype, device=eng.ent.device)
             mine[:sp.n_local] = eng.ent[:sp.n_local]
             parts = [torch.empty_like(mine) for _ in range(sp.world)]
             self._dist().all_gather(parts, mine)
@@ -538,7 +538,7 @@ class ScoringBasedEmbeddingModel:
         import torch
 
         tab = self._entity_table() if embedding_type == "e" else self._engine.rel
-        return tab[torch.as_tensor(idx).to(tab.device)].cpu().numpy()
+        return self._engine.unpack(tab[torch.as_tensor(idx).to(tab.device)]).cpu().numpy()
 
     # ------------------------------------------------------------------------------------ calibration
     def calibrate(self, X_pos, X_neg=None, positive_base_rate=None, batch_size=32, epochs=50, verbose=0):
@@ -639,35 +639,46 @@ class ScoringBasedEmbeddingModel:
         arrays = {}
         if self._spec is not None:
             sp = self._spec
-            mine = {"ent": eng.ent[:sp.n_local].cpu().numpy(), "lo": np.int64(sp.lo), "hi": np.int64(sp.hi)}
+            dense = lambda t: eng.unpack(t).cpu().numpy()   # noqa: E731  checkpoints hold dense rows, whatever the engine stores
+            mine = {"ent": dense(eng.ent[:sp.n_local]), "lo": np.int64(sp.lo), "hi": np.int64(sp.hi)}
             for kname, t in getattr(eng, "slots", {}).items():
                 if kname.endswith("_e"):
-                    mine["slot_" + kname] = t[:sp.n_local].cpu().numpy()
+                    mine["slot_" + kname] = dense(t[:sp.n_local])
             np.savez(self._shard_file(filepath, sp.rank, sp.world), **mine)
-            arrays = {"rel": eng.rel.cpu().numpy(), "shard_world": np.int64(sp.world), "n_ents": np.int64(sp.n_ents)}
+            arrays = {"rel": dense(eng.rel), "shard_world": np.int64(sp.world), "n_ents": np.int64(sp.n_ents)}
             for kname, t in getattr(eng, "slots", {}).items():
                 if kname.endswith("_r"):
-                    arrays["slot_" + kname] = t.cpu().numpy()
+                    arrays["slot_" + kname] = dense(t)
             self._dist().barrier()
             if sp.rank != 0:
                 return
         else:
             if self._loop is not None and hasattr(self._loop, "sync_optimizer_slots"):
                 self._loop.sync_optimizer_slots()   # data-parallel sharded merge: collective, call on every rank
+            d = self._dist()
+            if d is not None and d.get_rank() != 0:
+                d.barrier()   # replicated tables: every rank holds the same bytes, rank 0 writes them (barrier: file complete)
+                return
             ent, rel = eng.get_tables()
             arrays = {"ent": ent, "rel": rel}
             for kname, t in getattr(eng, "slots", {}).items():
-                arrays["slot_" + kname] = t.cpu().numpy()
+                arrays["slot_" + kname] = eng.unpack(t).cpu().numpy()
         st = self.data_indexer.state()
         arrays["ent_raw"], arrays["rel_raw"] = st["ent_raw"], st["rel_raw"]
-        np.savez(filepath + ".npz", **arrays)
+        # written under a temporary name and renamed: a reader never sees a torn archive
+        with open(filepath + ".npz.tmp", "wb") as f:
+            np.savez(f, **arrays)
+        os.replace(filepath + ".npz.tmp", filepath + ".npz")
         meta = {"eta": self.eta, "k": self.k, "scoring_type": self.scoring_type, "seed": self.seed,
                 "optimizer": self.optimizer.get_config() if self.is_compiled else None,
                 "iterations": self.optimizer.iterations if self.is_compiled else 0,
                 "loss": {"name": self.loss.name, "params": self.loss._loss_parameters} if self.is_compiled else None,
                 "calibration": self.calibration_parameters if self.is_calibrated else None}
-        with open(filepath + ".json", "w") as f:
+        with open(filepath + ".json.tmp", "w") as f:
             json.dump(meta, f)
+        os.replace(filepath + ".json.tmp", filepath + ".json")
+        if self._spec is None and self._dist() is not None:
+            self._dist().barrier()
 
     def load_weights(self, filepath):
         """Whole-table or row-sharded checkpoint -> this model, whatever its own sharding (rows are re-sliced)."""
@@ -716,7 +727,7 @@ class ScoringBasedEmbeddingModel:
                 if kname.endswith("_e"):
                     self._upload_rows(eng.slots[kname], rows_of("slot_" + kname), lo, hi)
                 else:
-                    eng.slots[kname].copy_(torch.as_tensor(z["slot_" + kname]))
+                    eng.pack(z["slot_" + kname], out=eng.slots[kname])
             if os.path.exists(filepath + ".json"):
                 self.optimizer.iterations = int(json.load(open(filepath + ".json")).get("iterations", 0))
         if os.path.exists(filepath + ".json"):

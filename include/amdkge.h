@@ -12,6 +12,14 @@
  *   - plain C types only; every pointer named d_* is a DEVICE pointer (HBM), every other pointer
  *     is a host pointer.  Tables are fp32 row-major [rows, K]; K = k for TransE/DistMult and 2k
  *     ([re || im] halves) for ComplEx/HolE/RotatE.  Triples are int32 [n,3] row-major (s,p,o).
+ *   - STORED row layout: a model descriptor may declare a padded half width k_pad >= k (amdkge_model.k_pad);
+ *     every device table / gradient / optimizer-slot pointer of that model then has rows of
+ *     amdkge_row_floats(m) = NC * k_pad floats, [re(k_pad) || im(k_pad)], with the k_pad - k trailing units of
+ *     each half ZERO (they stay zero under every optimizer rule and regulariser; RotatE masks them in its
+ *     gradient, whose modulus has no epsilon, RotatE.py:102-104).  k_pad % 4 == 0 is what gives every k the
+ *     16-byte kernels (owner-computes train pair, pipelined MFMA rank kernel); amdkge_padded_k(k) returns the
+ *     smallest such value, amdkge_pack_rows / amdkge_unpack_rows convert to and from the dense [rows, NC*k] form
+ *     the reference's get_embeddings / checkpoints use.  k_pad == 0 means dense rows (k_pad = k).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All compute entry
  *     points are asynchronous on that stream; the caller owns synchronisation.
  *   - return value: 0 = ok, negative = error class below; amdkge_last_error() gives a message
@@ -26,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AMDKGE_ABI_VERSION 1
+#define AMDKGE_ABI_VERSION 2
 
 /* error classes */
 #define AMDKGE_OK 0
@@ -62,7 +70,7 @@ typedef struct amdkge_model {
     int64_t n_ents;         /* rows of the entity table */
     int64_t n_rels;         /* rows of the relation table */
     int32_t max_rel_size;   /* RotatE phase normaliser (RotatE.py:95); <=0 means "None" -> 1 */
-    int32_t reserved;
+    int32_t k_pad;          /* stored units per half (>= k), 0 = dense rows; see "STORED row layout" above */
 } amdkge_model;
 
 /* Loss hyper-parameters: loss_functions.py:76-117 (`hyperparam_dict`), defaults :23-35 */
@@ -106,6 +114,14 @@ int amdkge_stream_sync(void* stream);
 
 /* internal_k of a model (2k for ComplEx/HolE/RotatE) -- ComplEx.py:37, RotatE.py:57 */
 int amdkge_internal_k(int scoring_type, int k);
+/* smallest k_pad >= k with 16-byte-aligned halves (multiple of 4) */
+int amdkge_padded_k(int k);
+/* floats per STORED table row of a model: internal_k(scoring_type, k_pad ? k_pad : k); negative on a bad descriptor */
+int amdkge_row_floats(const amdkge_model* m);
+/* dense rows [n, internal_k(k)] (what EmbeddingLookupLayer holds, EmbeddingLookupLayer.py:307-342) <-> stored rows
+ * [n, amdkge_row_floats(m)].  pack zero-fills the padding.  d_src and d_dst must not overlap. */
+int amdkge_pack_rows(const amdkge_model* m, const float* d_dense, int64_t n, float* d_stored, void* stream);
+int amdkge_unpack_rows(const amdkge_model* m, const float* d_stored, int64_t n, float* d_dense, void* stream);
 
 /* predict(): EmbeddingLookupLayer.call + <Model>._compute_scores
  * (layers/encoding/EmbeddingLookupLayer.py:307-342; TransE.py:37, DistMult.py:34, ComplEx.py:39,
@@ -150,7 +166,7 @@ int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_s
  * of entity rows accumulates the staged row gradients in LDS and applies the optimizer + regulariser to its rows in
  * place.  Same reference code as amdkge_train_fwdbwd + amdkge_opt_step (ScoringBasedEmbeddingModel.py:370-429,
  * optimizers.py:136-168, regularizers.py:35-37) without global atomics or a dense gradient buffer for the entity
- * table (see `flags` for the skewed-graph variant).  Supported for all five models when k % 4 == 0 and k <= 2048 (amdkge_train_tiled_workspace_bytes returns 0
+ * table (see `flags` for the skewed-graph variant).  Supported for all five models when the STORED half width (k_pad, or k when k_pad == 0) is a multiple of 4 and <= 2048 (amdkge_train_tiled_workspace_bytes returns 0
  * otherwise and the call returns AMDKGE_EUNSUPPORTED).
  *   apply_update : 1 -> the entity table and its slots are updated in place (single GPU);
  *                0 -> d_grad_ent receives the complete entity gradient (every row written), the relation gradient is ADDED
@@ -198,6 +214,10 @@ int amdkge_platt_step(const float* d_scores_pos, int64_t n_pos, const float* d_s
  *   d_counts  : int32 [n,2], += (#corr with q(pos) < q(corr), #corr with q(pos) == q(corr))
  *   d_work    : scratch of amdkge_rank_workspace_bytes(m, n) bytes */
 int64_t amdkge_rank_workspace_bytes(const amdkge_model* m, int64_t n);
+/* Testing aid (process-wide): which tile kernel amdkge_rank_counts launches.  0 = automatic (the default: pipelined MFMA
+ * kernel for DistMult / ComplEx / HolE, VALU tile kernel for TransE / RotatE), 1 = always the VALU tile kernel, 2 = the
+ * first (un-pipelined) MFMA kernel.  All three produce the same bits; the parity tests compare them. */
+int amdkge_set_rank_kernel(int which);
 int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d_rel,
                        const int32_t* d_triples, int64_t n, int32_t side,
                        const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/amdkge.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
-    assert lib.amdkge_abi_version() == 1
+    assert lib.amdkge_abi_version() == 2
     assert lib.amdkge_internal_k(2, 200) == 400 and lib.amdkge_internal_k(0, 50) == 50
 
 
@@ -51,7 +51,13 @@ def test_abi_argument_validation_without_gpu():
     assert lib.amdkge_opt_step(ctypes.byref(o), None, None, None, None, 0, None, None) == -1   # iteration is 1-based
     o = _ffi.Opt(2, 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 1)
     assert lib.amdkge_opt_step(ctypes.byref(o), None, None, None, None, 0, None, None) == 0
-    assert lib.amdkge_train_tiled_workspace_bytes(ctypes.byref(m), 100, 5) == 0                 # k % 4 != 0: unsupported
+    assert lib.amdkge_train_tiled_workspace_bytes(ctypes.byref(m), 100, 5) == 0                 # dense rows with k % 4 != 0
+    mp = _ffi.Model(2, 10, 5, 5, 0, lib.amdkge_padded_k(10))                                    # ... padded to 12: supported
+    assert lib.amdkge_padded_k(10) == 12 and lib.amdkge_row_floats(ctypes.byref(mp)) == 24
+    assert lib.amdkge_train_tiled_workspace_bytes(ctypes.byref(mp), 100, 5) > 0
+    assert lib.amdkge_row_floats(ctypes.byref(_ffi.Model(2, 10, 5, 5, 0, 8))) == -1              # k_pad < k
+    assert lib.amdkge_pack_rows(ctypes.byref(mp), None, 0, None, None) == 0 and lib.amdkge_pack_rows(ctypes.byref(mp), None, 2, None, None) == -1
+    assert lib.amdkge_set_rank_kernel(3) == -1 and lib.amdkge_set_rank_kernel(0) == 0
     m4 = _ffi.Model(2, 200, 14505, 237, 0, 0)
     assert lib.amdkge_train_tiled_workspace_bytes(ctypes.byref(m4), 10000, 20) > 10000 * 4 * 400 * 4
     assert lib.amdkge_train_step_tiled(ctypes.byref(m4), None, ctypes.byref(o), *([None] * 6), 0.0, None, 1, 1, 0, 1,

@@ -57,7 +57,7 @@ def test_hip_path_against_golden(gpu_lib, model):
             for got_t, key in ((eng.g_ent, "g_ent"), (eng.g_rel, "g_rel")):
                 T = G[f"{model}/{ls}/{key}"]
                 scale = np.maximum(np.abs(T).max(axis=1, keepdims=True), 1e-6 * max(np.abs(T).max(), 1e-30))
-                assert (np.abs(got_t.cpu().numpy() - T) / scale).max() < 4e-5, (ls, path, key)
+                assert (np.abs(eng.unpack(got_t).cpu().numpy() - T) / scale).max() < 4e-5, (ls, path, key)
     if model != "RotatE":
         eng.set_tables(G[f"{model}/dy_ent"], G[f"{model}/dy_rel"])
         fl = [np.unique(np.concatenate([X[(X[:, 1] == t[1]) & (X[:, 2] == t[2]), 0], [t[0]]])).astype(np.int32) for t in X]

@@ -15,8 +15,8 @@ def _engine(model, k, N, R, seed=0):
     eng = KgeEngine(model, k, N, R, max_rel_size=R)
     g = torch.Generator(device="cuda").manual_seed(seed)
     lim = float(np.sqrt(6.0 / (N + eng.K)))
-    eng.ent.copy_((torch.rand(N, eng.K, device="cuda", generator=g) * 2 - 1) * lim)
-    eng.rel.copy_((torch.rand(R, eng.K, device="cuda", generator=g) * 2 - 1) * float(np.sqrt(6.0 / (R + eng.K))))
+    eng.pack((torch.rand(N, eng.K, device="cuda", generator=g) * 2 - 1) * lim, out=eng.ent)
+    eng.pack((torch.rand(R, eng.K, device="cuda", generator=g) * 2 - 1) * float(np.sqrt(6.0 / (R + eng.K))), out=eng.rel)
     return eng
 
 
@@ -40,7 +40,10 @@ def _rows_close(a, b, tol):
 
 @pytest.mark.parametrize("model,k,eta,N,R,B,loss", [("ComplEx", 200, 20, 14505, 237, 10000, "self_adversarial"),    # C2
                                                      ("DistMult", 400, 30, 40943, 11, 10000, "multiclass_nll"),      # C3
-                                                     ("TransE", 52, 5, 14505, 237, 10000, "pairwise"),               # C1 (k padded to 52)
+                                                     ("TransE", 52, 5, 14505, 237, 10000, "pairwise"),
+                                                     ("TransE", 50, 5, 14505, 237, 10000, "pairwise"),               # C1 (stored as 52 units)
+                                                     ("ComplEx", 350, 20, 14505, 237, 10000, "self_adversarial"),    # the reference's published k (experiments/config.json:43-52), stored as 352
+                                                     ("RotatE", 350, 20, 14505, 237, 4096, "self_adversarial"),
                                                      ("ComplEx", 200, 20, 123182, 37, 8192, "nll")])                 # C4
 def test_fullsize_train_paths_agree(gpu_lib, model, k, eta, N, R, B, loss):
     """The owner-computes pair (gradient-only form) and the atomic-scatter kernel are independent implementations of the
@@ -83,7 +86,7 @@ def test_fullsize_train_paths_agree(gpu_lib, model, k, eta, N, R, B, loss):
     assert float(eng.g_rel.abs().max()) == 0.0
 
 
-def test_fullsize_c3_eval_invariants(gpu_lib, monkeypatch):
+def test_fullsize_c3_eval_invariants(gpu_lib):
     """C3: DistMult k=400, 40 943 entities, 2 924 test triples, both sides (MFMA path)."""
     from ampligraph_amd import _ffi
     from ampligraph_amd.datasets import make_synthetic_kg
@@ -99,11 +102,12 @@ def test_fullsize_c3_eval_invariants(gpu_lib, monkeypatch):
     for side, nm, rng_fn, ids in ((_ffi.SIDE_S, "s", fi.subject_ranges, fi.s_ids), (_ffi.SIDE_O, "o", fi.object_ranges, fi.o_ids)):
         lo, hi = rng_fn(test)
         flt = (torch.as_tensor(lo).cuda(), torch.as_tensor(hi).cuda(), torch.as_tensor(ids).cuda())
-        monkeypatch.delenv("AMDKGE_RANK_PATH", raising=False)
         r_w, c_mfma, sub = eng.rank_side(Xd, side, "worst", flt)
-        monkeypatch.setenv("AMDKGE_RANK_PATH", "valu")
-        c_valu = eng.rank_side(Xd, side, "worst")[1]
-        monkeypatch.delenv("AMDKGE_RANK_PATH", raising=False)
+        try:
+            _ffi.check(gpu_lib.amdkge_set_rank_kernel(1))
+            c_valu = eng.rank_side(Xd, side, "worst")[1]
+        finally:
+            gpu_lib.amdkge_set_rank_kernel(0)
         assert torch.equal(c_mfma, c_valu)                       # exact-fp32 MFMA == VALU chain, bit for bit
         r_b = eng.rank_side(Xd, side, "best", flt)[0]
         r_m = eng.rank_side(Xd, side, "middle", flt)[0]

@@ -15,10 +15,12 @@ MODELS = list(O.MODELS)
 LOSSES = list(O.LOSS_DEFAULTS)
 
 
-def make_engine(model, k, N, R, seed=0, scale=None):
+def make_engine(model, k, N, R, seed=0, scale=None, pad=True):
+    """pad=True: the product's stored layout (halves padded to a multiple of 4 units, every k on the 16-byte kernels);
+    pad=False: dense rows through the same ABI (k % 4 != 0 then takes the scalar-load kernels)."""
     from ampligraph_amd.engine import KgeEngine
 
-    eng = KgeEngine(model, k, N, R, max_rel_size=R)
+    eng = KgeEngine(model, k, N, R, max_rel_size=R, pad=pad)
     rng = np.random.default_rng(seed)
     K = eng.K
     if scale is None:
@@ -29,6 +31,11 @@ def make_engine(model, k, N, R, seed=0, scale=None):
         rel = (rng.normal(size=(R, K)) * scale).astype(np.float32)
     eng.set_tables(ent, rel)
     return eng, ent, rel
+
+
+def dense(eng, t):
+    """device tensor of stored rows -> dense numpy rows (what the oracle speaks)"""
+    return eng.unpack(t).cpu().numpy()
 
 
 def rand_triples(rng, n, N, R):
@@ -53,7 +60,7 @@ def loss_desc(name, reduction="sum", **kw):
 
 # -------------------------------------------------------------------------------- wave reduction
 def test_library_loaded(gpu_lib):
-    assert gpu_lib.amdkge_abi_version() == 1
+    assert gpu_lib.amdkge_abi_version() == 2
     c = C.c_int(0)
     assert gpu_lib.amdkge_device_count(C.byref(c)) == 0 and c.value >= 1
 
@@ -115,7 +122,7 @@ def run_fwdbwd(eng, X, eta, loss_name, reduction, seed, step, negs=None):
     eng.train_fwdbwd(dev(X), eta, loss_desc(loss_name, reduction), seed, step,
                      neg_override=None if negs is None else dev(negs), pos_scores=ps, neg_scores=ns)
     torch.cuda.synchronize()
-    return (float(eng.loss_acc[0].item()), eng.g_ent.cpu().numpy(), eng.g_rel.cpu().numpy(),
+    return (float(eng.loss_acc[0].item()), dense(eng, eng.g_ent), dense(eng, eng.g_rel),
             ps.cpu().numpy(), ns.cpu().numpy())
 
 
@@ -145,13 +152,15 @@ def test_train_fwdbwd_parity(gpu_lib, model, loss):
         assert_grads_close(Gr, Tr)
 
 
+@pytest.mark.parametrize("pad", [False, True])
 @pytest.mark.parametrize("model,k", [("TransE", 50), ("TransE", 7), ("DistMult", 400), ("ComplEx", 200),
                                        ("ComplEx", 350), ("HolE", 100), ("RotatE", 1000), ("RotatE", 33),
-                                       ("ComplEx", 1024), ("DistMult", 2048)])
-def test_train_fwdbwd_geometries(gpu_lib, model, k):
-    """Every slot geometry (W waves x CH quads, VEC 1/2/4) against the oracle, incl. a ragged tail block."""
+                                       ("ComplEx", 1024), ("DistMult", 2048), ("RotatE", 350), ("HolE", 50)])
+def test_train_fwdbwd_geometries(gpu_lib, model, k, pad):
+    """Every slot geometry (W waves x CH quads, VEC 1/2/4) against the oracle, incl. a ragged tail block; dense rows
+    and the padded stored layout (RotatE's padding units must yield exact zero gradients, not 0/0)."""
     N, R, B, eta = 200, 4, 37, 5
-    eng, ent, rel = make_engine(model, k, N, R, scale=0.3 if k < 100 else 0.08)
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.3 if k < 100 else 0.08, pad=pad)
     rng = np.random.default_rng(4)
     X = rand_triples(rng, B, N, R)
     L, Ge, Gr, ps, ns = run_fwdbwd(eng, X, eta, "self_adversarial", "sum", seed=1, step=0)
@@ -195,7 +204,7 @@ def run_tiled_grads(eng, X, eta, loss_name, reduction, seed, step, negs=None, po
     eng.train_step_tiled(dev(X), eta, loss_desc(loss_name, reduction), d, seed, step, grad_only=True, pos_atomic=pos_atomic,
                          neg_override=None if negs is None else dev(negs), pos_scores=ps, neg_scores=ns)
     torch.cuda.synchronize()
-    return (float(eng.loss_acc[0].item()), eng.g_ent.cpu().numpy(), eng.g_rel.cpu().numpy(),
+    return (float(eng.loss_acc[0].item()), dense(eng, eng.g_ent), dense(eng, eng.g_rel),
             ps.cpu().numpy(), ns.cpu().numpy())
 
 
@@ -226,9 +235,13 @@ def test_tiled_gradients_parity(gpu_lib, model, loss, pos_atomic):
                                          ("DistMult", 4, 3), ("TransE", 512, 1000),
                                          # one positive per workgroup (k > 512): 1 and 2 quads per lane, ragged rows
                                          ("RotatE", 1000, 300), ("ComplEx", 1024, 150), ("DistMult", 2048, 90),
-                                         ("TransE", 600, 200), ("HolE", 516, 64), ("TransE", 2044, 50)])
+                                         ("TransE", 600, 200), ("HolE", 516, 64), ("TransE", 2044, 50),
+                                         # k % 4 != 0: the stored layout pads each half to a multiple of 4 units
+                                         ("TransE", 7, 300), ("TransE", 50, 14505), ("DistMult", 350, 500), ("ComplEx", 350, 700),
+                                         ("HolE", 350, 200), ("RotatE", 350, 300), ("RotatE", 33, 100), ("ComplEx", 50, 2000),
+                                         ("ComplEx", 3, 40), ("RotatE", 1001, 120), ("DistMult", 2047, 60)])
 def test_tiled_geometries(gpu_lib, model, k, N):
-    """1 and 2 quads per lane, one-row tiles, tiles larger than the table, ragged last tile."""
+    """1 and 2 quads per lane, one-row tiles, tiles larger than the table, ragged last tile, padded halves."""
     R, B, eta = 4, 37, 5
     eng, ent, rel = make_engine(model, k, N, R, scale=0.3 if k < 100 else 0.08)
     rng = np.random.default_rng(4)
@@ -244,8 +257,9 @@ def test_tiled_geometries(gpu_lib, model, k, N):
 def test_tiled_unsupported_shapes(gpu_lib):
     from ampligraph_amd import _ffi
 
+    assert make_engine("DistMult", 6, 50, 3, scale=0.1)[0].tiled_supported(10, 2)   # padded to 8 units by the engine
     for model, k in (("DistMult", 6), ("ComplEx", 2052), ("TransE", 7)):
-        eng, _, _ = make_engine(model, k, 50, 3, scale=0.1)
+        eng, _, _ = make_engine(model, k, 50, 3, scale=0.1, pad=False)   # dense rows: the ABI's own limits
         assert not eng.tiled_supported(10, 2)
         eng.prepare_training("sgd")
         with pytest.raises(_ffi.AmdKgeError):
@@ -315,7 +329,7 @@ def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg, pos_atomic):
         assert np.abs(e - st.ent).max() < 2.5e-2   # a sign flip of a ~0 gradient moves Adam by at most 2*lr
         for nme in st.slots:
             # RMSprop-with-momentum's lr*g/sqrt(r + eps) is as ill-conditioned at g ~ 0 as Adam's update: bulk comparison
-            ok = np.isclose(eng.slots[nme].cpu().numpy(), st.slots[nme], rtol=1e-3, atol=1e-6)
+            ok = np.isclose(dense(eng, eng.slots[nme]), st.slots[nme], rtol=1e-3, atol=1e-6)
             assert ok.mean() > (0.99 if opt == "rmsprop_mom" and nme.startswith("mom") else 0.9999), (nme, t, ok.mean())
 
 
@@ -341,7 +355,7 @@ def test_opt_step_parity(gpu_lib, name, hp, reg):
     from ampligraph_amd import _ffi
 
     N, R, k = 123, 3, 9   # 123*9 is not a multiple of 4: exercises the scalar tail
-    eng, ent, rel = make_engine("DistMult", k, N, R, scale=0.5)
+    eng, ent, rel = make_engine("DistMult", k, N, R, scale=0.5, pad=False)
     w, mk = make_optimizer(name, hp)
     eng.prepare_training(w.name)
     st = mk(ent, rel)
@@ -509,32 +523,41 @@ def test_rank_filter_consistent_with_tile_kernel(gpu_lib):
         assert (got == 1).all(), (model, got.min(), got.max())
 
 
+@pytest.mark.parametrize("pad", [True, False])
 @pytest.mark.parametrize("model,k,N,n", [("DistMult", 37, 130, 50), ("ComplEx", 200, 1000, 333), ("HolE", 66, 257, 129),
                                            ("DistMult", 400, 4100, 300), ("DistMult", 16, 300, 77), ("DistMult", 32, 300, 77),
-                                           ("ComplEx", 24, 300, 200), ("ComplEx", 2, 150, 40)])
-def test_rank_mfma_kernel_bitwise_equals_valu_kernel(gpu_lib, model, k, N, n, monkeypatch):
+                                           ("ComplEx", 24, 300, 200), ("ComplEx", 2, 150, 40), ("ComplEx", 350, 600, 150),
+                                           ("DistMult", 50, 500, 100), ("HolE", 7, 200, 64)])
+def test_rank_mfma_kernel_bitwise_equals_valu_kernel(gpu_lib, model, k, N, n, pad):
     """v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain: the MFMA tile kernels (the software-pipelined default for rows of
-    whole float4s, the first kernel otherwise / with AMDKGE_RANK_PATH=mfma0) must return exactly the (greater, equal)
-    counts of the VALU tile kernel on random fp32 tables (ragged tiles, both sides, subset; rows of 4..800 units: one
-    stage, a half-empty last stage, odd and even stage counts)."""
+    whole float4s -- every k in the padded stored layout --, the first kernel otherwise / with amdkge_set_rank_kernel(2))
+    must return exactly the (greater, equal) counts of the VALU tile kernel on random fp32 tables (ragged tiles, both
+    sides, subset; rows of 4..800 units: one stage, a half-empty last stage, odd and even stage counts).  The padded and
+    the dense layout must also agree with each other: padding units add exact zeros to the chain."""
     from ampligraph_amd import _ffi
 
     rng = np.random.default_rng(11)
-    eng, ent, rel = make_engine(model, k, N, 5, scale=0.3)
+    eng, ent, rel = make_engine(model, k, N, 5, scale=0.3, pad=pad)
+    other, _, _ = make_engine(model, k, N, 5, scale=0.3, pad=not pad)
     X = rand_triples(rng, n, N, 5)
     sub = dev(np.sort(rng.choice(N, N // 3, replace=False)).astype(np.int32))
-    for side in (_ffi.SIDE_S, _ffi.SIDE_O):
-        for ent_ids in (None, sub):
-            monkeypatch.delenv("AMDKGE_RANK_PATH", raising=False)
-            c_mfma = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
-            monkeypatch.setenv("AMDKGE_RANK_PATH", "mfma0")
-            c_mfma0 = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
-            monkeypatch.setenv("AMDKGE_RANK_PATH", "valu")
-            c_valu = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
-            assert (c_mfma == c_valu).all(), (model, side, np.abs(c_mfma - c_valu).max())
-            assert (c_mfma0 == c_valu).all(), (model, side, np.abs(c_mfma0 - c_valu).max())
-            m = N if ent_ids is None else int(ent_ids.shape[0])
-            assert (c_mfma.sum(1) <= m).all() and c_mfma.min() >= 0
+    try:
+        for side in (_ffi.SIDE_S, _ffi.SIDE_O):
+            for ent_ids in (None, sub):
+                _ffi.check(gpu_lib.amdkge_set_rank_kernel(0))
+                c_mfma = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
+                c_other = other.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
+                _ffi.check(gpu_lib.amdkge_set_rank_kernel(2))
+                c_mfma0 = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
+                _ffi.check(gpu_lib.amdkge_set_rank_kernel(1))
+                c_valu = eng.rank_side(dev(X), side, "worst", ent_ids=ent_ids)[1].cpu().numpy()
+                assert (c_mfma == c_valu).all(), (model, side, np.abs(c_mfma - c_valu).max())
+                assert (c_mfma0 == c_valu).all(), (model, side, np.abs(c_mfma0 - c_valu).max())
+                assert (c_other == c_valu).all(), (model, side, "padded vs dense layout")
+                m = N if ent_ids is None else int(ent_ids.shape[0])
+                assert (c_mfma.sum(1) <= m).all() and c_mfma.min() >= 0
+    finally:
+        gpu_lib.amdkge_set_rank_kernel(0)
 
 
 # -------------------------------------------------------------------------------- FocusE (a23)
@@ -575,8 +598,8 @@ def test_focuse_gradients_parity(gpu_lib, nl, model, k, path):
         assert np.allclose(ns.cpu().numpy(), sn, rtol=2e-5, atol=2e-5 * np.abs(sn).max())
         L = float(eng.loss_acc[0].item())
         assert abs(L - float(per.astype(np.float64).sum())) <= 2e-5 * max(1.0, abs(L)), (loss, nl, L)
-        assert_grads_close(eng.g_ent.cpu().numpy(), Te, tol=4e-5)
-        assert_grads_close(eng.g_rel.cpu().numpy(), Tr, tol=4e-5)
+        assert_grads_close(dense(eng, eng.g_ent), Te, tol=4e-5)
+        assert_grads_close(dense(eng, eng.g_rel), Tr, tol=4e-5)
 
 
 @pytest.mark.parametrize("model", ["ComplEx", "TransE"])

@@ -218,10 +218,10 @@ def test_row_sharded_engines_on_one_gpu(gpu_lib, model, k, negatives):
                 loop.step(Xt[b0:b0 + bs], step)
                 step += 1
         lossv = loop.mean_batch_loss()
-        full = loop.gather_entity_table().cpu().numpy()
+        full = eng.unpack(loop.gather_entity_table()).cpu().numpy()
         cs, _ = sharded_rank_counts(eng, sp, dist, torch.as_tensor(T).cuda(), _ffi.SIDE_S)
         co, _ = sharded_rank_counts(eng, sp, dist, torch.as_tensor(T).cuda(), _ffi.SIDE_O)
-        return full, eng.rel.cpu().numpy(), lossv, cs.cpu().numpy(), co.cpu().numpy()
+        return full, eng.unpack(eng.rel).cpu().numpy(), lossv, cs.cpu().numpy(), co.cpu().numpy()
 
     res = ThreadedWorld(W).run(body)
     full, relg, lossv, cs, co = res[0]
@@ -324,7 +324,7 @@ def test_model_row_sharded_matches_single_gpu(gpu_lib):
         assert np.allclose(pred, p1, rtol=1e-3, atol=1e-4)
     # the two replicas agree exactly with each other; ranks are compared on THEIR (gathered) tables
     assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4])
-    m1._engine.set_tables(_reorder(res[0][1], m1, ents), m1._engine.rel.cpu().numpy())
+    m1._engine.set_tables(_reorder(res[0][1], m1, ents), m1._engine.get_tables()[1])
     # relation tables differ by fp32 summation order only; compare ranks up to that noise
     rf1 = m1.evaluate(Xtest, use_filter={"train": X}, corrupt_side="s,o", verbose=False)
     assert (np.abs(rf1 - res[0][3]) <= 1).mean() > 0.97
@@ -557,7 +557,7 @@ def test_replicated_evaluate_splits_queries_over_ranks(gpu_lib):
         # same complete Adam state as the single-GPU run holds
         m._loop.sync_optimizer_slots()
         for nme in ("m_e", "v_e", "m_r", "v_r"):
-            a_, b_ = m._engine.slots[nme].cpu().numpy(), m1._engine.slots[nme].cpu().numpy()
+            a_, b_ = m._engine.unpack(m._engine.slots[nme]).cpu().numpy(), m1._engine.unpack(m1._engine.slots[nme]).cpu().numpy()
             assert np.allclose(a_, b_, rtol=2e-3, atol=1e-7), nme
         m._engine.set_tables(e1, r1)   # identical tables: DP training differs only by fp32 summation order
         return [m.evaluate(Xt, use_filter=True, corrupt_side="s,o", verbose=False),
