@@ -15,6 +15,9 @@ class FilterIndex:
             np.zeros((0, 3), dtype=np.int64)
         self.n_ents, self.n_rels = int(n_ents), int(n_rels)
         N, R = self.n_ents, self.n_rels
+        if R * N * N >= 2 ** 63:   # (python ints: no wrap) the packed int64 sort keys below would overflow silently
+            raise ValueError(f"FilterIndex: n_rels * n_ents^2 = {R * N * N} does not fit the packed int64 keys "
+                             "(n_ents up to ~96 M at 1 000 relations)")
         s, p, o = X[:, 0], X[:, 1], X[:, 2]
         # subject side: group by (p,o), values s (unique)
         k_s = np.unique((p * N + o) * N + s)

@@ -27,7 +27,7 @@ def train_test_split_no_unseen(X, test_size=100, seed=0, allow_duplication=False
         order = np.random.permutation(np.arange(cand.shape[0]))
         idx_test, idx_train = [], []
         for i, idx in enumerate(order):
-            s, p, o = cand[idx].tolist()
+            s, p, o = cand[idx][:3].tolist()   # rows may carry numeric edge columns behind s, p, o (FocusE): only the triple counts
             e_left[s] -= 1
             r_left[p] -= 1
             e_left[o] -= 1

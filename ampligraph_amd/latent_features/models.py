@@ -181,6 +181,32 @@ class ScoringBasedEmbeddingModel:
                 raise ValueError(f"table rows have shape {blk.shape}, expected {(r1 - r0, eng.K)}")
             eng.pack(blk, out=dst[r0 - lo:r1 - lo])
 
+    def _ensure_shard_capacity(self, batch_size):
+        """Row-sharded mode, continued training: the scratch rows behind the shard were sized for the first fit()'s
+        batch (or for the default batch by load_weights); a larger batch gets a larger engine, tables and optimizer
+        state carried over."""
+        if self._spec is None:
+            return
+        from ..engine import KgeEngine
+        from ..sharded import ShardedStepLoop
+
+        sp, old = self._spec, self._engine
+        per_rank = -(-int(batch_size) // sp.world)
+        need = max(ShardedStepLoop.rows_needed(per_rank, self.eta, self._sharded_negatives), 2 * self.EVAL_CHUNK_SHARDED)
+        if need <= int(old.ent.shape[0]) - sp.n_local:
+            return
+        new = KgeEngine(self.scoring_type, self.k, sp.n_local + need, self._n_rels, max_rel_size=self._n_rels)
+        new.ent[:sp.n_local].copy_(old.ent[:sp.n_local])
+        new.rel.copy_(old.rel)
+        old_slots = dict(getattr(old, "slots", {}))
+        self._engine = new
+        self._loop = self._make_loop() if self.is_compiled else None   # allocates fresh slots on the new engine
+        for name, t in old_slots.items():
+            if name in new.slots:
+                (new.slots[name][:sp.n_local] if name.endswith("_e") else new.slots[name]).copy_(
+                    t[:sp.n_local] if name.endswith("_e") else t)
+        self._full_ent = None
+
     def _dist(self):
         if self._dist_override is not None:
             return self._dist_override if self._dist_override.get_world_size() > 1 else None
@@ -278,10 +304,14 @@ class ScoringBasedEmbeddingModel:
             self._build(self.data_indexer.get_entities_count(), self.data_indexer.get_relations_count(), batch_size)
         else:  # continue training (initial_epoch > 0): same id map, same tables
             Xi = self.data_indexer.get_indexes(X[:, :3])
+            self._ensure_shard_capacity(batch_size)
         eng = self._engine
         if self._loop is None:
             self._loop = self._make_loop()
         loop = self._loop
+        # negatives are keyed by a step counter that continues where the optimizer's iteration count stands: a run resumed
+        # from a checkpoint draws what the uninterrupted run would have drawn, and a second fit() draws fresh negatives
+        rng_base = int(self.optimizer.iterations)
         self._full_ent = None
         if hasattr(loop, "configure_for_data"):
             loop.configure_for_data(Xi, batch_size)
@@ -318,16 +348,16 @@ class ScoringBasedEmbeddingModel:
                 # AMDKGE_DP_MERGE=auto: the first steps of this epoch are run under each gradient-merge schedule and the
                 # fastest is kept (StepLoop.tune_merge; every schedule computes the same update).  The epoch's reported
                 # loss then covers the remaining steps only.
-                base = epoch * steps
+                base = rng_base
                 first = loop.tune_merge(lambda s_: train[(s_ - base) * batch_size:(s_ - base + 1) * batch_size], base)
                 loop.auto_tune = False
             for step in range(first, steps):
                 b0 = step * batch_size
                 if focus_dev is not None:
                     focus = (focus_dev[b0:b0 + batch_size], self.focusE_params["structural_wt"], self.focusE_params["non_linearity"])
-                    loop.step(train[b0:b0 + batch_size], epoch * steps + step, focus)
+                    loop.step(train[b0:b0 + batch_size], rng_base + (epoch - int(initial_epoch)) * steps + step, focus)
                 else:
-                    loop.step(train[b0:b0 + batch_size], epoch * steps + step)
+                    loop.step(train[b0:b0 + batch_size], rng_base + (epoch - int(initial_epoch)) * steps + step)
             logs = {"loss": loop.mean_batch_loss()}
             validate = (epoch >= (validation_burn_in - 1) and validation_data is not None
                         and (epoch + 1) % int(validation_freq) == 0)

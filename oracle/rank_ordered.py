@@ -1,0 +1,231 @@
+"""TEST INFRASTRUCTURE -- second oracle mode for evaluate(): fp32 in a DECLARED order.
+
+`oracle/kge_oracle.py` restates AbstractScoringLayer.get_ranks (AbstractScoringLayer.py:156-422) with fp64
+accumulation: order-free, but neither the reference's fp32 bits nor anybody else's, so ranks on real-valued tables
+could only be compared up to "fragile" comparisons at the int32(score * 1000) truncation boundary
+(AbstractScoringLayer.py:11,201).  The reference's own fp32 order is unspecified (Eigen reductions; its CPU and GPU
+kernels differ).  This module fixes ONE order -- the one the HIP rank kernels declare (ampligraph_amd/csrc/kge_rank.hip)
+-- and restates it on the CPU, so that filtered ranks are comparable BIT FOR BIT at full size:
+
+  * query vectors and the positive's score in fp32 exactly where the reference rounds them (TransE.py:77-83,107-113,
+    DistMult.py:71-73,96-98, ComplEx.py:93-107,138-150): numpy float32 element-wise operations below;
+  * the positive's reduce_sum as: unit c goes to slot c % 64, each slot sums its units in increasing c, the 64 slot
+    sums are combined by a fixed pairwise tree (the wave64 DPP reduction of kge_device.h: neighbours within rows of
+    16, then rows 0+1 and 2+3, then the two halves);
+  * the 1-vs-all corruption scores as one accumulator per (query, entity) walked in table order with a fused
+    multiply-add (contraction models) or add-of-absolute-value (TransE) per unit: oracle/csrc/rank_ordered.c.
+
+RotatE is restated too, but its kernels use the hardware cos/sin/sqrt (1 ulp), so only the contraction models and
+TransE are bit-comparable; RotatE stays on the fragile-bounded comparison.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import kge_oracle as O
+
+F32 = np.float32
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "librank_ordered.so")
+_SRC = os.path.join(_HERE, "csrc", "rank_ordered.c")
+MODE_DOT, MODE_L1, MODE_ROT_O, MODE_ROT_S, MODE_L1_SUB = 0, 1, 2, 3, 4
+_lib = None
+
+
+def build():
+    """gcc over oracle/csrc (oracle/Makefile)."""
+    subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO) or (os.path.exists(_SRC) and os.path.getmtime(_SRC) > os.path.getmtime(_SO)):
+            build()
+        h = C.CDLL(_SO)
+        P, I64 = C.c_void_p, C.c_int64
+        h.ro_counts.restype = None
+        h.ro_counts.argtypes = [C.c_int, P, I64, C.c_int, P, I64, C.c_int, C.c_int, P, I64, P, I64, C.c_float, P]
+        h.ro_pair_qscores.restype = None
+        h.ro_pair_qscores.argtypes = [C.c_int, P, I64, C.c_int, P, I64, C.c_int, C.c_int, P, P, I64, C.c_float, P]
+        _lib = h
+    return _lib
+
+
+def wave_sum(x):
+    """Sum over the last axis (64 fp32 slot sums) in the order of kge_device.h wave_sum (DPP row_shr 1, 2, 4, 8, then
+    row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; the total is lane 63)."""
+    v = np.ascontiguousarray(x, dtype=F32).copy()
+    assert v.shape[-1] == 64
+    r = v.reshape(v.shape[:-1] + (4, 16))
+    for sh in (1, 2, 4, 8):
+        add = np.zeros_like(r)
+        add[..., sh:] = r[..., :-sh]
+        r = (r + add).astype(F32)
+    d15, d31, d47, d63 = r[..., 0, 15], r[..., 1, 15], r[..., 2, 15], r[..., 3, 15]
+    return ((d63 + d47).astype(F32) + (d31 + d15).astype(F32)).astype(F32)
+
+
+def _slot_sum(units):
+    """[n, k] per-unit contributions -> [n] : slot c % 64 accumulates its units in increasing c, then wave_sum."""
+    n, k = units.shape
+    part = np.zeros((n, 64), dtype=F32)
+    for c0 in range(0, k, 64):
+        blk = units[:, c0:c0 + 64]
+        part[:, :blk.shape[1]] = (part[:, :blk.shape[1]] + blk).astype(F32)
+    return wave_sum(part)
+
+
+def prep(model, side, s, p, o, max_rel_size=None):
+    """rank_prep_kernel: (qpos int32 [n], Q fp32 [n, QW], mode, U, qplane/eplane, sgn_scale) for dense rows s, p, o."""
+    s, p, o = (np.ascontiguousarray(a, dtype=F32) for a in (s, p, o))
+    n, K = s.shape
+    if model == "TransE":
+        pos = _slot_sum(np.abs(((s + p).astype(F32) - o).astype(F32)))
+        Q = (p - o).astype(F32) if side == "s" else (s + p).astype(F32)     # TransE.py:77-83 / 107-113
+        return O.quantise(F32(-1.0) * pos), Q, (MODE_L1 if side == "s" else MODE_L1_SUB), K, 0, F32(-1.0)
+    if model == "DistMult":
+        pos = _slot_sum((((s * p).astype(F32)) * o).astype(F32))           # DistMult.py:48
+        Q = (p * o).astype(F32) if side == "s" else (s * p).astype(F32)     # :71-73 / :96-98
+        return O.quantise(pos), Q, MODE_DOT, K, 0, F32(1.0)
+    k = K // 2
+    sr, si, pr, pi, orr, oi = s[:, :k], s[:, k:], p[:, :k], p[:, k:], o[:, :k], o[:, k:]
+    m = lambda a, b: (a * b).astype(F32)   # noqa: E731
+    if model in ("ComplEx", "HolE"):
+        a = (m(pr, orr) + m(pi, oi)).astype(F32)
+        b = (m(pr, oi) - m(pi, orr)).astype(F32)
+        pos = _slot_sum((m(sr, a) + m(si, b)).astype(F32))                  # ComplEx.py:58-62
+        if side == "s":                                                    # ComplEx.py:93-107
+            Q = np.concatenate([a, b], 1)
+        else:                                                              # ComplEx.py:138-150
+            Q = np.concatenate([(m(sr, pr) - m(si, pi)).astype(F32), (m(si, pr) + m(sr, pi)).astype(F32)], 1)
+        scale = F32(2.0 / k) if model == "HolE" else F32(1.0)             # HolE.py:45
+        return O.quantise(scale * pos), np.ascontiguousarray(Q), MODE_DOT, K, 0, scale
+    # RotatE (RotatE.py:96-104,151-160,209-214) -- not bit-comparable with the kernels (hardware cos / sin / sqrt)
+    div = O.rotate_phase_divisor(k, max_rel_size)
+    phi = (pr / div).astype(F32)
+    c, sn = np.cos(phi).astype(F32), np.sin(phi).astype(F32)
+    re = ((m(sr, c) - m(si, sn)).astype(F32) - orr).astype(F32)
+    im = ((m(sr, sn) + m(si, c)).astype(F32) - oi).astype(F32)
+    pos = _slot_sum(np.sqrt((m(re, re) + m(im, im)).astype(F32)).astype(F32))
+    if side == "s":
+        Q = np.concatenate([c, sn, orr, oi], 1)
+        mode = MODE_ROT_S
+    else:
+        Q = np.concatenate([(m(sr, c) - m(si, sn)).astype(F32), (m(sr, sn) + m(si, c)).astype(F32)], 1)
+        mode = MODE_ROT_O
+    return O.quantise(F32(-1.0) * pos), np.ascontiguousarray(Q), mode, k, k, F32(-1.0)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def side_counts(model, side, ent, rel, triples, max_rel_size=None, ent_ids=None):
+    """((greater, equal) counts int32 [n, 2], context) of one corruption side against rows `ent_ids` (None: all)."""
+    triples = np.asarray(triples, dtype=np.int64)
+    ent = np.ascontiguousarray(ent, dtype=F32)
+    s, p, o = O.lookup(ent, np.ascontiguousarray(rel, dtype=F32), triples)
+    qpos, Q, mode, U, plane, scale = prep(model, side, s, p, o, max_rel_size)
+    Q = np.ascontiguousarray(Q, dtype=F32)
+    n = triples.shape[0]
+    counts = np.zeros((n, 2), dtype=np.int32)
+    ids = None if ent_ids is None else np.ascontiguousarray(ent_ids, dtype=np.int32)
+    m = ent.shape[0] if ids is None else ids.shape[0]
+    if n and m:
+        lib().ro_counts(mode, _ptr(Q), Q.shape[1], plane, _ptr(ent), ent.shape[1], plane, U, _ptr(ids), m,
+                        _ptr(np.ascontiguousarray(qpos, dtype=np.int32)), n, float(scale), _ptr(counts))
+    return counts, (qpos, Q, mode, U, plane, scale, ent)
+
+
+def filter_sub(ctx, filters, keep=None):
+    """#{f in filters[i] : qpos[i] <= q(score(i, f))} per triple (AbstractScoringLayer.py:292-303, always "<=").
+    keep: None or a boolean mask over entity ids (entities_subset: ids outside are dropped, :266-275)."""
+    qpos, Q, mode, U, plane, scale, ent = ctx
+    n = len(filters)
+    pq, pe = [], []
+    for i in range(n):
+        f = np.asarray(filters[i], dtype=np.int64).reshape(-1)
+        if keep is not None:
+            f = f[keep[f]]
+        pq.append(np.full(f.shape[0], i, dtype=np.int64))
+        pe.append(f)
+    pq = np.concatenate(pq) if pq else np.zeros(0, np.int64)
+    pe = np.concatenate(pe) if pe else np.zeros(0, np.int64)
+    out = np.zeros(pq.shape[0], dtype=np.int32)
+    if pq.shape[0]:
+        lib().ro_pair_qscores(mode, _ptr(Q), Q.shape[1], plane, _ptr(ent), ent.shape[1], plane, U, _ptr(pq), _ptr(pe),
+                              pq.shape[0], float(scale), _ptr(out))
+    sub = np.zeros(n, dtype=np.int64)
+    np.add.at(sub, pq, (qpos[pq] <= out).astype(np.int64))
+    return sub.astype(np.int32)
+
+
+def evaluate_ranks(model, ent, rel, triples, filters_s=None, filters_o=None, corrupt_side="s,o",
+                   ranking_strategy="worst", entities_subset=None, max_rel_size=None):
+    """Same contract as kge_oracle.evaluate_ranks (1-based int32 ranks (n, sides); "s+o" sums the sides), computed in the
+    declared fp32 order.  Dense tables."""
+    triples = np.asarray(triples, dtype=np.int64)
+    n = triples.shape[0]
+    ids = keep = None
+    if entities_subset is not None and len(entities_subset) > 0:
+        ids = np.asarray(entities_subset, dtype=np.int32)
+        keep = np.zeros(np.asarray(ent).shape[0], dtype=bool)
+        keep[ids] = True
+    cols = []
+    for side, flt in (("s", filters_s), ("o", filters_o)):
+        if side not in corrupt_side:
+            continue
+        counts, ctx = side_counts(model, side, ent, rel, triples, max_rel_size, ids)
+        gt, eq = counts[:, 0].astype(np.int64), counts[:, 1].astype(np.int64)
+        if ranking_strategy == "best":
+            r = gt
+        elif ranking_strategy == "middle":
+            r = gt + (eq + 1) // 2
+        else:
+            r = gt + eq
+        if flt is not None:
+            r = r - filter_sub(ctx, flt, keep)
+        cols.append(r)
+    if not cols:
+        return np.zeros((n, 0), dtype=np.int32)
+    r = np.stack(cols, 1)
+    if corrupt_side == "s+o":
+        r = r.sum(1, keepdims=True)
+    return (r + 1).astype(np.int32)
+
+
+def chain_scores_numpy(mode, Q, E, U, plane, scale):
+    """Pure-numpy restatement of the per-(query, entity) chain (fused multiply-add emulated exactly through a
+    round-to-odd fp64 sum) -- small cases only; pins the C code in tests/test_oracle_rank_ordered.py."""
+    Q, E = np.asarray(Q, dtype=F32), np.asarray(E, dtype=F32)
+    n, m = Q.shape[0], E.shape[0]
+    acc = np.zeros((n, m), dtype=F32)
+    for u in range(U):
+        if mode == MODE_DOT:
+            prod = Q[:, u].astype(np.float64)[:, None] * E[:, u].astype(np.float64)[None, :]   # exact: 24 x 24 bits
+            a = acc.astype(np.float64)
+            s = prod + a
+            bb = s - prod
+            err = (prod - (s - bb)) + (a - bb)                        # TwoSum: prod + a == s + err exactly
+            bits = s.view(np.int64)
+            odd = (bits & 1) == 1
+            toward = np.where(err > 0, np.inf, -np.inf)
+            s = np.where((err != 0) & ~odd, np.nextafter(s, toward), s)   # round to odd, then one rounding to fp32
+            acc = s.astype(F32)
+        elif mode in (MODE_L1, MODE_L1_SUB):
+            d = (Q[:, u][:, None] + E[:, u][None, :]).astype(F32) if mode == MODE_L1 else (Q[:, u][:, None] - E[:, u][None, :]).astype(F32)
+            acc = (acc + np.abs(d)).astype(F32)
+        elif mode == MODE_ROT_O:
+            re = (Q[:, u][:, None] - E[:, u][None, :]).astype(F32)
+            im = (Q[:, plane + u][:, None] - E[:, plane + u][None, :]).astype(F32)
+            acc = (acc + np.sqrt(((re * re).astype(F32) + (im * im).astype(F32)).astype(F32)).astype(F32)).astype(F32)
+        else:
+            c, sn, orr, oi = (Q[:, j * plane + u][:, None] for j in range(4))
+            e0, e1 = E[:, u][None, :], E[:, plane + u][None, :]
+            re = (((e0 * c).astype(F32) - (e1 * sn).astype(F32)).astype(F32) - orr).astype(F32)
+            im = (((e0 * sn).astype(F32) + (e1 * c).astype(F32)).astype(F32) - oi).astype(F32)
+            acc = (acc + np.sqrt(((re * re).astype(F32) + (im * im).astype(F32)).astype(F32)).astype(F32)).astype(F32)
+    return (F32(scale) * acc).astype(F32)

@@ -299,3 +299,73 @@ def test_table_beyond_2_31_elements(gpu_lib, model, k):
             ref = np.stack([(tq[:, None] < cq).sum(1), (tq[:, None] == cq).sum(1)], 1)
             _, counts, _ = eng.rank_side(Xd[:12], side, "worst", None, ent_lo=base, ent_hi=base + M)
             assert np.abs(counts.cpu().numpy() - ref).max() <= 2, nm
+
+
+@pytest.mark.parametrize("model,k,dataset,n_test", [("ComplEx", 200, "synth-fb15k237", None),     # C2: all 20 438 test triples
+                                                      ("DistMult", 400, "synth-wn18rr", None),      # C3: all 2 924 test triples
+                                                      ("HolE", 350, "synth-fb15k237", 3000),        # padded halves (350 -> 352)
+                                                      ("TransE", 50, "synth-fb15k237", 3000)])      # C1 shape, L1 chain
+def test_fullsize_filtered_ranks_bit_identical(gpu_lib, model, k, dataset, n_test):
+    """"Identical filtered ranks" (BASELINE.json north_star) at full size on REAL-VALUED tables: the HIP path against the
+    oracle's declared-order fp32 mode (oracle/rank_ordered.py: same rounding points, same accumulation order as
+    kge_rank.hip declares) -- every test triple, filter = train + valid + test, three tie strategies, four corrupt_side
+    forms, bit for bit.  (The fp64 oracle mode stays as the order-free cross-check in test_fullsize_ranks_against_oracle.)"""
+    from oracle import kge_oracle as O
+    from oracle import rank_ordered as RO
+
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.datasets import make_synthetic_kg
+    from ampligraph_amd.datasets.filters import FilterIndex
+    from ampligraph_amd.engine import KgeEngine
+
+    d = make_synthetic_kg(dataset)
+    N, R = d["n_ents"], d["n_rels"]
+    rng = np.random.default_rng(17)
+    K = O.internal_k(model, k)
+    # trained-table-like magnitudes: scores of a few units, thousands of distinct quantised values, some ties
+    ent = (rng.normal(size=(N, K)) * 0.25).astype(np.float32)
+    rel = (rng.normal(size=(R, K)) * 0.25).astype(np.float32)
+    test = d["test"] if n_test is None else d["test"][:n_test]
+    n = test.shape[0]
+    eng = KgeEngine(model, k, N, R, max_rel_size=R)
+    eng.set_tables(ent, rel)
+    fi = FilterIndex([d["train"], d["valid"], d["test"]], N, R)
+    Xd = torch.as_tensor(test).cuda()
+    gpu, ora = {}, {}
+    for side, nm, rng_fn, ids in ((_ffi.SIDE_S, "s", fi.subject_ranges, fi.s_ids), (_ffi.SIDE_O, "o", fi.object_ranges, fi.o_ids)):
+        lo, hi = rng_fn(test)
+        flt = (torch.as_tensor(lo).cuda(), torch.as_tensor(hi).cuda(), torch.as_tensor(ids).cuda())
+        _, counts, sub = eng.rank_side(Xd, side, "worst", flt)
+        gpu[nm] = (counts.cpu().numpy().astype(np.int64), sub.cpu().numpy().astype(np.int64))
+        lists = [ids[a:b] for a, b in zip(lo, hi)]
+        if nm == "s":   # the filter lists handed to the oracle are the reference's sets (graph_data_loader.py:287-350): spot-check
+            pick = rng.choice(n, 64, replace=False)
+            fs_ref, _ = O.filter_sets(test[pick], [d["train"], d["valid"], d["test"]])
+            assert all(np.array_equal(np.sort(lists[i]), np.sort(np.asarray(f))) for i, f in zip(pick, fs_ref))
+        oc, ctx = RO.side_counts(model, nm, ent, rel, test, R)
+        ora[nm] = (oc.astype(np.int64), RO.filter_sub(ctx, lists).astype(np.int64))
+        assert np.array_equal(gpu[nm][0], ora[nm][0]), (nm, "counts", int((gpu[nm][0] != ora[nm][0]).sum()))
+        assert np.array_equal(gpu[nm][1], ora[nm][1]), (nm, "filter subtraction")
+        assert len(np.unique(ora[nm][0][:, 0])) > min(n, N) // 50 and int(ora[nm][0][:, 1].sum()) >= 0   # a real ranking problem
+
+    def ranks(src, strat, cs):
+        cols = []
+        for nm in ("s", "o"):
+            if nm not in cs:
+                continue
+            (gt, eq), sub = (src[nm][0][:, 0], src[nm][0][:, 1]), src[nm][1]
+            r = gt if strat == "best" else (gt + (eq + 1) // 2 if strat == "middle" else gt + eq)
+            cols.append(r - sub)
+        r = np.stack(cols, 1)
+        return (r.sum(1, keepdims=True) if cs == "s+o" else r) + 1
+
+    for strat in ("worst", "best", "middle"):
+        for cs in ("s", "o", "s,o", "s+o"):
+            assert np.array_equal(ranks(gpu, strat, cs), ranks(ora, strat, cs)), (strat, cs)
+    # and through the product's own compose kernel (tie strategy + filter subtraction + 1)
+    for strat in ("worst", "best", "middle"):
+        got = torch.stack([eng.rank_side(Xd, sd, strat, (torch.as_tensor(f(test)[0]).cuda(), torch.as_tensor(f(test)[1]).cuda(), torch.as_tensor(i_).cuda()))[0]
+                           for sd, f, i_ in ((_ffi.SIDE_S, fi.subject_ranges, fi.s_ids), (_ffi.SIDE_O, fi.object_ranges, fi.o_ids))], 1).cpu().numpy()
+        assert np.array_equal(got, ranks(ora, strat, "s,o")), strat
+    mrr_g, mrr_o = float(np.mean(1.0 / ranks(gpu, "worst", "s,o"))), float(np.mean(1.0 / ranks(ora, "worst", "s,o")))
+    assert mrr_g == mrr_o

@@ -59,6 +59,9 @@ def test_evaluation_protocol_helpers():
     assert np.array_equal(te, te2) and np.array_equal(tr, tr2)  # seeded
     tr3, te3 = train_test_split_no_unseen(X, test_size=0.1, seed=1, filtered_test_predicates=["1", "2"])
     assert len(te3) == int(0.1 * np.isin(X[:, 1], ["1", "2"]).sum()) and set(te3[:, 1]) <= {"1", "2"}
+    X4 = np.concatenate([X, rng.random((400, 2)).astype(str)], 1)            # numeric edge columns behind the triple (FocusE input)
+    tr4, te4 = train_test_split_no_unseen(X4, test_size=50, seed=3)
+    assert tr4.shape == (350, 5) and te4.shape == (50, 5) and np.array_equal(te4[:, :3], te) and np.array_equal(tr4[:, :3], tr)
     chain = np.array([["a", "r", "b"], ["b", "r", "c"], ["c", "r", "d"]])   # every triple carries an entity seen once
     with pytest.raises(Exception):
         train_test_split_no_unseen(chain, test_size=2)
