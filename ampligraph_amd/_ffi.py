@@ -50,7 +50,8 @@ class Loss(C.Structure):
 
 class Opt(C.Structure):
     _fields_ = [("kind", C.c_int32), ("reg_p", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
-                ("beta2", C.c_float), ("epsilon", C.c_float), ("reg_lambda", C.c_float), ("iteration", C.c_int64)]
+                ("beta2", C.c_float), ("epsilon", C.c_float), ("reg_lambda", C.c_float), ("iteration", C.c_int64),
+                ("lazy", C.c_int32), ("row_floats", C.c_int32)]
 
 
 class SessionConfig(C.Structure):
@@ -99,6 +100,12 @@ SIGNATURES = {
     "amdkge_rank_filter": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, P, P, P, I64, I64, P, P, P]),
     "amdkge_rank_compose": (C.c_int, [P, P, I64, I32, P, I64, P]),
     "amdkge_filter_ranges": (C.c_int, [P, P, I64, P, I64, I32, I64, I64, P, P, P]),
+    "amdkge_shard_route_workspace_bytes": (I64, [I64, I64]),
+    "amdkge_shard_route": (C.c_int, [I64, I32, I32, P, I64, P, I64, I32, P, P, P, P, P, P]),
+    "amdkge_gather_rows": (C.c_int, [P, I32, P, I64, P, P]),
+    "amdkge_scatter_add_rows": (C.c_int, [P, I32, P, I64, P, P]),
+    "amdkge_opt_step_merged": (C.c_int, [C.POINTER(Opt), P, P, I32, I64, P, P, I64, P, P]),
+    "amdkge_synth_triples": (C.c_int, [U64, I64, I64, I64, I64, P, P]),
     "amdkge_session_create": (C.c_int, [C.POINTER(SessionConfig), C.POINTER(P)]),
     "amdkge_session_destroy": (None, [P]),
     "amdkge_session_set_rows": (C.c_int, [P, I32, I64, I64, P]),

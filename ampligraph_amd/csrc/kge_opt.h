@@ -14,6 +14,7 @@ struct OptArgs {
     double* reg_loss;
     float lr, lr_t, beta1, beta2, omb1, omb2, eps, lam;
     int kind, reg_p;
+    int lazy, row_floats;   // touched-rows mode (include/amdkge.h, amdkge_opt.lazy)
 };
 
 __device__ __forceinline__ float ipowf(float a, int p) {
@@ -120,12 +121,52 @@ __device__ __forceinline__ float opt_sweep(const OptArgs& a, int64_t first, int6
     return reg_acc;
 }
 
+// Touched-rows sweep: one wave per row (grid-stride over rows).  The wave first reads the gradient row and ORs "non-zero";
+// an all-zero row is left alone -- x, the slots and the regulariser are not even read.  A touched row is re-read from
+// cache and goes through the same opt_elem as the dense sweep, and its gradient row is reset.
+template <int KIND>
+__device__ __forceinline__ float opt_sweep_rows(const OptArgs& a, int64_t first_row, int64_t row_stride, int lane) {
+    const int nq = a.row_floats >> 2;
+    const int64_t rows = a.n / a.row_floats;
+    float reg_acc = 0.f;
+    for (int64_t r = first_row; r < rows; r += row_stride) {
+        const int64_t base = r * (int64_t)nq;
+        const float4* g4 = reinterpret_cast<const float4*>(a.g) + base;
+        bool nz = false;
+        for (int q = lane; q < nq; q += KGE_WAVE) {
+            const float4 g = g4[q];
+            nz |= (g.x != 0.f) | (g.y != 0.f) | (g.z != 0.f) | (g.w != 0.f);
+        }
+        if (!__ballot(nz)) continue;
+        float4* x4 = reinterpret_cast<float4*>(a.x) + base;
+        float4* m4 = reinterpret_cast<float4*>(a.s0) + base;
+        float4* v4 = reinterpret_cast<float4*>(a.s1) + base;
+        float4* gw4 = reinterpret_cast<float4*>(a.g) + base;
+        for (int q = lane; q < nq; q += KGE_WAVE) {
+            float4 x = x4[q], g = gw4[q];
+            float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
+            if constexpr (opt_nslots(KIND) >= 1) m = m4[q];
+            if constexpr (opt_nslots(KIND) == 2) v = v4[q];
+            opt_elem<KIND>(a, x.x, g.x, m.x, v.x, reg_acc);
+            opt_elem<KIND>(a, x.y, g.y, m.y, v.y, reg_acc);
+            opt_elem<KIND>(a, x.z, g.z, m.z, v.z, reg_acc);
+            opt_elem<KIND>(a, x.w, g.w, m.w, v.w, reg_acc);
+            x4[q] = x;
+            gw4[q] = make_float4(0, 0, 0, 0);
+            if constexpr (opt_nslots(KIND) >= 1) m4[q] = m;
+            if constexpr (opt_nslots(KIND) == 2) v4[q] = v;
+        }
+    }
+    return reg_acc;
+}
+
 // host-side: fill the derived fields of OptArgs from the ABI descriptor
 inline void fill_opt_args(OptArgs& a, const amdkge_opt* opt) {
     a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->epsilon;
     a.omb1 = (float)(1.0 - (double)opt->beta1);   // python: 1 - beta_1, cast to fp32 like the TF constant
     a.omb2 = (float)(1.0 - (double)opt->beta2);
     a.lam = opt->reg_lambda; a.kind = opt->kind; a.reg_p = opt->reg_p;
+    a.lazy = opt->lazy ? 1 : 0; a.row_floats = opt->row_floats;
     const double t = (double)opt->iteration;
     if (opt->kind == AMDKGE_OPT_ADAMAX) a.lr_t = (float)((double)opt->lr / (1.0 - pow((double)opt->beta1, t)));
     else a.lr_t = (float)((double)opt->lr * sqrt(1.0 - pow((double)opt->beta2, t)) / (1.0 - pow((double)opt->beta1, t)));
@@ -136,6 +177,8 @@ inline int validate_opt(const amdkge_opt* opt) {
     if (opt->kind < AMDKGE_OPT_SGD || opt->kind > AMDKGE_OPT_ADAMAX) return set_error(AMDKGE_EINVAL, "unknown optimizer kind");
     if (opt->iteration < 1) return set_error(AMDKGE_EINVAL, "optimizer iteration is 1-based");
     if (opt->reg_lambda != 0.f && opt->reg_p < 1) return set_error(AMDKGE_EINVAL, "regulariser p must be >= 1");
+    if (opt->lazy && (opt->row_floats < 4 || opt->row_floats % 4 != 0))
+        return set_error(AMDKGE_EINVAL, "lazy optimizer mode needs row_floats = amdkge_row_floats(model) of a padded layout (multiple of 4)");
     return AMDKGE_OK;
 }
 

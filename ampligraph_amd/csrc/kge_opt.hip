@@ -20,6 +20,19 @@ __global__ __launch_bounds__(256) void opt_kernel(OptArgs a) {
     }
 }
 
+// touched-rows variant (amdkge_opt.lazy): one wave per row, see opt_sweep_rows
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_rows_kernel(OptArgs a) {
+    const float reg_acc = opt_sweep_rows<KIND>(a, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4, threadIdx.x & 63);
+    if (a.reg_loss && a.lam != 0.f) {
+        __shared__ float red[4];
+        const float w = wave_sum(reg_acc);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(a.reg_loss, (double)a.lam * ((double)red[0] + red[1] + red[2] + red[3]));
+    }
+}
+
 }  // namespace kge
 
 using namespace kge;
@@ -37,10 +50,19 @@ extern "C" int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad,
     OptArgs a{};
     a.x = d_x; a.g = d_grad; a.s0 = d_slot0; a.s1 = d_slot1; a.n = n_elems; a.reg_loss = d_reg_loss;
     fill_opt_args(a, opt);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.lazy) {
+        if (n_elems % a.row_floats != 0) return set_error(AMDKGE_EINVAL, "opt_step: lazy mode sweeps whole rows (n_elems must be a multiple of row_floats)");
+        const int64_t rows = n_elems / a.row_floats;
+        unsigned gridr = (unsigned)((rows + 3) / 4 < 256 * 16 ? (rows + 3) / 4 : 256 * 16);
+#define KGE_OPT_LAUNCH_ROWS(KIND) hipLaunchKernelGGL(opt_rows_kernel<KIND>, dim3(gridr), dim3(256), 0, st, a)
+        KGE_OPT_DISPATCH(opt->kind, KGE_OPT_LAUNCH_ROWS)
+#undef KGE_OPT_LAUNCH_ROWS
+        return check_launch("opt_step(lazy)");
+    }
     const int64_t n4 = (n_elems + 3) / 4;
     unsigned grid = (unsigned)((n4 + 255) / 256);
     if (grid > 2048) grid = 2048;   // 256 CUs x 8 blocks, grid-stride beyond
-    hipStream_t st = (hipStream_t)stream;
 #define KGE_OPT_LAUNCH(KIND) hipLaunchKernelGGL(opt_kernel<KIND>, dim3(grid), dim3(256), 0, st, a)
     KGE_OPT_DISPATCH(opt->kind, KGE_OPT_LAUNCH)
 #undef KGE_OPT_LAUNCH

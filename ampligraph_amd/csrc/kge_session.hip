@@ -105,6 +105,7 @@ extern "C" int amdkge_session_create(const amdkge_session_config* cfg, amdkge_se
     s->cfg.model.k_pad = amdkge_padded_k(cfg->model.k);   // every k gets the 16-byte kernels; hosts only ever see dense rows
     s->K = amdkge_internal_k(cfg->model.scoring_type, cfg->model.k);
     s->Ks = row_floats(&s->cfg.model);
+    s->cfg.opt.row_floats = s->Ks;   // touched-rows mode (cfg.opt.lazy) sweeps whole stored rows
     const int64_t ne = cfg->model.n_ents * (int64_t)s->Ks, nr = cfg->model.n_rels * (int64_t)s->Ks;
     const int nslots = opt_nslots(cfg->opt.kind);
     auto fail = [&](int rc) { amdkge_session_destroy(s); return rc; };

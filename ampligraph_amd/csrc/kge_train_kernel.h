@@ -37,6 +37,7 @@ struct TrainArgs {
     // owner-computes (STAGE) outputs: see kge_train_tiled.hip
     float* stage_rows;       // [B][4][K]: gradient rows of the positive's s and o (unless pos_atomic), then the side rows A, B
     int pos_atomic;          // the positives' own s / o rows go through atomics into g_ent (skewed graphs)
+    uint8_t* touched;        // pos_atomic + lazy optimizer: byte per entity row, set for rows that received an atomic row-add
     StageEntry* st_lists;    // [n_tiles][cap] buckets of row-gradient entries, by owning tile
     StageEntry* st_ovf;      // overflow of full buckets
     int* st_counters;        // [(n_tiles + 1) * 32] bucket fill counts (128-byte stride), last = overflow count
@@ -844,6 +845,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
             if (a.pos_atomic) {
                 emit_row(a.g_ent + (int64_t)ps * a.K, gs, a.K, 1.f);
                 emit_row(a.g_ent + (int64_t)po * a.K, go, a.K, 1.f);
+                if (a.touched && ts == 0) { a.touched[ps] = 1; a.touched[po] = 1; }   // same value from every writer
             } else {
                 float* ps_ = a.stage_rows + ((int64_t)i * 4 + 0) * a.K;
                 float* po_ = a.stage_rows + ((int64_t)i * 4 + 1) * a.K;

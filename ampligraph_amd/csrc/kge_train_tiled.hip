@@ -51,6 +51,8 @@ struct TileArgs {
     float* g_ent;             // dense entity gradient buffer
     int apply_update;         // 1: optimizer applied from LDS; 0: g_ent receives the entity gradient (data parallel)
     int pos_atomic;           // g_ent holds the s / o rows of the positives (forward kernel's atomics): fold them in
+    int lazy;                 // touched-rows optimizer mode (amdkge_opt.lazy): rows without an entry keep their bits
+    uint8_t* touched;         // lazy + pos_atomic: rows the forward kernel's atomics touched (read, then cleared here)
     const float* rel;         // live relation table (TransE / RotatE side of the gradient)
     const float* rel_cs;      // RotatE: [R][cos(phase) || sin(phase)] of this step's relation table (rel_phase_kernel)
     const int32_t* triples;
@@ -126,6 +128,12 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
 #pragma unroll
             for (int h = 0; h < NC; ++h)
                 if (qok[c]) *reinterpret_cast<float4*>(acc + (size_t)r * a.K + qoff[c] + h * a.k) = make_float4(0, 0, 0, 0);
+    // touched-rows mode: one flag byte per (row, wave of the owning group) behind the accumulators.  Every wave of a group
+    // sees the same entries, so each keeps its own copy: written and read by the same wave, no synchronisation needed.
+    uint8_t* tflag = reinterpret_cast<uint8_t*>(acc + (size_t)a.tile_rows * a.K);
+    if (a.lazy)
+        for (int r = grp + G * lane; r < nrow; r += G * 64)
+            tflag[r * gw + wg] = (a.touched && a.touched[t0 + r]) ? 1 : 0;
 
     // side-row loads of one staged entry.  All arguments are wave-uniform.
     // Operand loads of one staged entry (all arguments wave-uniform): the staged side row and, for TransE / RotatE
@@ -160,6 +168,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         const int role = meta & 3;
         const int lr = (int)(meta >> 2);
         float* arow = acc + (size_t)lr * a.K;
+        if (a.lazy) tflag[lr * gw + wg] = 1;
         float4 out[CH][NC];
         if (TRILINEAR || role >= 2) {
 #pragma unroll
@@ -251,6 +260,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     constexpr int KIND = decltype(kind_c)::value;
     for (int r = grp; r < nrow; r += G) {
         const float* arow = acc + (size_t)r * a.K;
+        if (a.lazy && a.apply_update && !tflag[r * gw + wg]) continue;   // untouched row: x, slots, regulariser stay as they are
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if (!qok[c]) continue;
@@ -290,6 +300,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     }
     // ---- leave the bookkeeping zeroed for the next step: own bucket now, overflow count by the last tile ----
     __syncthreads();
+    if (a.touched)   // every wave has read its flags: clear the forward kernel's marks for the next step
+        for (int r = tid; r < nrow; r += TILE_THREADS) a.touched[t0 + r] = 0;
     if (tid == 0) {
         a.counters[tile * 32] = 0;
         __threadfence();
@@ -317,12 +329,12 @@ __global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict_
 // ---- plan: tile size, bucket capacity and workspace layout (shared by the two entry points) ------------------
 struct TiledPlan {
     int tile_rows, n_tiles, cap, ovf_cap;
-    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, total;
+    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, total;
 };
 
 // rows per tile: as many as fit the LDS budget, then shrunk so that the tiles fill whole waves of 256 CUs evenly
 static int pick_tile_rows(int64_t n_rows, int K) {
-    const size_t budget = 150 * 1024;
+    const size_t budget = 150 * 1024;   // accumulators; up to 4 KB of row flags (lazy mode) sit behind them
     int fit = (int)(budget / ((size_t)K * 4));
     if (fit < 1) return 0;
     if (fit > 4096) fit = 4096;
@@ -353,6 +365,7 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
     p.off_rows = o; o += up((size_t)B * 4 * K * 4);
     p.off_cs = o; o += up(m->scoring_type == AMDKGE_ROTATE ? (size_t)m->n_rels * K * 4 : 0);
+    p.off_touch = o; o += up((size_t)m->n_ents);   // byte per entity row (lazy optimizer + POS_ATOMIC), kept zero between steps
     p.total = o + 256;
     return true;
 }
@@ -400,8 +413,8 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     else rc = launch_forward<MODEL, 4, 2>(f, st);
     if (rc) return rc;
     // T: entity tiles (the owner applies the optimizer)
-    const size_t shmem_t = (size_t)te.tile_rows * te.K * 4;
     te.gw = f.nq <= 128 ? 1 : (f.nq <= 256 ? 4 : 8);
+    const size_t shmem_t = (size_t)te.tile_rows * te.K * 4 + (te.lazy ? (((size_t)te.tile_rows * te.gw + 15) & ~(size_t)15) : 0);
     // entries in flight per wave: bounded by the 128 VGPRs a 1024-thread workgroup leaves per lane (RotatE holds three
     // complex operand rows per entry)
     constexpr int U1 = TRILINEAR ? 8 : (MODEL == AMDKGE_ROTATE ? 2 : 4);
@@ -458,6 +471,8 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     StageEntry* ovf = (StageEntry*)(w + p.off_ovf);
     float* stage_rows = (float*)(w + p.off_rows);
     float* rel_cs = (float*)(w + p.off_cs);
+    const bool lazy = opt->lazy != 0;
+    uint8_t* touched = (lazy && apply_update && (flags & AMDKGE_TILED_POS_ATOMIC)) ? (uint8_t*)(w + p.off_touch) : nullptr;
 
     TrainArgs f{};
     f.ent = d_ent; f.rel = d_rel; f.triples = d_triples; f.neg_override = d_neg_override;
@@ -466,6 +481,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     f.sc = SampleCfg{sample_base, (uint32_t)sample_range, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step,
                      (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
     f.mc = model_const(m); f.loss = *loss;
+    f.touched = touched;
     f.stage_rows = stage_rows; f.st_lists = lists; f.st_ovf = ovf; f.st_counters = counters;
     f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap;
 #ifdef KGE_ABLATE
@@ -474,7 +490,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
 
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
-    te.rel_cs = rel_cs;
+    te.rel_cs = rel_cs; te.lazy = lazy ? 1 : 0; te.touched = touched;
     te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = ks; te.K = K; te.k_live = m->k; te.nq = ks / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;
@@ -483,7 +499,8 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     // and the tables are updated in place: the relation sweep rides in extra workgroups of the tile kernel.
     // TransE / RotatE tiles read live relation rows, so their relation sweep stays a separate launch behind.
     const bool rel_here = apply_update && d_rel_slot_ok;
-    const bool fuse_rel = rel_here && (m->scoring_type == AMDKGE_DISTMULT || m->scoring_type == AMDKGE_COMPLEX || m->scoring_type == AMDKGE_HOLE);
+    // (the touched-rows relation sweep is row-wise: it runs as its own launch behind the tiles)
+    const bool fuse_rel = rel_here && !lazy && (m->scoring_type == AMDKGE_DISTMULT || m->scoring_type == AMDKGE_COMPLEX || m->scoring_type == AMDKGE_HOLE);
     te.rel_blocks = 0;
     if (rel_here) {
         te.rel_opt = te.opt;
@@ -511,5 +528,6 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     if (rc != AMDKGE_OK || !rel_here || fuse_rel) return rc;
     amdkge_opt ro = *opt;
     ro.reg_lambda = rel_reg_lambda;
+    ro.row_floats = K;
     return amdkge_opt_step(&ro, d_rel, d_grad_rel, d_rel_slot0, d_rel_slot1, (int64_t)m->n_rels * K, d_reg_loss, stream);
 }

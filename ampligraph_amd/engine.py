@@ -61,6 +61,18 @@ class KgeEngine:
         self.loss_acc = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._work = None
         self._twork = None
+        self._bufs = {}
+
+    def _buf(self, name, shape, dtype):
+        """Reusable scratch tensor (grown on demand, never shrunk): the step loops allocate nothing per step."""
+        n = 1
+        for d_ in shape:
+            n *= int(d_)
+        t = self._bufs.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t[:n].view(*shape)
 
     def _flat(self, pad_to=64 * 16, fill=0.0):
         """Flat fp32 buffer [entity part | pad | relation part | pad]; total length a multiple of `pad_to` floats so that
@@ -163,6 +175,7 @@ class KgeEngine:
         s0, s1 = self._slots_of("e")
         r0, r1 = self._slots_of("r")
         opt_desc.reg_lambda = float(reg_e)
+        opt_desc.row_floats = self.Ks
         try:
             check(self.lib.amdkge_train_step_tiled(
                 C.byref(self.model), C.byref(loss), C.byref(opt_desc), _ptr(self.ent), _ptr(self.rel), _ptr(s0), _ptr(s1),
@@ -180,6 +193,7 @@ class KgeEngine:
         sweep to the first rows_e rows (row-sharded mode: the rows behind them are fetched copies of remote
         rows); reg_slots = loss_acc slots receiving the entity / relation regulariser values."""
         n_e = self.ent.numel() if rows_e is None else int(rows_e) * self.Ks
+        opt_desc.row_floats = self.Ks
         for x, g, table, lam, n_el, slot in ((self.ent, self.g_ent, "e", reg_e, n_e, reg_slots[0]),
                                              (self.rel, self.g_rel, "r", reg_r, self.rel.numel(), reg_slots[1])):
             reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(slot))
@@ -201,11 +215,75 @@ class KgeEngine:
             segs.append((a, b, reg_r))
         reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(reg_slot))
         names = _ffi.OPT_SLOTS[self.opt_kind]
+        if opt_desc.lazy:
+            raise ValueError("the touched-rows optimizer mode sweeps whole rows: use the all-reduce gradient merge")
         for a, b, lam in segs:
             opt_desc.reg_lambda = float(lam)
             sl = [self.slot_flat[n][a:b] for n in names] + [None, None]
             check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(self.p_flat[a:b]), _ptr(self.g_flat[a:b]), _ptr(sl[0]),
                                            _ptr(sl[1]), b - a, reg_ptr, _stream()))
+
+    # ------------------------------------------------------------------ multi-GPU data path (kge_shard.hip)
+    def shard_route(self, spec, triples, negs, cap):
+        """amdkge_shard_route: int32 device triples [b,3] (+ corruptions [nneg,3] or None) with GLOBAL ids -> the same in this
+        rank's local index space, plus the per-peer request lists.  Returns (xl, nl, send_ids [world*cap], counts [world+1]);
+        counts[world] is a sticky overflow flag (zeroed by zero_route_overflow)."""
+        b = int(triples.shape[0])
+        nneg = 0 if negs is None else int(negs.shape[0])
+        xl = self._buf("route_xl", (b, 3), torch.int32)
+        nl = self._buf("route_nl", (nneg, 3), torch.int32) if negs is not None else None
+        send_ids = self._buf("route_send", (spec.world * int(cap),), torch.int32)
+        counts = self._bufs.get("route_counts")
+        if counts is None or counts.numel() != spec.world + 1:
+            counts = self._bufs["route_counts"] = torch.zeros(spec.world + 1, dtype=torch.int32, device=self.device)
+        need = int(self.lib.amdkge_shard_route_workspace_bytes(b, nneg))
+        if need < 0:
+            raise ValueError("batch too large for one shard_route call")
+        work = self._buf("route_work", (need,), torch.uint8)
+        check(self.lib.amdkge_shard_route(spec.n_ents, spec.world, spec.rank, _ptr(triples), b, _ptr(negs), nneg, int(cap),
+                                          _ptr(xl), _ptr(nl), _ptr(send_ids), _ptr(counts), _ptr(work), _stream()))
+        return xl, nl, send_ids, counts
+
+    def gather_rows(self, table, idx, name="gathered"):
+        """rows table[idx] (idx < 0: zero rows) into a reusable [n, Ks] buffer (amdkge_gather_rows)."""
+        n = int(idx.shape[0])
+        out = self._buf(name, (n, int(table.shape[1])), torch.float32)
+        check(self.lib.amdkge_gather_rows(_ptr(table), int(table.shape[1]), _ptr(idx), n, _ptr(out), _stream()))
+        return out
+
+    def scatter_add_rows(self, table, idx, src):
+        """table[idx[j]] += src[j] (idx < 0 skipped) (amdkge_scatter_add_rows)."""
+        check(self.lib.amdkge_scatter_add_rows(_ptr(table), int(table.shape[1]), _ptr(idx), int(idx.shape[0]), _ptr(src), _stream()))
+
+    def zero_(self, t):
+        """hipMemsetAsync on the launch stream (no torch op in the step loops)."""
+        if t.numel():
+            check(self.lib.amdkge_dev_memset(_ptr(t), 0, t.numel() * t.element_size(), _stream()))
+
+    def opt_step_merged(self, opt_desc, lo, hi, parts, n_parts, part_stride, reg_e=0.0, reg_r=0.0, reg_slot=1):
+        """Sharded-optimizer data parallelism: sweep elements [lo, hi) of the flat parameter vector with the gradient
+        sum_q parts[q * part_stride + (i - lo)] (amdkge_opt_step_merged: the W partial slices are summed inside the sweep)."""
+        segs = []
+        a, b = max(lo, 0), min(hi, self._ne)
+        if b > a:
+            segs.append((a, b, reg_e))
+        a, b = max(lo, self._off), min(hi, self._off + self._nr)
+        if b > a:
+            segs.append((a, b, reg_r))
+        reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(reg_slot))
+        names = _ffi.OPT_SLOTS[self.opt_kind]
+        for a, b, lam in segs:
+            opt_desc.reg_lambda = float(lam)
+            sl = [self.slot_flat[n][a:b] for n in names] + [None, None]
+            check(self.lib.amdkge_opt_step_merged(C.byref(opt_desc), _ptr(self.p_flat[a:b]), _ptr(parts[a - lo:]), int(n_parts),
+                                                  int(part_stride), _ptr(sl[0]), _ptr(sl[1]), b - a, reg_ptr, _stream()))
+
+    def synth_triples(self, seed, first_row, n, n_ents, n_rels, out=None):
+        """int32 [n,3] triples number first_row .. of the counter-based synthetic stream (amdkge_synth_triples)."""
+        if out is None:
+            out = torch.empty(int(n), 3, dtype=torch.int32, device=self.device)
+        check(self.lib.amdkge_synth_triples(int(seed), int(first_row), int(n), int(n_ents), int(n_rels), _ptr(out), _stream()))
+        return out
 
     def sample_corruptions(self, triples, eta, seed, step, sample_base=0, sample_range=None,
                            row_offset=0, b_global=0):

@@ -92,9 +92,13 @@ class ScoringBasedEmbeddingModel:
         """:1145-1152.  optimizer: name | OptimizerWrapper; loss: name | Loss; initializer: one value or
         [entity_init, relation_init]; regularizer: None | 'LP'/'l1'/'l2'/'l3' | LPRegularizer | pair.
 
-        Extra keywords of this engine (multi-GPU, one process per GPU under torch.distributed):
+        Extra keywords of this engine: optimizer_mode="dense" (default, the reference's semantics) | "lazy" (touched rows
+        only; see amdkge_opt.lazy).  Multi-GPU, one process per GPU under torch.distributed:
         entity_sharding="replicated" (default: tables replicated, gradient all-reduce) | "rows" (entity table
         row-sharded over the ranks, ampligraph_amd/sharded.py); sharded_negatives="local" | "global"."""
+        optimizer_mode = kwargs.pop("optimizer_mode", "dense")
+        if optimizer_mode not in ("dense", "lazy"):
+            raise ValueError("optimizer_mode must be 'dense' (the reference's behaviour) or 'lazy' (touched rows only)")
         self._sharding = kwargs.pop("entity_sharding", "replicated")
         self._sharded_negatives = kwargs.pop("sharded_negatives", "local")
         if self._sharding not in ("replicated", "rows"):
@@ -102,6 +106,10 @@ class ScoringBasedEmbeddingModel:
         if self._sharded_negatives not in ("local", "global"):
             raise ValueError("sharded_negatives must be 'local' or 'global'")
         self.optimizer = optimizers.get(optimizer)
+        if optimizer_mode == "lazy":
+            # DEVIATION from the reference (its optimizer is dense, optimizers.py:136-168): only rows that received a
+            # gradient this step are updated and regularised -- TF-Addons LazyAdam semantics (amdkge_opt.lazy)
+            self.optimizer.lazy = True
         if loss is None:
             raise ValueError("compile(): a loss is required")
         self.loss = loss_functions.get(loss)
@@ -160,7 +168,8 @@ class ScoringBasedEmbeddingModel:
             # same initial values as one GPU: rows [lo, hi) of the whole-table draw
             sp = self._spec = ShardSpec(n_ents, d.get_world_size(), d.get_rank())
             per_rank = -(-int(batch_size or 1000) // sp.world)
-            cap = max(ShardedStepLoop.rows_needed(per_rank, self.eta, self._sharded_negatives), 2 * self.EVAL_CHUNK_SHARDED)
+            cap = max(ShardedStepLoop.rows_needed(per_rank, self.eta, self._sharded_negatives, sp.world, n_ents),
+                      2 * self.EVAL_CHUNK_SHARDED)
             self._engine = KgeEngine(self.scoring_type, self.k, sp.n_local + cap, n_rels, max_rel_size=n_rels)
             lo, hi = sp.lo, sp.hi
         else:
@@ -192,7 +201,8 @@ class ScoringBasedEmbeddingModel:
 
         sp, old = self._spec, self._engine
         per_rank = -(-int(batch_size) // sp.world)
-        need = max(ShardedStepLoop.rows_needed(per_rank, self.eta, self._sharded_negatives), 2 * self.EVAL_CHUNK_SHARDED)
+        need = max(ShardedStepLoop.rows_needed(per_rank, self.eta, self._sharded_negatives, sp.world, sp.n_ents),
+                   2 * self.EVAL_CHUNK_SHARDED)
         if need <= int(old.ent.shape[0]) - sp.n_local:
             return
         new = KgeEngine(self.scoring_type, self.k, sp.n_local + need, self._n_rels, max_rel_size=self._n_rels)

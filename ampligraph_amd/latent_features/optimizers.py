@@ -12,7 +12,7 @@ class OptimizerWrapper:
     momentum, "rmsprop_mom" for RMSprop with momentum): it also names the optimizer-state layout of engine / checkpoints."""
 
     def __init__(self, name, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, momentum=0.0, nesterov=False,
-                 rho=None, amsgrad=False, centered=False, **unused):
+                 rho=None, amsgrad=False, centered=False, lazy=False, **unused):
         name = name.lower()
         if name not in ("sgd", "adagrad", "adam", "rmsprop", "adadelta", "adamax") or name.endswith("_mom"):
             raise ValueError("Could not interpret optimizer identifier: ", name)
@@ -29,6 +29,9 @@ class OptimizerWrapper:
         elif name == "rmsprop" and self.momentum != 0.0:
             self.name = "rmsprop_mom"
         self.iterations = 0
+        # touched-rows mode: an opt-in that deviates from the reference's dense optimizer (optimizers.py:136-168), see
+        # amdkge_opt.lazy in include/amdkge.h; set by compile(optimizer_mode="lazy") or OptimizerWrapper(lazy=True)
+        self.lazy = bool(lazy)
 
     def to_ffi(self, iteration, reg_p=2):
         b1, b2 = self.beta_1, self.beta_2
@@ -38,12 +41,13 @@ class OptimizerWrapper:
             b1, b2 = self.rho, self.momentum
         elif self.name == "adadelta":
             b1, b2 = self.rho, 0.0
-        return _ffi.Opt(_ffi.OPTIMIZERS[self.name], int(reg_p), self.learning_rate, b1, b2, self.epsilon, 0.0, int(iteration))
+        return _ffi.Opt(_ffi.OPTIMIZERS[self.name], int(reg_p), self.learning_rate, b1, b2, self.epsilon, 0.0, int(iteration),
+                        1 if self.lazy else 0, 0)   # row_floats is filled in by the engine (it knows the stored row layout)
 
     def get_config(self):
         return {"name": self.keras_name, "learning_rate": self.learning_rate, "beta_1": self.beta_1,
                 "beta_2": self.beta_2, "epsilon": self.epsilon, "momentum": self.momentum, "nesterov": self.nesterov,
-                "rho": self.rho}
+                "rho": self.rho, "lazy": self.lazy}
 
 
 def get(identifier, hyperparams=None):

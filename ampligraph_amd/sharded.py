@@ -25,8 +25,10 @@ Negative sampling locality is an explicit flag because it changes the distributi
     training does: corruptions come from the partition's entities, ScoringBasedEmbeddingModel.py:227,259-261);
     only the positives' own remote s/o rows move (<= 2 rows per positive).
 
-torch ops below (sort / bincount / index_select / index_add_ / all_to_all_single) are the exchange plumbing;
-every score, loss, gradient and update is a libamdkge kernel.
+The training step (ShardedStepLoop.step) issues only libamdkge kernels (kge_shard.hip: device-side routing with
+de-duplication, row gather, gradient scatter-add) and equal-split collectives -- no torch compute op, no host sync.
+RowExchange below (torch sort / bincount / index_select, host-known variable splits) remains the exchange of the
+evaluation / prediction paths, where a host round trip per chunk of test triples is immaterial.
 """
 import torch
 
@@ -106,7 +108,14 @@ class ShardedStepLoop:
     """Row-sharded counterpart of trainer.StepLoop (same step()/reset_loss()/mean_batch_loss() surface).
 
     engine: KgeEngine-like backend whose entity table has `spec.n_local + capacity` rows: the local shard first,
-    scratch rows for fetched copies behind it."""
+    scratch rows for fetched copies behind it, `capacity // world` of them per peer.
+
+    A step issues only libamdkge kernels and collectives, all on the launch stream, with no host round trip: the ids are
+    routed on the device (engine.shard_route), every all_to_all has EQUAL, host-known splits (a fixed number of request
+    slots per peer; unused slots carry -1 / zero rows), gathers and scatter-adds are kernels.  The price is bandwidth for
+    the unused slots; a peer list that overflows sets a sticky device flag that mean_batch_loss() turns into an error."""
+
+    PHASES = ("route+fetch", "kernels", "return", "sweep")   # what kernel_hook(i) / kernel_hook(i + 1) bracket
 
     def __init__(self, engine, spec, eta, loss, optimizer, regularizer, seed, dist, negatives="local", capacity=None):
         if negatives not in ("local", "global"):
@@ -121,21 +130,39 @@ class ShardedStepLoop:
         self.negatives = negatives
         self.world, self.rank = spec.world, spec.rank
         self.capacity = int(capacity) if capacity is not None else int(engine.ent.shape[0]) - spec.n_local
-        if self.capacity < 0:
-            raise ValueError("engine table is smaller than the local shard")
+        if self.capacity < self.world:
+            raise ValueError("engine table is smaller than the local shard plus one scratch row per peer")
+        self.cap_peer = self.capacity // self.world
         self.n_steps = 0
         self.use_tiled = prefer_tiled(engine)
-        self.kernel_hook = None   # bench.py: callable(phase) recording HIP events around the fused kernels
+        self.kernel_hook = None   # bench.py: callable(i) recording HIP events at the phase boundaries (PHASES)
+        self._route_counts = None
         engine.prepare_training(optimizer.name)
 
     @staticmethod
-    def rows_needed(batch_per_rank, eta, negatives):
-        """Upper bound of the scratch rows one step needs behind the shard (distinct remote ids)."""
-        return int(batch_per_rank) * (2 + (int(eta) if negatives == "global" else 0))
+    def peer_capacity(batch_per_rank, eta, negatives, world=1, n_ents=None):
+        """Request slots per peer.  Worst case = every id of the rank's share is remote, distinct and owned by ONE peer;
+        with more than two ranks the lists are sized at AMDKGE_SHARD_CAP_FACTOR (default 2) times the even split instead
+        (ids spread over the owners; an overflow is detected on the device and reported, never silent)."""
+        import os
+
+        worst = int(batch_per_rank) * (2 + (int(eta) if negatives == "global" else 0))
+        if n_ents is not None:
+            worst = min(worst, -(-int(n_ents) // int(world)))
+        if world <= 2:
+            return max(1, worst)
+        factor = float(os.environ.get("AMDKGE_SHARD_CAP_FACTOR", "2.0"))
+        return max(1, min(worst, int(factor * worst / world) + 64))
+
+    @staticmethod
+    def rows_needed(batch_per_rank, eta, negatives, world=1, n_ents=None):
+        """Scratch rows one step needs behind the shard: `world` peer lists of peer_capacity rows."""
+        return int(world) * ShardedStepLoop.peer_capacity(batch_per_rank, eta, negatives, world, n_ents)
 
     def step(self, global_batch, rng_step, focus=None):
         """focus: None or (w fp32 device tensor [Bg], beta, non-linearity name) -- FocusE, as trainer.StepLoop.step."""
-        eng, sp = self.engine, self.spec
+        eng, sp, W, cap = self.engine, self.spec, self.world, self.cap_peer
+        hook = self.kernel_hook
         bg = int(global_batch.shape[0])
         lo, hi = shard_bounds(bg, self.world, self.rank)
         if focus is not None:
@@ -146,37 +173,32 @@ class ShardedStepLoop:
         else:
             self.loss_ffi.focus_nonlinearity = 0
             self.loss_ffi.d_focus_w = None
-        xb = global_batch[lo:hi].to(torch.int64)
+        xb = global_batch[lo:hi]
         b = int(xb.shape[0])
+        if hook is not None:
+            hook(0)
         negs = None
         if self.negatives == "global" and b > 0:
             # the very corruptions one GPU would draw (global Philox rows, ids over all N entities)
-            negs = eng.sample_corruptions(global_batch[lo:hi], self.eta, self.seed, rng_step, sample_base=0,
-                                          sample_range=sp.n_ents, row_offset=lo, b_global=bg).to(torch.int64)
-        # ---- 1. route remote ids, fetch their rows behind the shard, re-index the batch ------------------
-        cols = [xb[:, 0], xb[:, 2]] + ([negs[:, 0], negs[:, 2]] if negs is not None else [])
-        ids = torch.cat(cols) if cols else xb.new_zeros(0)
-        remote = (ids < sp.lo) | (ids >= sp.hi)
-        # one scratch row per DISTINCT remote id: equal ids must stay equal after re-indexing (the kernels tell a
-        # kept from a replaced side by comparing ids) and their gradients must meet in one row
-        rid, rinv = torch.unique(ids[remote], return_inverse=True)
-        if int(rid.numel()) > self.capacity:
-            raise RuntimeError(f"row-sharded step needs {int(rid.numel())} scratch rows, engine has {self.capacity}")
-        ex = RowExchange(sp, self.dist, rid)
-        ex.fetch(eng.ent, sp.n_local)
-        local_idx = ids - sp.lo
-        local_idx[remote] = sp.n_local + ex.slots()[rinv]
-        parts = torch.split(local_idx, [b, b] + ([negs.shape[0]] * 2 if negs is not None else []))
-        xl = torch.stack([parts[0], xb[:, 1], parts[1]], 1).to(torch.int32).contiguous()
-        nl = None
-        if negs is not None:
-            nl = torch.stack([parts[2], negs[:, 1], parts[3]], 1).to(torch.int32).contiguous()
+            negs = eng.sample_corruptions(xb, self.eta, self.seed, rng_step, sample_base=0,
+                                          sample_range=sp.n_ents, row_offset=lo, b_global=bg)
+        # ---- 1. route remote ids on the device, fetch their rows behind the shard ----------------------------
+        # one scratch row per DISTINCT remote id: equal ids must stay equal after re-indexing (the kernels tell a kept
+        # from a replaced side by comparing ids) and their gradients must meet in one row
+        xl, nl, send_ids, counts = eng.shard_route(sp, xb, negs, cap)
+        self._route_counts = counts
+        recv_ids = eng._buf("route_recv", (W * cap,), send_ids.dtype)
+        self.dist.all_to_all_single(recv_ids, send_ids)                 # equal splits: `cap` request slots per peer
+        rows = eng.gather_rows(eng.ent, recv_ids, "rows_out")           # owner side: requested rows (-1 -> zero row)
+        scratch = eng.ent[sp.n_local:sp.n_local + W * cap]
+        self.dist.all_to_all_single(scratch.reshape(-1), rows.reshape(-1))   # fetched copies land behind the shard
+        if hook is not None:
+            hook(1)
         # ---- 2. fused train step on the local index space (gradient only) --------------------------------
         self.optimizer.iterations += 1
         lam = self.reg.lam if self.reg is not None else 0.0
         opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2)
-        if self.kernel_hook is not None:
-            self.kernel_hook(0)
+        g_scratch = eng.g_ent[sp.n_local:sp.n_local + W * cap]
         if b > 0:
             kw = dict(row_offset=lo, b_global=bg, neg_override=nl)
             if nl is None:   # shard-local negatives: replacement rows are local rows [0, n_local)
@@ -185,15 +207,20 @@ class ShardedStepLoop:
                 eng.train_step_tiled(xl, self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step, grad_only=True, **kw)
             else:
                 eng.train_fwdbwd(xl, self.eta, self.loss_ffi, self.seed, rng_step, **kw)
-        if self.kernel_hook is not None:
-            self.kernel_hook(1)
+        if hook is not None:
+            hook(2)
         # ---- 3. gradients of fetched copies go home; relation gradient is summed over ranks ----------------
-        ex.return_grads(eng.g_ent, sp.n_local)
-        if ex.n:
-            eng.g_ent[sp.n_local:sp.n_local + ex.n].zero_()
+        back = eng._buf("grads_back", tuple(g_scratch.shape), g_scratch.dtype)
+        self.dist.all_to_all_single(back.reshape(-1), g_scratch.reshape(-1))
+        eng.scatter_add_rows(eng.g_ent, recv_ids, back)
+        eng.zero_(g_scratch)   # (the atomic-scatter train path accumulates into these rows)
         self.dist.all_reduce(eng.g_rel)
+        if hook is not None:
+            hook(3)
         # ---- 4. every rank sweeps its rows and the replicated relation table -------------------------------
         eng.opt_step(opt_ffi, lam, lam if self.lam_rel is None else self.lam_rel, rows_e=sp.n_local, reg_slots=(1, 2))
+        if hook is not None:
+            hook(4)
         self.n_steps += 1
 
     def reset_loss(self):
@@ -203,6 +230,9 @@ class ShardedStepLoop:
     def mean_batch_loss(self):
         """Data loss and the entity-shard regulariser parts are summed over ranks; the relation-table
         regulariser part is identical on every rank and counted once."""
+        if self._route_counts is not None and int(self._route_counts[self.world].item()) != 0:
+            raise RuntimeError(f"row-sharded step: a peer's request list overflowed its {self.cap_peer} slots (skewed ids?); "
+                               "results of this epoch are invalid -- raise AMDKGE_SHARD_CAP_FACTOR or the scratch capacity")
         acc = self.engine.loss_acc.clone()
         part = acc[0:2].clone()
         self.dist.all_reduce(part)

@@ -55,6 +55,8 @@ HOT_ROW_THRESHOLD = 256.0   # expected entries on one row per batch beyond which
 
 
 class StepLoop:
+    PHASES = ("kernels", "merge+sweep")   # what kernel_hook(i) / kernel_hook(i + 1) bracket
+
     def __init__(self, engine, eta, loss, optimizer, regularizer=None, seed=0, dist=None, merge=None):
         """engine: KgeEngine-like backend; loss/optimizer: objects with .to_ffi(); dist: None or the
         torch.distributed module (already initialised); merge: how N > 1 ranks merge gradients --
@@ -85,6 +87,9 @@ class StepLoop:
         if merge not in ("sharded", "allreduce"):
             raise ValueError("merge must be 'sharded', 'allreduce' or 'auto'")
         self.merge = merge if hasattr(engine, "opt_step_flat") else "allreduce"
+        if getattr(optimizer, "lazy", False):
+            # touched-rows optimizer: rows are the unit of work, the slice-wise sharded sweep would cut them
+            self.merge, self.auto_tune = "allreduce", False
         self.merge_report = None
         self.collectives = os.environ.get("AMDKGE_DP_GATHER", "alltoall")   # sharded merge: "alltoall" | "native"
         if self.collectives == "allgather":   # older spelling: all_to_all reduce-scatter + native all_gather
@@ -92,7 +97,7 @@ class StepLoop:
         self.n_steps = 0
         self.use_tiled = prefer_tiled(engine)
         self.pos_atomic = False   # see configure_for_data
-        self.kernel_hook = None   # bench.py: callable(phase) recording HIP events around the fused kernel
+        self.kernel_hook = None   # bench.py: callable(i) recording HIP events at the phase boundaries (PHASES)
         engine.prepare_training(optimizer.name)
         if self.merge == "sharded" and self.world > 1 and int(engine.g_flat.numel()) % self.world != 0:
             self.merge = "allreduce"   # the flat buffers split evenly over 1, 2, 4, 8, 16 ranks; other counts all-reduce
@@ -146,34 +151,57 @@ class StepLoop:
                     self.dist.all_reduce(g)
             if not (tiled and self.world == 1):   # the single-GPU owner-computes call is the complete step
                 eng.opt_step(opt_ffi, lam, lam_r)
+        if self.kernel_hook is not None:
+            self.kernel_hook(2)
         self.n_steps += 1
 
     def _merge_sharded(self, opt_ffi, lam, lam_r):
-        """Reduce-scatter (all_to_all + local sum), sharded sweep, all_gather of the parameters."""
-        import torch
-
+        """Reduce-scatter (all_to_all of the partial slices), sharded sweep that sums the W partials on the fly
+        (amdkge_opt_step_merged), parameters back to everyone.  Only collectives and libamdkge calls: no torch compute op,
+        no host synchronisation."""
         eng, W, r = self.engine, self.world, self.rank
         g, p = eng.g_flat, eng.p_flat
         chunk = g.numel() // W                      # the flat buffers are padded to a multiple of 16 * 64 floats
-        mine = g[r * chunk:(r + 1) * chunk]
+        lo, hi = r * chunk, (r + 1) * chunk
+        merged = hasattr(eng, "opt_step_merged")
         if self.collectives == "native":            # the library's own reduce-scatter / all-gather schedules
-            red = torch.empty(chunk, dtype=g.dtype, device=g.device)
+            red = eng._buf("dp_red", (chunk,), g.dtype) if merged else g.new_empty(chunk)
             self.dist.reduce_scatter_tensor(red, g)
+            parts, n_parts = red, 1
+        else:
+            parts = eng._buf("dp_recv", (g.numel(),), g.dtype) if merged else g.new_empty(g.numel())
+            self.dist.all_to_all_single(parts, g)   # parts[q*chunk:(q+1)*chunk] = rank q's partial sums of MY slice
+            n_parts = W
+        if merged:
+            # the spent gradient buffer is cleared on the stream (the tile kernel stores the entity part anyway; the
+            # relation part and, with atomic positives, everything must start at zero)
+            eng.zero_(g)
+            eng.opt_step_merged(opt_ffi, lo, hi, parts, n_parts, chunk, lam, lam_r, reg_slot=1)
+        else:   # backends without the fused kernel (CPU test double): explicit sum + slice sweep
+            import torch
+
             g.zero_()
-            mine.copy_(red)
+            torch.sum(parts.view(n_parts, chunk), dim=0, out=g[lo:hi])
+            eng.opt_step_flat(opt_ffi, lo, hi, lam, lam_r, reg_slot=1)   # leaves my gradient slice zero
+        self._gather_slices(p)   # parameters back to everyone
+
+    def _gather_slices(self, flat):
+        """Every rank's slice of `flat` to every peer, in place.  "alltoall": W - 1 point-to-point sends of MY slice and
+        W - 1 receives into the peers' slices, batched into one group -- every xGMI link carries one slice at once, where a
+        ring all-gather pushes W - 1 hops through each link in turn; the other schedules use the library's all-gather."""
+        W, r = self.world, self.rank
+        chunk = flat.numel() // W
+        mine = flat[r * chunk:(r + 1) * chunk]
+        if self.collectives == "alltoall" and hasattr(self.dist, "batch_isend_irecv"):
+            ops = []
+            for q in range(W):
+                if q != r:
+                    ops.append(self.dist.P2POp(self.dist.isend, mine, q))
+                    ops.append(self.dist.P2POp(self.dist.irecv, flat[q * chunk:(q + 1) * chunk], q))
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
         else:
-            recv = torch.empty_like(g)
-            self.dist.all_to_all_single(recv, g)    # recv[q*chunk:(q+1)*chunk] = rank q's partial sums of MY slice
-            g.zero_()                               # gradients of the other slices are spent
-            torch.sum(recv.view(W, chunk), dim=0, out=mine)
-        eng.opt_step_flat(opt_ffi, r * chunk, (r + 1) * chunk, lam, lam_r, reg_slot=1)   # leaves my gradient slice zero
-        # parameters back to everyone.  Also as an all_to_all (the same slice to every peer, one link each) rather than a
-        # ring all-gather, which would push W - 1 hops through a single xGMI link.  AMDKGE_DP_GATHER=allgather switches.
-        mine_p = p[r * chunk:(r + 1) * chunk]
-        if self.collectives != "alltoall":
-            self.dist.all_gather_into_tensor(p, mine_p.clone())
-        else:
-            self.dist.all_to_all_single(p, mine_p.expand(W, chunk).contiguous().view(-1))
+            self.dist.all_gather_into_tensor(flat, mine)
 
     def tune_merge(self, batch_of, first_step=0, trials=4, pick=None):
         """Measure the merge schedules on THIS machine's fabric and keep the fastest (collective: call on every rank).
@@ -210,8 +238,8 @@ class StepLoop:
                     self.dist.all_to_all_single(b, a)
                 if coll == "native":
                     self.dist.reduce_scatter_tensor(b[:4], a)
-                if coll != "alltoall":
-                    self.dist.all_gather_into_tensor(b, a[:4].clone())
+                if coll != "alltoall" or not hasattr(self.dist, "batch_isend_irecv"):
+                    self.dist.all_gather_into_tensor(b, b[self.rank * 4:(self.rank + 1) * 4])
             except RuntimeError:
                 return False
             return True
@@ -251,8 +279,7 @@ class StepLoop:
             return
         W, r = self.world, self.rank
         for fl in self.engine.slot_flat.values():
-            chunk = fl.numel() // W
-            self.dist.all_to_all_single(fl, fl[r * chunk:(r + 1) * chunk].expand(W, chunk).contiguous().view(-1))
+            self._gather_slices(fl)
 
     def reset_loss(self):
         self.engine.loss_acc.zero_()

@@ -33,26 +33,54 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+# BASELINE.json `configs`, in its order (C1 = configs[0] ... C5 = configs[4]).  C2 is the configuration the metric is quoted on
+# and the default workload; the others are selected with --config.  C4 / C5 row-shard the entity table when N > 1.
+PRESETS = {
+    "C1": dict(model="TransE", k=50, eta=5, loss="pairwise", dataset="synth-fb15k237", batch=10000, parallelism="replicated"),
+    "C2": dict(model="ComplEx", k=200, eta=20, loss="self_adversarial", dataset="synth-fb15k237", batch=10000, parallelism="replicated"),
+    "C3": dict(model="DistMult", k=400, eta=30, loss="self_adversarial", dataset="synth-wn18rr", batch=10000, parallelism="replicated"),
+    "C4": dict(model="ComplEx", k=200, eta=20, loss="self_adversarial", dataset="synth-yago310", batch=8192, parallelism="sharded-local"),
+    # 50 M entities / 500 M triples over 8 GPUs = 6.25 M rows per GPU (weak scaling: the shard size is per GPU), triples from
+    # the on-device counter RNG; touched-rows Adam (north_star: "sparse Adam"), see --optimizer-mode
+    "C5": dict(model="RotatE", k=1000, eta=64, loss="self_adversarial", dataset="synth-50M", batch=65536, parallelism="sharded-local",
+               optimizer_mode="lazy"),
+}
+SYNTH_STREAM = {"synth-50M": dict(ents_per_gpu=6_250_000, n_rels=1000)}   # datasets that exist only as a device-side stream
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=280)
     ap.add_argument("--warmup", type=int, default=28)
-    ap.add_argument("--batch", type=int, default=10000, help="positives per GPU per step")
-    ap.add_argument("--model", default="ComplEx")
-    ap.add_argument("--k", type=int, default=200)
-    ap.add_argument("--eta", type=int, default=20)
-    ap.add_argument("--loss", default="self_adversarial")
-    ap.add_argument("--dataset", default="synth-fb15k237")
+    ap.add_argument("--config", default=None, choices=sorted(PRESETS), help="a BASELINE.json configuration; explicit flags override it")
+    ap.add_argument("--batch", type=int, default=None, help="positives per GPU per step")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--eta", type=int, default=None)
+    ap.add_argument("--loss", default=None)
+    ap.add_argument("--dataset", default=None)
+    ap.add_argument("--ents-per-gpu", type=int, default=None, help="synth-50M only: rows of the entity table per GPU (cut-down runs)")
     ap.add_argument("--popularity", default="uniform", choices=["uniform", "zipf"],
                     help="entity/relation popularity of the synthetic graph (SURVEY.md 8d: uniform primary, zipf secondary)")
+    ap.add_argument("--optimizer-mode", default=None, choices=["dense", "lazy"],
+                    help="dense = the reference's Keras-legacy behaviour (every row every step); lazy = touched rows only "
+                         "(amdkge_opt.lazy, a documented deviation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
-    ap.add_argument("--parallelism", default="replicated", choices=["replicated", "sharded-local", "sharded-global"],
-                    help="N>1: replicated tables + gradient all-reduce (default, right for tables that fit one GPU), or the "
+    ap.add_argument("--parallelism", default=None, choices=["replicated", "sharded-local", "sharded-global"],
+                    help="N>1: replicated tables + gradient merge (right for tables that fit one GPU), or the "
                          "row-sharded entity table of ampligraph_amd/sharded.py with shard-local / global negatives")
-    return ap.parse_args()
+    args = ap.parse_args()
+    preset = dict(PRESETS[args.config or "C2"])
+    for key, val in preset.items():
+        if getattr(args, key, None) is None:
+            setattr(args, key, val)
+    if args.optimizer_mode is None:
+        args.optimizer_mode = "dense"
+    args.preset = args.config or ("C2" if all(getattr(args, k_) == v_ for k_, v_ in PRESETS["C2"].items()) else None)
+    return args
 
 
 def cpu_baseline(args, data, ent0, rel0):
@@ -147,70 +175,88 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from ampligraph_amd import _ffi
     from ampligraph_amd.datasets import make_synthetic_kg
     from ampligraph_amd.engine import KgeEngine
     from ampligraph_amd.latent_features import loss_functions, optimizers
     from ampligraph_amd.trainer import StepLoop
 
-    data = make_synthetic_kg(args.dataset, seed=0, popularity=args.popularity)
-    N, R = data["n_ents"], data["n_rels"]
+    stream = SYNTH_STREAM.get(args.dataset)
+    if stream is not None:     # no host-side triples at all: (s, p, o) number i comes from the counter RNG on the device
+        N, R = (args.ents_per_gpu or stream["ents_per_gpu"]) * world, stream["n_rels"]
+        data = {"n_ents": N, "n_rels": R, "train": None, "valid": None, "test": None}
+    else:
+        data = make_synthetic_kg(args.dataset, seed=0, popularity=args.popularity)
+        N, R = data["n_ents"], data["n_rels"]
     sharded = args.parallelism != "replicated" and world > 1
     rng = np.random.Generator(np.random.PCG64(0))
     Kf = 2 * args.k if args.model in ("ComplEx", "HolE", "RotatE") else args.k
-    lim_e, lim_r = np.sqrt(6.0 / (N + Kf)), np.sqrt(6.0 / (R + Kf))
+    lim_e, lim_r = float(np.sqrt(6.0 / (N + Kf))), float(np.sqrt(6.0 / (R + Kf)))
     big = N * Kf > 400_000_000   # > 1.6 GB tables: initialise on the device (no CPU baseline / oracle at that size)
     ent0 = None if big else rng.uniform(-lim_e, lim_e, size=(N, Kf)).astype(np.float32)  # Glorot uniform, same on every rank
     rel0 = rng.uniform(-lim_r, lim_r, size=(R, Kf)).astype(np.float32)
+    opt = optimizers.get("adam")
+    opt.lazy = args.optimizer_mode == "lazy"
+
+    def fill_rows(eng, lo, hi):
+        """rows [lo, hi) of the whole-table initial values into eng.ent[0 : hi - lo] (host draw for small tables, a seeded
+        device draw per rank for tables that do not fit host RAM), always through pack(): the stored layout may be padded"""
+        if ent0 is not None:
+            eng.pack(ent0[lo:hi], out=eng.ent[:hi - lo])
+            return
+        g = torch.Generator(device="cuda").manual_seed(1 + rank)
+        step = max(1, (1 << 28) // Kf)
+        for r0 in range(0, hi - lo, step):
+            r1 = min(hi - lo, r0 + step)
+            eng.pack((torch.rand(r1 - r0, Kf, device="cuda", generator=g) * 2 - 1) * lim_e, out=eng.ent[r0:r1])
+
     if sharded:
         from ampligraph_amd.sharded import ShardedStepLoop, ShardSpec
 
         negs = args.parallelism.split("-")[1]
         spec = ShardSpec(N, world, rank)
-        cap = ShardedStepLoop.rows_needed(args.batch, args.eta, negs)
+        cap = ShardedStepLoop.rows_needed(args.batch, args.eta, negs, world, N)
         eng = KgeEngine(args.model, args.k, spec.n_local + cap, R, max_rel_size=R)
-        shard = np.zeros((spec.n_local + cap, Kf), dtype=np.float32)
-        shard[:spec.n_local] = ent0[spec.lo:spec.hi]
-        eng.set_tables(shard, rel0)
-        loop = ShardedStepLoop(eng, spec, args.eta, loss_functions.get(args.loss), optimizers.get("adam"), None, 0, dist,
-                               negatives=negs)
+        fill_rows(eng, spec.lo, spec.hi)
+        eng.pack(rel0, out=eng.rel)
+        loop = ShardedStepLoop(eng, spec, args.eta, loss_functions.get(args.loss), opt, None, 0, dist, negatives=negs)
     else:
         eng = KgeEngine(args.model, args.k, N, R, max_rel_size=R)
-        if big:
-            g = torch.Generator(device="cuda").manual_seed(0)
-            for r0 in range(0, N, 1 << 20):
-                eng.ent[r0:r0 + (1 << 20)].uniform_(-lim_e, lim_e, generator=g)
-            eng.rel.copy_(torch.as_tensor(rel0))
-        else:
-            eng.set_tables(ent0, rel0)
+        fill_rows(eng, 0, N)
+        eng.pack(rel0, out=eng.rel)
         # the product's own step loop (what ScoringBasedEmbeddingModel.fit drives)
-        loop = StepLoop(eng, args.eta, loss_functions.get(args.loss), optimizers.get("adam"), None, seed=0, dist=dist)
+        loop = StepLoop(eng, args.eta, loss_functions.get(args.loss), opt, None, seed=0, dist=dist)
 
-    if hasattr(loop, "configure_for_data"):
-        loop.configure_for_data(data["train"], args.batch * world)
-    # the training set lives in HBM; a global batch is a contiguous slice (reference order: sequential,
-    # un-shuffled, graph_data_loader.py:472-523); each rank takes its share of it inside StepLoop
     B = args.batch
     Bg = B * world
-    train = torch.as_tensor(data["train"]).cuda()
-    n_train = train.shape[0]
-    steps_per_epoch = max(1, n_train // Bg)
+    if hasattr(loop, "configure_for_data") and data["train"] is not None:
+        loop.configure_for_data(data["train"], Bg)
+    # the training set lives in HBM; a global batch is a contiguous slice (reference order: sequential,
+    # un-shuffled, graph_data_loader.py:472-523); each rank takes its share of it inside the step loop
+    if stream is None:
+        train = torch.as_tensor(data["train"]).cuda()
+        steps_per_epoch = max(1, train.shape[0] // Bg)
 
-    def batch_of(step):
-        b0 = (step % steps_per_epoch) * Bg
-        return train[b0:b0 + Bg]
+        def batch_of(step):
+            b0 = (step % steps_per_epoch) * Bg
+            return train[b0:b0 + Bg]
+    else:
+        stream_buf = torch.empty(Bg, 3, dtype=torch.int32, device="cuda")
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        def batch_of(step):   # triples [step * Bg, (step + 1) * Bg) of the 500 M-triple stream, generated in place (one launch)
+            return eng.synth_triples(0, step * Bg, Bg, N, R, out=stream_buf)
+
+    phases = list(loop.PHASES)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(phases) + 1)] for _ in range(args.steps)]
     cur = {"i": None}
 
-    def hook(phase):   # HIP events on the stream the kernel is launched on (torch's current stream)
+    def hook(i):   # HIP events on the stream the kernels are launched on (torch's current stream), at the phase boundaries
         if cur["i"] is not None:
-            ev[cur["i"]][phase].record()
+            ev[cur["i"]][i].record()
 
     # N > 1, replicated tables: which gradient-merge schedule is fastest depends on the fabric -- measure the candidates
     # on this node first (ordinary training steps, before the warmup; AMDKGE_DP_MERGE pins one instead)
     tuned = 0
-    if world > 1 and not sharded and "AMDKGE_DP_MERGE" not in os.environ:
+    if world > 1 and not sharded and "AMDKGE_DP_MERGE" not in os.environ and not opt.lazy:
         tuned = loop.tune_merge(batch_of, 0)
     loop.kernel_hook = hook
     loop.reset_loss()
@@ -236,48 +282,61 @@ def main():
         dt = float(t.item())
     loss_mean = loop.mean_batch_loss()
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    phase_ms = {nm: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i, nm in enumerate(phases)} if args.steps else {}
+    kern_ms = phase_ms.get("kernels", float("nan"))
     if rank == 0:
         triples = float(world) * B * (1 + args.eta) * args.steps
         bytes_per_pos = 2.0 * (3 + args.eta) * 4.0 * eng.K   # each distinct row read once + its gradient written once
         achieved = bytes_per_pos * B / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        headline = (args.model, args.k, args.eta, args.dataset, args.batch, args.popularity) == ("ComplEx", 200, 20, "synth-fb15k237", 10000, "uniform")
-        if os.path.exists(pmc) and world == 1 and headline:   # the PMC passes were collected on the headline workload only
-            try:
-                traffic = json.load(open(pmc)).get("train_step_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # PMC traffic cannot be collected inside this process (rocprofv3 wraps the command): the figure below is REPLAYED from
+        # the committed counter passes of the headline workload (scripts/profile_bench.sh) and labelled as such; null otherwise
+        traffic, traffic_source = None, None
+        if world == 1 and args.preset == "C2" and args.popularity == "uniform" and not opt.lazy:
+            for cand in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+                pmc = os.path.join(ROOT, "profiles", cand)
+                if os.path.exists(pmc):
+                    try:
+                        traffic = json.load(open(pmc)).get("train_step_hbm_bytes_per_launch")
+                        traffic_source = f"replayed from profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; not measured in this run)"
+                    except Exception:
+                        traffic = None
+                    break
         tiled = loop.use_tiled and eng.tiled_supported(B, args.eta)
         kernel_names = (["train_fwdbwd_kernel<..., STAGE=true>", "tile_backward_kernel"] if tiled else ["train_fwdbwd_kernel"])
+        opt_txt = ("dense (non-lazy) Keras-legacy Adam every step" if not opt.lazy else
+                   "touched-rows (lazy) Adam: a documented deviation from the reference's dense optimizer")
+        if sharded:
+            par = (f"rows{world} (row-sharded entity table, {args.parallelism.split('-')[1]} negatives, device-side routing, "
+                   f"equal-split all_to_all row / gradient exchange, {loop.cap_peer} request slots per peer)")
+        elif world > 1:
+            par = (f"dp{world} (replicated tables, gradient merge: {getattr(loop, 'merge', 'allreduce')}"
+                   f"{'/' + loop.collectives if getattr(loop, 'merge', '') == 'sharded' else ''})")
+        else:
+            par = "single GPU"
+        headline = args.preset == "C2"
         out = {
-            "metric": ("training triples/sec (incl. negatives), ComplEx k=200 eta=20 FB15K-237-shaped"
-                       if (args.model, args.k, args.eta, args.dataset) == ("ComplEx", 200, 20, "synth-fb15k237")
+            "metric": ("training triples/sec (incl. negatives), ComplEx k=200 eta=20 FB15K-237-shaped" if headline
                        else f"training triples/sec (incl. negatives), {args.model} k={args.k} eta={args.eta} {args.dataset}"),
             "value": triples / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.dataset} ({args.popularity}, seed 0) {args.model} k={args.k} eta={args.eta} "
-                                   f"{args.loss} adam lr=1e-3, {B} positives/GPU/step, tables resident in HBM, "
-                                   f"dense (non-lazy) Keras-legacy Adam every step",
-                       "global_batch": Bg, "n_ents": N, "n_rels": R, "row_floats": eng.K,
-                       "parallelism": (f"rows{world} (row-sharded entity table, {args.parallelism.split('-')[1]} negatives, "
-                                       "all_to_all row/gradient exchange)" if sharded else
-                                       f"dp{world} (replicated tables, gradient merge: {getattr(loop, 'merge', 'allreduce')}"
-                                       f"{'/' + loop.collectives if getattr(loop, 'merge', '') == 'sharded' else ''})" if world > 1 else "single GPU"),
-                       "merge_ms_per_step_measured": getattr(loop, "merge_report", None)},
+                                   f"{args.loss} adam lr=1e-3, {B} positives/GPU/step, tables resident in HBM, {opt_txt}",
+                       "preset": args.preset, "optimizer_mode": args.optimizer_mode,
+                       "global_batch": Bg, "n_ents": N, "n_rels": R, "row_floats": eng.K, "stored_row_floats": eng.Ks,
+                       "parallelism": par, "merge_ms_per_step_measured": getattr(loop, "merge_report", None)},
             "mean_batch_loss": loss_mean,
+            "phases_ms": phase_ms,
             "roofline": {"bound": "hbm", "kernel": " + ".join(kernel_names), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_pos * B,
                          "note": "launch = one train step's kernel pair (HIP events on the launch stream around both); "
-                                 "the pair also applies the optimizer (7*4K*(N+R) B/step), which is NOT counted in "
-                                 "the algorithmic bytes; traffic = L2<->fabric bytes (PMC, Infinity-Cache hits included)"},
+                                 "single GPU: the pair also applies the optimizer (7*4K*(N+R) B/step dense), which is NOT counted "
+                                 "in the algorithmic bytes; traffic = L2<->fabric bytes (PMC, Infinity-Cache hits included)"},
         }
-        if world == 1 and not args.no_eval:
+        if world == 1 and not args.no_eval and data["test"] is not None:
             out["eval"] = eval_bench(eng, data, rank)
-        if world == 1 and not args.no_cpu_baseline and not big:
+        if world == 1 and not args.no_cpu_baseline and not big and data["train"] is not None and not opt.lazy:
             out["cpu_baseline"] = cpu_baseline(args, data, ent0, rel0)
         print(json.dumps(out), flush=True)
     if world > 1:

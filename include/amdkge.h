@@ -98,6 +98,15 @@ typedef struct amdkge_opt {
     float epsilon;          /* Adam / Adagrad (Keras legacy default 1e-7) */
     float reg_lambda;       /* 0 = no regulariser */
     int64_t iteration;      /* t = optimizer.iterations + 1 of this step (1-based) */
+    /* Touched-rows ("lazy") mode -- an explicit OPT-IN that DEVIATES from the reference, whose optimizer is dense
+     * (optimizers.py:136-168 hands Keras a dense gradient: every row's slots decay and every row moves every step).
+     * lazy != 0: only table rows whose gradient row of this step is non-zero are updated (x, slots) and regularised;
+     * all other rows keep their bits -- the semantics of TensorFlow-Addons' LazyAdam, generalised to every rule above.
+     * This is what makes a 50 M-row table trainable at HBM speed: the dense sweep moves 7 * 4K bytes per row per step
+     * whether or not the row was used.  row_floats = floats per stored table row (amdkge_row_floats); needed by
+     * amdkge_opt_step to find row boundaries, ignored when lazy == 0. */
+    int32_t lazy;
+    int32_t row_floats;
 } amdkge_opt;
 
 /* ---- library / device helpers (so that a host without torch can drive the engine) ---- */
@@ -157,6 +166,8 @@ int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* loss,
  * whole-table LP regulariser (regularizers.py:35-37): one dense sweep over `n_elems` floats of a
  * table.  grad_total = d_grad + lambda*p*|x|^(p-1)*sign(x); updates d_x and the slots in place,
  * zeroes d_grad, and adds lambda*sum|x|^p (pre-update x) to *d_reg_loss (double, may be NULL).
+ * With opt->lazy the sweep is row-wise: d_x must start at a row boundary, n_elems must be a multiple of opt->row_floats,
+ * rows whose gradient row is entirely zero are skipped (not read beyond the gradient, not written, not regularised).
  *   Adam:    d_slot0 = m, d_slot1 = v;  Adagrad: d_slot0 = accumulator;  SGD: no slots;  the other kinds: slot order as
  *   written in the AMDKGE_OPT_* enum (first state variable = d_slot0). */
 int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_slot0, float* d_slot1,
@@ -248,6 +259,38 @@ int amdkge_filter_ranges(const int64_t* d_keys, const int64_t* d_start, int64_t 
  * d_ranks[i] = strategy(gt,eq) - sub + 1;  d_sub may be NULL (unfiltered). */
 int amdkge_rank_compose(const int32_t* d_counts, const int32_t* d_sub, int64_t n, int32_t strategy,
                         int32_t* d_ranks, int64_t rank_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU data path (one process per GPU; the host issues the RCCL collectives between these calls -- see
+ * ampligraph_amd/sharded.py and trainer.py).  The reference has no multi-device path; what these replace is its
+ * partitioned training loop, ScoringBasedEmbeddingModel.py:227,259-261 (corruptions from the partition's entities) and
+ * :1431-1452 (evaluation bucket by bucket), with owner(e) = e / ceil(N / G) as in datasets/graph_partitioner.py:339-344.
+ *
+ * amdkge_shard_route: rank `rank` of `world` owns rows [rank * rows_per, min(N, (rank + 1) * rows_per)), rows_per =
+ *   ceil(n_ents / world).  Every s / o id of d_triples [b,3] (and d_negs [nneg,3], may be NULL / 0) is rewritten into the
+ *   rank's LOCAL index space: an owned id e -> e - lo; a remote id -> n_local + peer * cap + position, the scratch row
+ *   behind the shard that will hold its fetched copy (equal ids get equal rows).  d_send_ids [world * cap] receives, per
+ *   peer, the row indices AT THAT PEER of the distinct ids requested from it (-1 = unused slot): exchanged with one
+ *   equal-split all_to_all, they are the gather list of amdkge_gather_rows there.  d_counts [world + 1]: requests per peer,
+ *   d_counts[world] is set to 1 if a peer's list overflowed `cap` (results are then invalid: grow cap); it is sticky -- the
+ *   library never clears it, so the host can check it once per epoch.  No host synchronisation.
+ *   d_work: amdkge_shard_route_workspace_bytes(b, nneg) bytes.
+ * amdkge_gather_rows      : d_out[j] = d_table[d_idx[j]] (rows of row_floats floats; idx < 0 -> zero row)
+ * amdkge_scatter_add_rows : d_table[d_idx[j]] += d_src[j] (idx < 0 skipped; indices may repeat) -- gradient rows of fetched
+ *                           copies returning to their owner
+ * amdkge_opt_step_merged  : amdkge_opt_step whose gradient is the sum of n_parts slices d_grad_parts + q * part_stride
+ *                           (the partial sums a reduce-scatter by all_to_all delivered), summed in part order; dense mode only
+ * amdkge_synth_triples    : d_out[i] = triple number first_row + i of the counter-based synthetic stream (Philox4x32-10,
+ *                           key = seed): s, o uniform over n_ents, p uniform over n_rels (SURVEY.md 8d "synth-50M") */
+int64_t amdkge_shard_route_workspace_bytes(int64_t b, int64_t nneg);
+int amdkge_shard_route(int64_t n_ents, int32_t world, int32_t rank, const int32_t* d_triples, int64_t b,
+                       const int32_t* d_negs, int64_t nneg, int32_t cap, int32_t* d_out_triples, int32_t* d_out_negs,
+                       int32_t* d_send_ids, int32_t* d_counts, void* d_work, void* stream);
+int amdkge_gather_rows(const float* d_table, int32_t row_floats, const int32_t* d_idx, int64_t n, float* d_out, void* stream);
+int amdkge_scatter_add_rows(float* d_table, int32_t row_floats, const int32_t* d_idx, int64_t n, const float* d_src, void* stream);
+int amdkge_opt_step_merged(const amdkge_opt* opt, float* d_x, const float* d_grad_parts, int32_t n_parts, int64_t part_stride,
+                           float* d_slot0, float* d_slot1, int64_t n_elems, double* d_reg_loss, void* stream);
+int amdkge_synth_triples(uint64_t seed, int64_t first_row, int64_t n, int64_t n_ents, int64_t n_rels, int32_t* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Session layer: HOST pointers in, HOST pointers out.  One opaque handle owns the HBM-resident state of a model (both

@@ -575,13 +575,40 @@ def apply_optimizer(state, Ge, Gr, beta1=None, beta2=None, eps=None):
         raise ValueError(state.optimizer)
 
 
+def apply_optimizer_lazy(state, Ge, Gr, reg=None):
+    """Touched-rows mode of the engine (amdkge_opt.lazy, include/amdkge.h) -- NOT a reference behaviour: the reference's
+    optimizer is dense (optimizers.py:136-168).  Rows whose data-gradient row is entirely zero keep x and every slot;
+    the other rows get the regulariser gradient and the ordinary update rule (TF-Addons LazyAdam semantics, generalised).
+    Ge, Gr: data gradients WITHOUT the regulariser term.  Returns the regulariser loss over the touched rows."""
+    Ge, Gr = np.array(Ge, dtype=np.float64), np.array(Gr, dtype=np.float64)
+    masks = [np.any(Ge != 0, axis=1), np.any(Gr != 0, axis=1)]
+    reg_loss = 0.0
+    if reg is not None:
+        for x, G, mask, lam in ((state.ent, Ge, masks[0], reg["lam_e"]), (state.rel, Gr, masks[1], reg["lam_r"])):
+            xx = x.astype(np.float64)[mask]
+            reg_loss += lam * float((np.abs(xx) ** reg["p"]).sum())
+            G[mask] += lam * reg["p"] * np.abs(xx) ** (reg["p"] - 1) * np.sign(xx)
+    keep = [(state.ent.copy(), {k: v.copy() for k, v in state.slots.items() if k.endswith("_e")}),
+            (state.rel.copy(), {k: v.copy() for k, v in state.slots.items() if k.endswith("_r")})]
+    apply_optimizer(state, Ge, Gr)
+    for (x0, sl0), x, mask in zip(keep, (state.ent, state.rel), masks):
+        x[~mask] = x0[~mask]
+        for k, v in sl0.items():
+            state.slots[k][~mask] = v[~mask]
+    return reg_loss
+
+
 def train_step(state, model, pos, eta, loss_name, seed, step, n_ents=None, loss_params=None,
                reduction="sum", max_rel_size=None, reg=None, row_offset=0, b_global=None,
-               negs=None, focus=None):
+               negs=None, focus=None, lazy=False):
     if n_ents is None:
         n_ents = state.ent.shape[0]
     if negs is None:
         negs = generate_corruptions(pos, n_ents, eta, seed, step, row_offset, b_global)
+    if lazy:
+        loss, Ge, Gr, _ = dense_gradients(model, state.ent, state.rel, pos, negs, eta, loss_name,
+                                          loss_params, reduction, max_rel_size, None, focus)
+        return float(loss) + apply_optimizer_lazy(state, Ge, Gr, reg)
     loss, Ge, Gr, _ = dense_gradients(model, state.ent, state.rel, pos, negs, eta, loss_name,
                                       loss_params, reduction, max_rel_size, reg, focus)
     apply_optimizer(state, Ge, Gr)

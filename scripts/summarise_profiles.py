@@ -58,7 +58,8 @@ for k in sorted(set(fetch) | set(write)):
 step = [k for k in out["kernels"] if "train_fwdbwd_kernel" in k or "tile_backward_kernel" in k]
 out["train_step_kernels"] = step
 out["train_step_hbm_bytes_per_launch"] = sum(out["kernels"][k]["bytes_per_launch"] for k in step)
-json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+rnd = tag[:3] + "_" if tag[:1] == "r" and tag[1:3].isdigit() and tag[:3] != "r01" else ""   # round-1 files keep their names
+json.dump(out, open(os.path.join(dst, rnd + "pmc_traffic.json"), "w"), indent=1)
 
 # MFMA utilisation of the rank kernel: MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD * #SIMD)
 f = find("mfma", "counter_collection.csv")
@@ -77,7 +78,7 @@ if f:
               "note": "SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per v_mfma_f32_32x32x2_f32; 1024 SIMDs; GRBM_GUI_ACTIVE is reported "
                       "summed over 8 XCDs.  scripts/mfma_peak.hip (pure MFMA loop, same instruction) sustains 124-144 TFLOP/s on "
                       "this box, i.e. the practical ceiling is ~0.9 of the 157.3 TFLOP/s spec."}
-        json.dump(mf, open(os.path.join(dst, "pmc_mfma.json"), "w"), indent=1)
+        json.dump(mf, open(os.path.join(dst, rnd + "pmc_mfma.json"), "w"), indent=1)
         print("mfma util:", mf["mfma_util"])
 print(json.dumps({k: out["kernels"][k]["bytes_per_launch"] for k in out["kernels"]}, indent=1))
 print("train step:", out["train_step_hbm_bytes_per_launch"])

@@ -36,6 +36,59 @@ class OracleEngine:
     def rel(self):
         return torch.from_numpy(self.state.rel if self.state is not None else self.rel0)
 
+    # ---- multi-GPU data path of KgeEngine (kge_shard.hip), restated with torch CPU ops -------------------------------
+    def _buf(self, name, shape, dtype):
+        return torch.empty(*shape, dtype=dtype)
+
+    def zero_(self, t):
+        t.zero_()
+
+    def shard_route(self, spec, triples, negs, cap):
+        """amdkge_shard_route: local index space + per-peer request lists (-1 padded), distinct ids share a scratch row."""
+        W = spec.world
+        cols = [triples[:, 0], triples[:, 2]] + ([negs[:, 0], negs[:, 2]] if negs is not None else [])
+        ids = torch.cat(cols).to(torch.int64)
+        remote = (ids < spec.lo) | (ids >= spec.hi)
+        rid, rinv = torch.unique(ids[remote], return_inverse=True)
+        owner = torch.div(rid, spec.rows_per, rounding_mode="floor")
+        send_ids = torch.full((W * cap,), -1, dtype=torch.int32)
+        counts = torch.zeros(W + 1, dtype=torch.int32)
+        slot = torch.zeros_like(rid)
+        for q in range(W):
+            m = owner == q
+            n = int(m.sum())
+            counts[q] = n
+            if n > cap:
+                counts[W] = 1
+                n = cap
+            pos = torch.arange(int(m.sum())).clamp(max=cap - 1)
+            slot[m] = q * cap + pos
+            send_ids[q * cap:q * cap + n] = (rid[m][:n] - q * spec.rows_per).to(torch.int32)
+        loc = ids - spec.lo
+        loc[remote] = spec.n_local + slot[rinv]
+        b = int(triples.shape[0])
+        xl = torch.stack([loc[:b], triples[:, 1].to(torch.int64), loc[b:2 * b]], 1).to(torch.int32).contiguous()
+        nl = None
+        if negs is not None:
+            nn = int(negs.shape[0])
+            nl = torch.stack([loc[2 * b:2 * b + nn], negs[:, 1].to(torch.int64), loc[2 * b + nn:]], 1).to(torch.int32).contiguous()
+        if not hasattr(self, "_route_counts"):
+            self._route_counts = counts
+        else:
+            self._route_counts[:W] = counts[:W]
+            self._route_counts[W] |= counts[W]
+        return xl, nl, send_ids, self._route_counts
+
+    def gather_rows(self, table, idx, name="gathered"):
+        i = idx.to(torch.int64)
+        out = table[i.clamp(min=0)].clone()
+        out[i < 0] = 0
+        return out
+
+    def scatter_add_rows(self, table, idx, src):
+        i = idx.to(torch.int64)
+        table.index_add_(0, i[i >= 0], src[i >= 0])
+
     def sample_corruptions(self, triples, eta, seed, step, sample_base=0, sample_range=None, row_offset=0, b_global=0):
         X = triples.numpy()
         negs = O.generate_corruptions(X, int(sample_range or self.n_ents), eta, seed, step, row_offset,
