@@ -100,6 +100,11 @@ SIGNATURES = {
     "amdkge_rank_filter": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, P, P, P, I64, I64, P, P, P]),
     "amdkge_rank_compose": (C.c_int, [P, P, I64, I32, P, I64, P]),
     "amdkge_filter_ranges": (C.c_int, [P, P, I64, P, I64, I32, I64, I64, P, P, P]),
+    "amdkge_corruption_scores": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, I64, I64, P, I64, P, P]),
+    "amdkge_row_dots": (C.c_int, [P, I64, P, I32, P, I64, I64, P, I64, P]),
+    "amdkge_row_sqnorms": (C.c_int, [P, I32, P, I64, I64, C.c_float, I32, P, P]),
+    "amdkge_pair_distances": (C.c_int, [P, I64, P, I32, P, I64, P, I32, I32, P, P]),
+    "amdkge_topk_rows": (C.c_int, [P, I64, I64, I64, P, P, P, I32, I32, P, P, P]),
     "amdkge_shard_route_workspace_bytes": (I64, [I64, I64]),
     "amdkge_shard_route": (C.c_int, [I64, I32, I32, P, I64, P, I64, I32, P, P, P, P, P, P]),
     "amdkge_gather_rows": (C.c_int, [P, I32, P, I64, P, P]),

@@ -165,9 +165,11 @@ struct CountArgs {
     RankGeom g;
     float sgn_scale;
     int qtiles, splits;   // MFMA kernel: logical grid, decoded from a 1-D XCD-aware launch
+    float* scores;        // STORE variant of the VALU tile kernel: [n][ld] un-quantised scores instead of counts
+    int64_t ld;
 };
 
-template <int MODE, bool V4>
+template <int MODE, bool V4, bool STORE = false>
 __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
     constexpr int NQF = ModeTraits<MODE>::NQF, NEF = ModeTraits<MODE>::NEF;
     __shared__ __attribute__((aligned(16))) float Qs[NQF][KT][LDP];
@@ -179,11 +181,13 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
     const int64_t e_begin = a.ent_lo + (int64_t)blockIdx.y * a.ent_per_block;
     const int64_t e_end = min(a.ent_hi, e_begin + a.ent_per_block);
 
-    int qp[4];
+    int qp[4] = {0, 0, 0, 0};
+    if constexpr (!STORE) {
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int64_t qi = q0 + tq * 4 + x;
-        qp[x] = a.qpos[qi < a.n ? qi : a.n - 1];
+        for (int x = 0; x < 4; ++x) {
+            const int64_t qi = q0 + tq * 4 + x;
+            qp[x] = a.qpos[qi < a.n ? qi : a.n - 1];
+        }
     }
     int cgt[4] = {0, 0, 0, 0}, ceq[4] = {0, 0, 0, 0};
 
@@ -275,6 +279,19 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
             }
             __syncthreads();
         }
+        if constexpr (STORE) {
+            // ---- epilogue of the STORE variant: the scores themselves (discovery: top-k / nearest neighbours) ----
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int64_t qi = q0 + tq * 4 + x;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    const int64_t ej = et + te * 4 + y;
+                    if (qi < a.n && ej < e_end) a.scores[qi * a.ld + (ej - a.ent_lo)] = a.sgn_scale * acc[x][y];
+                }
+            }
+            continue;
+        }
         // ---- epilogue: quantise, compare, count ----
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
@@ -287,6 +304,7 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
             }
         }
     }
+    if constexpr (STORE) return;
     // reduce over the 16 lanes (te) that share the same queries, one atomic pair per query per block
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
@@ -1009,4 +1027,64 @@ extern "C" int amdkge_rank_compose(const int32_t* d_counts, const int32_t* d_sub
     if (!d_counts || !d_ranks) return set_error(AMDKGE_EINVAL, "rank_compose: NULL pointer");
     hipLaunchKernelGGL(rank_compose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_counts, d_sub, n, strategy, d_ranks, rank_stride);
     return check_launch("rank_compose");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Discovery: the un-quantised corruption scores themselves, for a bounded chunk of queries, through the
+// SAME prep + tile kernels (same rounding points and accumulation chain as the ranks).  Callers stream chunks through
+// amdkge_topk_rows (kge_discovery.hip), so the reference's (n, m) score matrix never exists for more than a chunk.
+// ------------------------------------------------------------------------------------------------
+static int launch_store(int mode, bool v4, CountArgs& a, int64_t n, int64_t m, hipStream_t st) {
+    const int64_t qtiles = (n + QT - 1) / QT, etiles = (m + ET - 1) / ET;
+    int64_t tiles_per = (etiles * qtiles + 4095) / 4096;   // ~4096 blocks: enough to fill the chip, few enough to amortise the Q reloads
+    if (tiles_per < 1) tiles_per = 1;
+    const int64_t splits = (etiles + tiles_per - 1) / tiles_per;
+    if (splits > 65535 || qtiles > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "scores: too many tiles for one launch; split the queries");
+    a.ent_per_block = (int)(tiles_per * ET);
+    const dim3 grid((unsigned)qtiles, (unsigned)splits);
+#define KGE_STORE(MODE) do { if (v4) hipLaunchKernelGGL((rank_count_kernel<MODE, true, true>), grid, dim3(256), 0, st, a); \
+                             else hipLaunchKernelGGL((rank_count_kernel<MODE, false, true>), grid, dim3(256), 0, st, a); } while (0)
+    switch (mode) {
+        case MODE_DOT: KGE_STORE(MODE_DOT); break;
+        case MODE_L1: KGE_STORE(MODE_L1); break;
+        case MODE_L1_SUB: KGE_STORE(MODE_L1_SUB); break;
+        case MODE_ROT_O: KGE_STORE(MODE_ROT_O); break;
+        default: KGE_STORE(MODE_ROT_S); break;
+    }
+#undef KGE_STORE
+    return check_launch("corruption_scores");
+}
+
+extern "C" int amdkge_corruption_scores(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
+                                        int64_t n, int32_t side, const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
+                                        float* d_scores, int64_t ld, void* d_work, void* stream) {
+    if (int rc = validate_model(m)) return rc;
+    if (side != AMDKGE_SIDE_S && side != AMDKGE_SIDE_O) return set_error(AMDKGE_EINVAL, "corruption_scores: side must be AMDKGE_SIDE_S or AMDKGE_SIDE_O");
+    if (n < 0 || ent_lo < 0 || ent_hi < ent_lo || ld < ent_hi - ent_lo) return set_error(AMDKGE_EINVAL, "corruption_scores: bad sizes");
+    if (!d_ent_ids && ent_hi > m->n_ents) return set_error(AMDKGE_EINVAL, "corruption_scores: entity range outside the table");
+    if (n == 0 || ent_hi == ent_lo) return AMDKGE_OK;
+    if (!d_ent || !d_rel || !d_triples || !d_scores || !d_work) return set_error(AMDKGE_EINVAL, "corruption_scores: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const RankGeom g = geom_of(m, side);
+    const Workspace w = carve(d_work, m, n);
+    if (int rc = run_prep(m, d_ent, d_rel, d_triples, n, side, g, w, st)) return rc;
+    const ModelConst mc = model_const(m);
+    CountArgs a{};
+    a.ent = d_ent; a.Q = w.Q; a.qpos = w.qpos; a.ent_ids = d_ent_ids; a.n = n; a.ent_lo = ent_lo; a.ent_hi = ent_hi; a.g = g;
+    a.sgn_scale = mc.score_sign * mc.score_scale; a.scores = d_scores; a.ld = ld;
+    const bool v4 = (g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
+    return launch_store(mode_of(m->scoring_type, side), v4, a, n, ent_hi - ent_lo, st);
+}
+
+extern "C" int amdkge_row_dots(const float* d_q, int64_t n, const float* d_table, int32_t row_floats, const int32_t* d_ent_ids,
+                               int64_t ent_lo, int64_t ent_hi, float* d_out, int64_t ld, void* stream) {
+    if (n < 0 || row_floats < 1 || ent_lo < 0 || ent_hi < ent_lo || ld < ent_hi - ent_lo) return set_error(AMDKGE_EINVAL, "row_dots: bad sizes");
+    if (n == 0 || ent_hi == ent_lo) return AMDKGE_OK;
+    if (!d_q || !d_table || !d_out) return set_error(AMDKGE_EINVAL, "row_dots: NULL pointer");
+    CountArgs a{};
+    a.ent = d_table; a.Q = d_q; a.qpos = nullptr; a.ent_ids = d_ent_ids; a.n = n; a.ent_lo = ent_lo; a.ent_hi = ent_hi;
+    a.g = RankGeom{row_floats, 0, 0, row_floats, row_floats, 1.f};
+    a.sgn_scale = 1.f; a.scores = d_out; a.ld = ld;
+    const bool v4 = row_floats % 4 == 0 && (((uintptr_t)d_q | (uintptr_t)d_table) & 15) == 0;
+    return launch_store(MODE_DOT, v4, a, n, ent_hi - ent_lo, (hipStream_t)stream);
 }

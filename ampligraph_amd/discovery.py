@@ -1,10 +1,15 @@
-"""Discovery helpers that are thin callers of the hot path: query_topn
+"""Discovery helpers on the device: query_topn
 (/root/reference/ampligraph/discovery/discovery.py:985-1168) and find_nearest_neighbours (:1171-1244).
 
-The reference materialises one STRING triple per candidate and calls model.predict; here the candidate triples are
-built as int32 ids on the device, scored by one launch of the libamdkge score kernel (the fixed s / p rows stay in
-L2) and only the top_n ids / scores travel back.  Same arguments, validation and error behaviour."""
+The reference materialises one STRING triple per candidate, calls model.predict and argsorts on the host; its nearest
+neighbours are sklearn on the host.  Here an entity completion is ONE query through the 1-vs-all corruption-score kernels
+of evaluate() (amdkge_corruption_scores: same prep + tile kernels as the ranks) followed by a streaming top-k selection
+kernel (amdkge_topk_rows); nearest neighbours are dot products on the same tile kernel with the norms folded into the
+selection.  Only top_n ids / scores travel back.  Both work on a row-sharded entity table (per-shard lists, merged).
+Same arguments, validation and error behaviour as the reference."""
 import numpy as np
+
+from . import _ffi
 
 
 def _known(indexer, values, type_of):
@@ -42,37 +47,78 @@ def query_topn(model, top_n=10, head=None, relation=None, tail=None, ents_to_con
             raise ValueError("`rels_to_consider` must be a list or numpy array.")
         if not _known(ix, rels_to_consider, "r"):
             raise ValueError("Relations in `rels_to_consider` have not been seen by the model.")
-    if getattr(model, "_spec", None) is not None:
-        raise NotImplementedError("query_topn with a row-sharded entity table")
     eng = model._engine
     dev = eng.device
+    sp = getattr(model, "_spec", None)
+    one = lambda v, t: int(ix.get_indexes(np.asarray([v]), t)[0])   # noqa: E731
 
-    def ids(values, type_of, count):
-        if values is None or len(values) == 0:
-            return torch.arange(count, dtype=torch.int32, device=dev)
-        return torch.as_tensor(np.asarray(ix.get_indexes(np.asarray(values), type_of), dtype=np.int32)).to(dev)
+    if relation is None:   # complete the relation: a handful of candidates, scored as ordinary triples
+        if rels_to_consider is None or len(rels_to_consider) == 0:
+            cand = np.arange(model._n_rels, dtype=np.int32)
+        else:
+            cand = np.asarray(ix.get_indexes(np.asarray(rels_to_consider), "r"), dtype=np.int32)
+        tri = np.stack([np.full_like(cand, one(head, "e")), cand, np.full_like(cand, one(tail, "e"))], 1)
+        scores = model._score_dev(torch.as_tensor(tri).to(dev))
+        n = min(int(top_n), len(cand))
+        idx, val = eng.topk_rows(scores.view(1, -1), n)
+        out = tri[idx[0].cpu().numpy().astype(np.int64)]
+        return ix.get_indexes(out, "t", "ind2raw"), val[0].cpu().numpy().astype(np.float32)
 
-    one = lambda v, t: int(ix.get_indexes(np.asarray([v]), t)[0])
-    if relation is None:
-        cand = ids(rels_to_consider, "r", model._n_rels)
-        cols = [torch.full_like(cand, one(head, "e")), cand, torch.full_like(cand, one(tail, "e"))]
+    # complete an entity: 1-vs-all corruption scores of ONE query on the rank kernels + a top-k selection on the device
+    side = _ffi.SIDE_O if tail is None else _ffi.SIDE_S
+    fixed = one(head if tail is None else tail, "e")
+    r_id = one(relation, "r")
+    q = np.array([[fixed, r_id, fixed]], dtype=np.int32)   # the replaced column is ignored by the corruption scores
+    cand_ids = None
+    if ents_to_consider is not None and len(ents_to_consider) > 0:
+        cand_ids = np.asarray(ix.get_indexes(np.asarray(ents_to_consider), "e"), dtype=np.int64)
+    n_cand = model._n_ents if cand_ids is None else len(cand_ids)
+    n = min(int(top_n), n_cand)
+    if n > 1024:
+        raise ValueError("query_topn: top_n is limited to 1024 on the device path")
+    if sp is None:
+        ids_dev = None if cand_ids is None else torch.as_tensor(cand_ids.astype(np.int32)).to(dev)
+        pos, val = eng.corruption_topk(torch.as_tensor(q).to(dev), side, n, ent_ids=ids_dev)
+        pos = pos[0].cpu().numpy().astype(np.int64)
+        ents = pos if cand_ids is None else cand_ids[pos]
+        val = val[0].cpu().numpy()
     else:
-        cand = ids(ents_to_consider, "e", model._n_ents)
-        r = torch.full_like(cand, one(relation, "r"))
-        cols = [torch.full_like(cand, one(head, "e")), r, cand] if head else [cand, r, torch.full_like(cand, one(tail, "e"))]
-    tri = torch.stack(cols, 1).contiguous()
-    scores = eng.score(tri)
-    n = min(int(top_n), int(tri.shape[0]))
-    top_s, top_i = torch.topk(scores, n, largest=True, sorted=True)
-    out = tri[top_i.long()].cpu().numpy()
-    return ix.get_indexes(out, "t", "ind2raw"), top_s.cpu().numpy().astype(np.float32)
+        # row-sharded table: every rank selects among ITS rows (the query's own rows are fetched behind the shard), the
+        # W partial lists (global ids, scores) are gathered and merged by a second selection
+        d = model._dist()
+        ql = model._localise(torch.as_tensor(q).to(dev))
+        if cand_ids is None:
+            loc, n_loc = None, sp.n_local
+        else:
+            loc = sp.local_subset(torch.as_tensor(cand_ids).to(dev))[0]
+            n_loc = int(loc.shape[0])
+        k_loc = min(n, 1024)
+        gid = torch.full((1, k_loc), -1, dtype=torch.int32, device=dev)
+        gval = torch.full((1, k_loc), float("-inf"), dtype=torch.float32, device=dev)
+        if n_loc > 0:
+            kk = min(k_loc, n_loc)
+            pos, val = eng.corruption_topk(ql, side, kk, ent_ids=loc, ent_lo=0, ent_hi=n_loc)
+            rows = pos[0].to(torch.int64) if loc is None else loc[pos[0].to(torch.int64)].to(torch.int64)
+            gid[0, :kk] = (rows + sp.lo).to(torch.int32)
+            gval[0, :kk] = val[0]
+        parts_i = [torch.empty_like(gid) for _ in range(sp.world)]
+        parts_v = [torch.empty_like(gval) for _ in range(sp.world)]
+        d.all_gather(parts_i, gid)
+        d.all_gather(parts_v, gval)
+        ents, val = eng.topk_rows(torch.cat(parts_v, 1).contiguous(), n, payload=torch.cat(parts_i, 1).contiguous())
+        ents, val = ents[0].cpu().numpy().astype(np.int64), val[0].cpu().numpy()
+    rel_col = np.full(n, r_id, dtype=np.int64)
+    fix_col = np.full(n, fixed, dtype=np.int64)
+    out = np.stack([fix_col, rel_col, ents], 1) if tail is None else np.stack([ents, rel_col, fix_col], 1)
+    return ix.get_indexes(out, "t", "ind2raw"), val.astype(np.float32)
 
 
 def find_nearest_neighbours(kge_model, entities, n_neighbors=10, entities_subset=None, metric="euclidean"):
     """k nearest neighbours of `entities` in embedding space (:1171-1244; the reference delegates to
-    sklearn.neighbors.NearestNeighbors on the host).  Distances on the device for "euclidean" / "cosine"; other
-    sklearn metrics fall back to sklearn on the downloaded embeddings.  Returns (neighbour labels, distances), each
-    (len(entities), n_neighbors), nearest first."""
+    sklearn.neighbors.NearestNeighbors on the host).  "euclidean" / "cosine": on the device -- dot products on the rank
+    tile kernel (GEMM form), norms folded into a per-row top-k selection; works with a row-sharded table (partial lists per
+    shard, merged).  Other sklearn metrics fall back to sklearn on the downloaded embeddings.  Returns (neighbour labels,
+    distances), each (len(entities), n_neighbors), nearest first."""
     import torch
 
     assert kge_model.is_fitted, "KGE model is not fit!"
@@ -83,23 +129,55 @@ def find_nearest_neighbours(kge_model, entities, n_neighbors=10, entities_subset
         all_neighbors = np.asarray(entities_subset)
         cand = np.asarray(ix.get_indexes(all_neighbors, "e"), dtype=np.int64)
     else:
-        cand = np.arange(kge_model._n_ents, dtype=np.int64)
-        all_neighbors = ix.get_indexes(cand, "e", "ind2raw")
-    assert n_neighbors < len(all_neighbors), "n_neighbors must be less than the number of entities being fit!"
-    tab = kge_model._entity_table()
-    unpack = kge_model._engine.unpack
-    E = unpack(tab[torch.as_tensor(cand).to(tab.device)])
-    Q = unpack(tab[torch.as_tensor(np.asarray(ix.get_indexes(np.asarray(entities), "e"), dtype=np.int64)).to(tab.device)])
-    if metric in ("euclidean", "l2", "minkowski"):
-        d = torch.cdist(Q.double(), E.double()).float()
-    elif metric == "cosine":
-        qn, en = torch.nn.functional.normalize(Q.double(), dim=1), torch.nn.functional.normalize(E.double(), dim=1)
-        d = (1.0 - qn @ en.T).float()
-    else:
+        cand = None
+        all_neighbors = None
+    n_all = kge_model._n_ents if cand is None else len(cand)
+    assert n_neighbors < n_all, "n_neighbors must be less than the number of entities being fit!"
+    eng = kge_model._engine
+    dev = eng.device
+    sp = getattr(kge_model, "_spec", None)
+    qid = np.asarray(ix.get_indexes(np.asarray(entities), "e"), dtype=np.int64)
+    k = int(n_neighbors)
+    if metric not in ("euclidean", "l2", "minkowski", "cosine") or k > 1024:
         from sklearn.neighbors import NearestNeighbors
 
-        knn = NearestNeighbors(n_neighbors=n_neighbors, metric=metric).fit(E.cpu().numpy())
-        dist, idx = knn.kneighbors(Q.cpu().numpy())
-        return np.asarray(all_neighbors)[idx], dist
-    dist, idx = torch.topk(d, int(n_neighbors), dim=1, largest=False, sorted=True)
-    return np.asarray(all_neighbors)[idx.cpu().numpy()], dist.cpu().numpy()
+        labels = all_neighbors if cand is not None else ix.get_indexes(np.arange(kge_model._n_ents), "e", "ind2raw")
+        E = kge_model.get_embeddings(labels)
+        knn = NearestNeighbors(n_neighbors=n_neighbors, metric=metric).fit(E)
+        dist, idx = knn.kneighbors(kge_model.get_embeddings(np.asarray(entities)))
+        return np.asarray(labels)[idx], dist
+    met = "cosine" if metric == "cosine" else "euclidean"
+    if sp is None:
+        Q = eng.ent[torch.as_tensor(qid).to(dev)]
+        ids_dev = None if cand is None else torch.as_tensor(cand.astype(np.int32)).to(dev)
+        pos, dist = eng.nearest_rows(Q, k, met, ent_ids=ids_dev)
+        pos = pos.cpu().numpy().astype(np.int64)
+        ids = pos if cand is None else cand[pos]
+        dist = dist.cpu().numpy()
+    else:
+        d = kge_model._dist()
+        fake = np.stack([qid, np.zeros_like(qid), qid], 1).astype(np.int32)
+        ql = kge_model._localise(torch.as_tensor(fake).to(dev))          # query rows, fetched behind the shard where remote
+        Q = eng.ent[ql[:, 0].to(torch.int64)]
+        if cand is None:
+            loc, n_loc = None, sp.n_local
+        else:
+            loc = sp.local_subset(torch.as_tensor(cand).to(dev))[0]
+            n_loc = int(loc.shape[0])
+        nq = len(qid)
+        gid = torch.full((nq, k), -1, dtype=torch.int32, device=dev)
+        gd = torch.full((nq, k), float("inf"), dtype=torch.float32, device=dev)
+        if n_loc > 0:
+            kk = min(k, n_loc)
+            pos, dl = eng.nearest_rows(Q, kk, met, ent_ids=loc, ent_lo=0, ent_hi=n_loc)
+            rows = pos.to(torch.int64) if loc is None else loc[pos.to(torch.int64)].to(torch.int64)
+            gid[:, :kk] = (rows + sp.lo).to(torch.int32)
+            gd[:, :kk] = dl
+        parts_i = [torch.empty_like(gid) for _ in range(sp.world)]
+        parts_d = [torch.empty_like(gd) for _ in range(sp.world)]
+        d.all_gather(parts_i, gid)
+        d.all_gather(parts_d, gd)
+        ids, dist = eng.topk_rows(torch.cat(parts_d, 1).contiguous(), k, largest=False, payload=torch.cat(parts_i, 1).contiguous())
+        ids, dist = ids.cpu().numpy().astype(np.int64), dist.cpu().numpy()
+    labels = ix.get_indexes(ids.reshape(-1), "e", "ind2raw").reshape(ids.shape)
+    return labels, dist.astype(np.float32)

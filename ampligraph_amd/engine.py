@@ -321,6 +321,71 @@ class KgeEngine:
                                     _ptr(out), _stream()))
         return out
 
+    # ------------------------------------------------------------------ discovery (kge_discovery.hip, kge_rank.hip)
+    SCORE_CHUNK_BYTES = 256 << 20   # bound of the transient (queries x candidates) score block
+
+    def topk_rows(self, vals, k, largest=True, col_scale=None, col_bias=None, payload=None):
+        """(idx int32 [n,k], val fp32 [n,k]) of the k best entries per row of vals [n,m] (amdkge_topk_rows); with `payload`
+        (int32, same shape and row stride as vals) idx holds the payload entries of the selected columns."""
+        n, m = int(vals.shape[0]), int(vals.shape[1])
+        idx = torch.empty(n, int(k), dtype=torch.int32, device=self.device)
+        val = torch.empty(n, int(k), dtype=torch.float32, device=self.device)
+        check(self.lib.amdkge_topk_rows(_ptr(vals), n, m, int(vals.stride(0)), _ptr(col_scale), _ptr(col_bias), _ptr(payload), int(k), 1 if largest else 0,
+                                        _ptr(idx), _ptr(val), _stream()))
+        return idx, val
+
+    def corruption_topk(self, triples, side, k, ent_ids=None, ent_lo=0, ent_hi=None):
+        """Top-k scoring corruptions of one side for every query triple: (positions int32 [n,k] into the candidate list /
+        row range, scores fp32 [n,k]).  Queries go through amdkge_corruption_scores in chunks whose score block stays under
+        SCORE_CHUNK_BYTES, each chunk straight into amdkge_topk_rows."""
+        n = int(triples.shape[0])
+        if ent_hi is None:
+            ent_hi = self.n_ents if ent_ids is None else int(ent_ids.shape[0])
+        m = int(ent_hi) - int(ent_lo)
+        rows = max(1, min(n, self.SCORE_CHUNK_BYTES // max(4 * m, 1)))
+        out_i = torch.empty(n, int(k), dtype=torch.int32, device=self.device)
+        out_v = torch.empty(n, int(k), dtype=torch.float32, device=self.device)
+        for c0 in range(0, n, rows):
+            c1 = min(n, c0 + rows)
+            blk = self._buf("disc_scores", (c1 - c0, m), torch.float32)
+            work = self._workspace(c1 - c0)
+            check(self.lib.amdkge_corruption_scores(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples[c0:c1]), c1 - c0, int(side),
+                                                    _ptr(ent_ids), int(ent_lo), int(ent_hi), _ptr(blk), m, _ptr(work), _stream()))
+            i_, v_ = self.topk_rows(blk, k)
+            out_i[c0:c1], out_v[c0:c1] = i_, v_
+        return out_i, out_v
+
+    def nearest_rows(self, q_rows, k, metric="euclidean", ent_ids=None, ent_lo=0, ent_hi=None, table=None):
+        """k nearest table rows of every query row (stored layout, [n, Ks]), nearest first: (positions int32 [n,k],
+        distances fp32 [n,k]).  Selection in GEMM form on the tile kernel (amdkge_row_dots) with the norms folded into
+        amdkge_topk_rows' column scale / bias (euclidean: v = <q,e> - |e|^2 / 2; cosine: v = <q,e> / |e|) -- the distance matrix
+        never exists; the k survivors are then re-measured exactly (amdkge_pair_distances: the GEMM form cancels for near
+        neighbours) and put in their final order."""
+        table = self.ent if table is None else table
+        n = int(q_rows.shape[0])
+        if ent_hi is None:
+            ent_hi = int(table.shape[0]) if ent_ids is None else int(ent_ids.shape[0])
+        m = int(ent_hi) - int(ent_lo)
+        Kf = int(table.shape[1])
+        q_rows = q_rows.contiguous()
+        col = torch.empty(m, dtype=torch.float32, device=self.device)
+        cosine = metric == "cosine"
+        check(self.lib.amdkge_row_sqnorms(_ptr(table), Kf, _ptr(ent_ids), int(ent_lo), m, -0.5, 1 if cosine else 0, _ptr(col), _stream()))
+        rows = max(1, min(n, self.SCORE_CHUNK_BYTES // max(4 * m, 1)))
+        out_i = torch.empty(n, int(k), dtype=torch.int32, device=self.device)
+        out_v = torch.empty(n, int(k), dtype=torch.float32, device=self.device)
+        for c0 in range(0, n, rows):
+            c1 = min(n, c0 + rows)
+            blk = self._buf("disc_scores", (c1 - c0, m), torch.float32)
+            check(self.lib.amdkge_row_dots(_ptr(q_rows[c0:c1]), c1 - c0, _ptr(table), Kf, _ptr(ent_ids), int(ent_lo), int(ent_hi), _ptr(blk), m,
+                                           _stream()))
+            i_, v_ = self.topk_rows(blk, k, True, col if cosine else None, None if cosine else col)
+            out_i[c0:c1], out_v[c0:c1] = i_, v_
+        dist = torch.empty(n, int(k), dtype=torch.float32, device=self.device)
+        check(self.lib.amdkge_pair_distances(_ptr(q_rows), n, _ptr(table), Kf, _ptr(ent_ids), int(ent_lo), _ptr(out_i), int(k), 1 if cosine else 0,
+                                             _ptr(dist), _stream()))
+        return self.topk_rows(dist, k, largest=False, payload=out_i)   # final order by the exact distances
+
     def platt_step(self, scores_pos, scores_neg, w, b, label_pos, label_neg, weight_pos, weight_neg):
         """(loss, dloss/dw, dloss/db) of the Platt-scaling objective for one batch (amdkge_platt_step)."""
         out = torch.zeros(3, dtype=torch.float64, device=self.device)

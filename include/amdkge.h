@@ -261,6 +261,37 @@ int amdkge_rank_compose(const int32_t* d_counts, const int32_t* d_sub, int64_t n
                         int32_t* d_ranks, int64_t rank_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Discovery helpers on the device: query_topn (discovery/discovery.py:985-1168) and find_nearest_neighbours (:1171-1244).
+ *
+ * amdkge_corruption_scores: the un-quantised scores of EVERY corruption of one side, d_scores[i * ld + j] = score of triple i
+ *   with its subject (side S) / object (side O) replaced by candidate j (table row ent_lo + j, or d_ent_ids[ent_lo + j]) --
+ *   <Model>._get_subject/object_corruption_scores (TransE.py:56-114, DistMult.py:51-99, ComplEx.py:65-151, HolE.py:47-89,
+ *   RotatE.py:107-217) through the same prep + tile kernels as amdkge_rank_counts (same accumulation chain).  Callers pass
+ *   a bounded chunk of queries and select with amdkge_topk_rows: the (n, m) matrix never exists beyond a chunk.
+ *   d_work: amdkge_rank_workspace_bytes(m, n) bytes.
+ * amdkge_row_dots   : d_out[i * ld + j] = <d_q[i], row j> (rows of row_floats floats) -- the GEMM form of euclidean / cosine
+ *   nearest neighbours (|q - e|^2 = |q|^2 + |e|^2 - 2 <q, e>)
+ * amdkge_row_sqnorms: d_out[j] = mul * |row j|^2, or 1 / |row j| when rsqrt != 0, for rows lo + j (or d_ids[lo + j])
+ * amdkge_topk_rows  : per row i of d_vals [n, m] (leading dimension ld) the k (<= 1024) largest (largest != 0) or smallest
+ *   entries of v[j] = d_vals[i*ld + j] * d_col_scale[j] + d_col_bias[j] (either array may be NULL): d_out_idx [n, k] column
+ *   indices (-1 when m < k) -- or, with d_payload int32 [n, ld], the payload entries of those columns (merging per-shard
+ *   candidate lists: payload = their global ids) --, d_out_val [n, k] the values v, best first; equal values in order of
+ *   increasing column. */
+int amdkge_corruption_scores(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples, int64_t n,
+                             int32_t side, const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi, float* d_scores, int64_t ld,
+                             void* d_work, void* stream);
+int amdkge_row_dots(const float* d_q, int64_t n, const float* d_table, int32_t row_floats, const int32_t* d_ent_ids,
+                    int64_t ent_lo, int64_t ent_hi, float* d_out, int64_t ld, void* stream);
+int amdkge_row_sqnorms(const float* d_table, int32_t row_floats, const int32_t* d_ids, int64_t lo, int64_t n, float mul, int32_t rsqrt,
+                       float* d_out, void* stream);
+int amdkge_topk_rows(const float* d_vals, int64_t n, int64_t m, int64_t ld, const float* d_col_scale, const float* d_col_bias,
+                     const int32_t* d_payload, int32_t k, int32_t largest, int32_t* d_out_idx, float* d_out_val, void* stream);
+/* exact distances of explicit pairs: d_out[i*k + j] = |d_q[i] - row(d_pos[i*k + j])| (cosine != 0: 1 - cos), rows addressed like
+ * amdkge_row_sqnorms (lo + pos, or d_ids[lo + pos]); pos < 0 -> +inf.  Re-measures the neighbours the GEMM-form selection kept. */
+int amdkge_pair_distances(const float* d_q, int64_t n, const float* d_table, int32_t row_floats, const int32_t* d_ids, int64_t lo,
+                          const int32_t* d_pos, int32_t k, int32_t cosine, float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Multi-GPU data path (one process per GPU; the host issues the RCCL collectives between these calls -- see
  * ampligraph_amd/sharded.py and trainer.py).  The reference has no multi-device path; what these replace is its
  * partitioned training loop, ScoringBasedEmbeddingModel.py:227,259-261 (corruptions from the partition's entities) and

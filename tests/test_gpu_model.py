@@ -496,7 +496,7 @@ def test_query_topn_and_neighbours(gpu_lib):
     assert np.all([x in ['y', 'x'] for x in Y[:, 1]])
     Y, S = query_topn(model, top_n=100, relation=pred, tail=obj)
     assert all(S[i] >= S[i + 1] for i in range(len(S) - 1))
-    assert np.allclose(S, model.predict(Y), rtol=1e-6)          # same scores as the predict path on the returned triples
+    assert np.allclose(S, model.predict(Y), rtol=1e-5, atol=1e-6)   # same scores as the predict path on the returned triples (fp32 summation order differs)
     nb, dist = find_nearest_neighbours(model, ['b'], n_neighbors=3, entities_subset=['a', 'c', 'd', 'e', 'f'])
     emb = model.get_embeddings(['a', 'c', 'd', 'e', 'f']).astype(np.float64)
     d_ref = np.sort(np.linalg.norm(emb - model.get_embeddings(['b']).astype(np.float64), axis=1))[:3]
