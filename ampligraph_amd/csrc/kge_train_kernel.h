@@ -37,6 +37,8 @@ struct TrainArgs {
     // owner-computes (STAGE) outputs: see kge_train_tiled.hip
     float* stage_rows;       // [B][4][K]: gradient rows of the positive's s and o (unless pos_atomic), then the side rows A, B
     int pos_atomic;          // the positives' own s / o rows go through atomics into g_ent (skewed graphs)
+    int ns;                  // staged rows per positive: 4, or 5 in deterministic mode (the relation-row gradient is staged too)
+    int det;                 // deterministic mode (AMDKGE_TILED_DETERMINISTIC): no atomics on any gradient
     uint8_t* touched;        // pos_atomic + lazy optimizer: byte per entity row, set for rows that received an atomic row-add
     StageEntry* st_lists;    // [n_tiles][cap] buckets of row-gradient entries, by owning tile
     StageEntry* st_ovf;      // overflow of full buckets
@@ -414,8 +416,8 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         static_assert(!STAGE || VEC == 4, "staging uses the 16-byte layout");
         constexpr bool TRILINEAR = (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
         if (active && !KGE_DBG(a, 64)) {
-            float* qa = a.stage_rows + ((int64_t)i * 4 + 2) * a.K;
-            float* qb = a.stage_rows + ((int64_t)i * 4 + 3) * a.K;
+            float* qa = a.stage_rows + ((int64_t)i * a.ns + 2) * a.K;
+            float* qb = a.stage_rows + ((int64_t)i * a.ns + 3) * a.K;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if (!qok[c]) continue;
@@ -847,8 +849,8 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 emit_row(a.g_ent + (int64_t)po * a.K, go, a.K, 1.f);
                 if (a.touched && ts == 0) { a.touched[ps] = 1; a.touched[po] = 1; }   // same value from every writer
             } else {
-                float* ps_ = a.stage_rows + ((int64_t)i * 4 + 0) * a.K;
-                float* po_ = a.stage_rows + ((int64_t)i * 4 + 1) * a.K;
+                float* ps_ = a.stage_rows + ((int64_t)i * a.ns + 0) * a.K;
+                float* po_ = a.stage_rows + ((int64_t)i * a.ns + 1) * a.K;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     if (!qok[c]) continue;
@@ -860,7 +862,19 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 }
             }
         }
-        if (active && !KGE_DBG(a, 2)) {
+        if (active && a.det) {
+            // deterministic mode: the relation-row gradient of this positive is staged as a fifth row; rel_backward_det_kernel
+            // adds the rows of one relation in batch order (fp32 atomics would add them in arrival order)
+            const float mul = (MODEL == AMDKGE_ROTATE) ? 1.f / a.mc.phase_div : 1.f;   // RotatE: d/dtheta = d/dphi / phase_div, second half 0
+            float* pr_ = a.stage_rows + ((int64_t)i * a.ns + 4) * a.K;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (!qok[c]) continue;
+#pragma unroll
+                for (int h = 0; h < NC; ++h)
+                    *reinterpret_cast<float4*>(pr_ + qoff[c] + h * a.k) = make_float4(gp[c][0][h] * mul, gp[c][1][h] * mul, gp[c][2][h] * mul, gp[c][3][h] * mul);
+            }
+        } else if (active && !KGE_DBG(a, 2)) {
             // relation rows: few and hot -> atomic row-add into the dense relation gradient (swept by kge_opt.hip)
             if constexpr (MODEL == AMDKGE_ROTATE) emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.k, 1.f / a.mc.phase_div);
             else emit_row(a.g_rel + (int64_t)pp * a.K, gp, a.K, 1.f);

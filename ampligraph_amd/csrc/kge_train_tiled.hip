@@ -51,6 +51,9 @@ struct TileArgs {
     float* g_ent;             // dense entity gradient buffer
     int apply_update;         // 1: optimizer applied from LDS; 0: g_ent receives the entity gradient (data parallel)
     int pos_atomic;           // g_ent holds the s / o rows of the positives (forward kernel's atomics): fold them in
+    int ns;                   // staged rows per positive (4; 5 in deterministic mode)
+    int det;                  // deterministic mode: the tile's entries are sorted into a canonical order before they are added
+    int sort_cap;             // det: entries the LDS sort buffer holds (power of two)
     int lazy;                 // touched-rows optimizer mode (amdkge_opt.lazy): rows without an entry keep their bits
     uint8_t* touched;         // lazy + pos_atomic: rows the forward kernel's atomics touched (read, then cleared here)
     const float* rel;         // live relation table (TransE / RotatE side of the gradient)
@@ -64,6 +67,7 @@ struct TileArgs {
     OptArgs rel_opt;          // fused relation-table sweep (rel_blocks > 0): blocks [n_tiles, n_tiles + rel_blocks)
     int rel_blocks;
     int64_t n_rows;
+    int64_t n_rels;
     int k, K, nq;             // stored half width, floats per stored row, quads per half
     int k_live;               // the model's k (RotatE: units behind it are zero padding, see grad_unit)
     int tile_rows, n_tiles, cap, ovf_cap;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     auto load_ops = [&](uint32_t pos, uint32_t meta, int pp, float4 (&v)[CH][NC], float4 (&pv)[CH][NX], float4 (&ev)[CH][NX]) {
         const int role = meta & 3;   // 0: corruption, object replaced; 1: corruption, subject replaced; 2: own s row; 3: own o row
         const int which = (role == 0) ? 2 : (role == 1) ? 3 : (role == 2) ? 0 : 1;
-        const float* src = a.stage_rows + ((int64_t)pos * 4 + which) * a.K;
+        const float* src = a.stage_rows + ((int64_t)pos * a.ns + which) * a.K;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -239,6 +243,59 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
 
     // ---- this tile's bucket: every wave walks all of it, 64 entries per coalesced 16-byte load ----
     const StageEntry* list = a.lists + (size_t)tile * a.cap;
+    if (a.det) {
+        // Deterministic mode.  The position of an entry in its bucket is decided by a returning atomic, i.e. by arrival
+        // order, and fp32 addition is not associative.  Here the tile's entries (bucket + its share of the overflow list) are
+        // first sorted in LDS by their full 128-bit content -- a canonical order that depends on the batch only (entries
+        // that compare equal ARE equal) -- and then added in that order.
+        uint4* sbuf = reinterpret_cast<uint4*>(smem + (((size_t)a.tile_rows * a.K * 4 + (size_t)a.tile_rows * gw + 15) & ~(size_t)15));
+        __shared__ int s_total;
+        if (tid == 0) s_total = cnt;
+        for (int i = tid; i < cnt && i < a.sort_cap; i += TILE_THREADS) sbuf[i] = reinterpret_cast<const uint4*>(list)[i];
+        __syncthreads();
+        for (int base = 0; base < on; base += TILE_THREADS) {
+            uint4 e = make_uint4(0, 0, 0, 0xFFFFFFFFu);
+            if (base + tid < on) e = reinterpret_cast<const uint4*>(a.ovf)[base + tid];
+            if ((int64_t)e.w >= t0 && (int64_t)e.w < t1) {   // .w = dest
+                const int at = atomicAdd(&s_total, 1);
+                if (at < a.sort_cap) sbuf[at] = e;
+            }
+        }
+        __syncthreads();
+        int total = s_total;
+        if (total > a.sort_cap) {   // more entries than the sort buffer holds (a very hot tile): flagged, the host raises
+            if (tid == 0) atomicExch(a.counters + (size_t)(a.n_tiles + 2) * 32, 1);
+            total = a.sort_cap;
+        }
+        int n2 = 64;
+        while (n2 < total) n2 <<= 1;
+        for (int i = total + tid; i < n2; i += TILE_THREADS) sbuf[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        __syncthreads();
+        auto less = [](const uint4& x, const uint4& y) {
+            if (x.x != y.x) return x.x < y.x;
+            if (x.y != y.y) return x.y < y.y;
+            if (x.z != y.z) return x.z < y.z;
+            return x.w < y.w;
+        };
+        for (int kk = 2; kk <= n2; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < n2; i += TILE_THREADS) {
+                    const int p = i ^ j;
+                    if (p > i) {
+                        const uint4 x = sbuf[i], y = sbuf[p];
+                        const bool up = (i & kk) == 0;
+                        if (up ? less(y, x) : less(x, y)) { sbuf[i] = y; sbuf[p] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int base = 0; base < total; base += 64) {
+            StageEntry mine{0u, 0u, 0.f, 0u};
+            const bool in = base + lane < total;
+            if (in) { const uint4 e = sbuf[base + lane]; mine = StageEntry{e.x, e.y, __uint_as_float(e.z), e.w}; }
+            process(mine, __ballot(in && (int)((mine.meta >> 2) % G) == grp));
+        }
+    } else {
     for (int base = 0; base < cnt; base += 64) {
         StageEntry mine{0u, 0u, 0.f, 0u};
         const bool in = base + lane < cnt;
@@ -251,6 +308,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         if (base + lane < on) mine = a.ovf[base + lane];
         const bool hit = (int64_t)mine.dest >= t0 && (int64_t)mine.dest < t1;
         process(mine, __ballot(hit && (int)((mine.meta >> 2) % G) == grp));
+    }
     }
 
     // ---- flush: the tile's rows leave LDS exactly once ------------------------------------------------
@@ -312,6 +370,41 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     }
 }
 
+// Deterministic mode: the relation-row gradient.  One workgroup per relation walks the batch in order, collects the
+// positives of its relation (compacted in batch order through a ballot prefix) and adds their staged fifth rows in that
+// order, every thread owning fixed columns of the row: the same additions in the same order on every run.
+__global__ __launch_bounds__(256) void rel_backward_det_kernel(const int32_t* __restrict__ triples, int64_t B, const float* __restrict__ stage_rows,
+                                                               int ns, int K, float* __restrict__ g_rel) {
+    __shared__ int s_idx[256];
+    __shared__ int s_wave[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float acc[16];   // K <= 4096 floats (k <= 2048 complex units): 16 columns per thread
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (int64_t base = 0; base < B; base += 256) {
+        const int64_t i = base + tid;
+        const bool hit = i < B && triples[3 * i + 1] == r;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wave[wv] = __popcll(m);
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wv; ++w) off += s_wave[w];
+        const int n_hit = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (hit) s_idx[off + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (int)(i - base);
+        __syncthreads();
+        for (int h = 0; h < n_hit; ++h) {
+            const float* row = stage_rows + ((base + s_idx[h]) * (int64_t)ns + 4) * K;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (tid + 256 * c < K) acc[c] += row[tid + 256 * c];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (tid + 256 * c < K) g_rel[(int64_t)r * K + tid + 256 * c] += acc[c];
+}
+
 // RotatE: cos / sin of every relation phase, once per step (same cosf / sinf as prep_rel, so the tile pass sees the
 // very values the forward kernel used)
 __global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict__ rel, int64_t n_rels, int k, int K, ModelConst mc,
@@ -329,12 +422,12 @@ __global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict_
 // ---- plan: tile size, bucket capacity and workspace layout (shared by the two entry points) ------------------
 struct TiledPlan {
     int tile_rows, n_tiles, cap, ovf_cap;
+    int ns, sort_cap;   // deterministic mode: 5 staged rows per positive, LDS sort buffer entries (0 otherwise)
     size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, total;
 };
 
 // rows per tile: as many as fit the LDS budget, then shrunk so that the tiles fill whole waves of 256 CUs evenly
-static int pick_tile_rows(int64_t n_rows, int K) {
-    const size_t budget = 150 * 1024;   // accumulators; up to 4 KB of row flags (lazy mode) sit behind them
+static int pick_tile_rows(int64_t n_rows, int K, size_t budget = 150 * 1024) {   // accumulators; up to 4 KB of row flags sit behind them
     int fit = (int)(budget / ((size_t)K * 4));
     if (fit < 1) return 0;
     if (fit > 4096) fit = 4096;
@@ -344,26 +437,37 @@ static int pick_tile_rows(int64_t n_rows, int K) {
     }
 }
 
-static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p) {
+static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p, bool det = false) {
     const int ks = stored_k(m), K = row_floats(m);
     if (ks % 4 != 0 || ks > 2048) return false;   // 16-byte layout; one wave (k <= 512) or one workgroup (k <= 2048) per positive
     if ((ks <= 512 ? (size_t)4 * slot_lds_bytes(eta, 1) + 32 + 16 * (size_t)K : slot_lds_bytes(eta, 4) + 8 + 4 * (size_t)K) > 150 * 1024) return false;
-    p.tile_rows = pick_tile_rows(m->n_ents, K);
-    if (p.tile_rows < 1) return false;
-    p.n_tiles = (int)((m->n_ents + p.tile_rows - 1) / p.tile_rows);
     const int64_t entries = B * (eta + 2);
     if (entries >= (1ll << 31)) return false;
-    {   // bucket capacity: twice the mean + slack (Poisson tail; anything beyond goes to the overflow list)
+    p.ns = det ? 5 : 4;
+    p.sort_cap = 0;
+    // deterministic mode shares the LDS between the accumulators and the sort buffer: shrink the tiles until a bucket
+    // (+ slack for overflow entries) fits the buffer next to them
+    for (size_t budget = det ? 96 * 1024 : 150 * 1024;; budget = budget * 3 / 4) {
+        p.tile_rows = pick_tile_rows(m->n_ents, K, budget);
+        if (p.tile_rows < 1) return false;
+        p.n_tiles = (int)((m->n_ents + p.tile_rows - 1) / p.tile_rows);
+        // bucket capacity: twice the mean + slack (Poisson tail; anything beyond goes to the overflow list)
         const int64_t mean = (entries + p.n_tiles - 1) / p.n_tiles;
         p.cap = (int)(2 * mean + (mean >= 224 ? 256 : 32 + mean));
+        if (!det) break;
+        int sc = 64;
+        while (sc < p.cap + 64) sc <<= 1;
+        const size_t lds = (size_t)p.tile_rows * K * 4 + 4096 + 16 + (size_t)sc * 16;
+        if (lds <= 158 * 1024) { p.sort_cap = sc; break; }
+        if (p.tile_rows == 1) return false;   // one row per tile and its bucket still does not fit: not a shape for this mode
     }
     p.ovf_cap = (int)(entries > 0 ? entries : 1);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
-    p.off_cnt = o; o += up((size_t)(p.n_tiles + 2) * 32 * 4);
+    p.off_cnt = o; o += up((size_t)(p.n_tiles + 3) * 32 * 4);   // bucket fills, overflow count, finished-tiles ticket, det-sort overflow flag
     p.off_lists = o; o += up((size_t)p.n_tiles * p.cap * sizeof(StageEntry));
     p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
-    p.off_rows = o; o += up((size_t)B * 4 * K * 4);
+    p.off_rows = o; o += up((size_t)B * p.ns * K * 4);
     p.off_cs = o; o += up(m->scoring_type == AMDKGE_ROTATE ? (size_t)m->n_rels * K * 4 : 0);
     p.off_touch = o; o += up((size_t)m->n_ents);   // byte per entity row (lazy optimizer + POS_ATOMIC), kept zero between steps
     p.total = o + 256;
@@ -374,7 +478,7 @@ template <int MODEL, int CH, int UNROLL>
 static int launch_tile(const TileArgs& a, size_t shmem, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)tile_backward_kernel<MODEL, CH, UNROLL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        if (hipError_t e = hipFuncSetAttribute((const void*)tile_backward_kernel<MODEL, CH, UNROLL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))   // (the kernel has a few bytes of static LDS)
             return set_error_hip(e, "hipFuncSetAttribute(tile_backward)");
         attr = true;
     }
@@ -412,9 +516,14 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     else if (f.nq <= 256) rc = launch_forward<MODEL, 4, 1>(f, st);
     else rc = launch_forward<MODEL, 4, 2>(f, st);
     if (rc) return rc;
+    if (te.det && f.B > 0) {   // deterministic mode: relation-row gradient from the staged fifth rows, in batch order
+        hipLaunchKernelGGL(rel_backward_det_kernel, dim3((unsigned)te.n_rels), dim3(256), 0, st, f.triples, f.B, f.stage_rows, f.ns, f.K, f.g_rel);
+        if ((rc = check_launch("rel_backward_det"))) return rc;
+    }
     // T: entity tiles (the owner applies the optimizer)
     te.gw = f.nq <= 128 ? 1 : (f.nq <= 256 ? 4 : 8);
-    const size_t shmem_t = (size_t)te.tile_rows * te.K * 4 + (te.lazy ? (((size_t)te.tile_rows * te.gw + 15) & ~(size_t)15) : 0);
+    const size_t shmem_t = (size_t)te.tile_rows * te.K * 4 + ((te.lazy || te.det) ? (((size_t)te.tile_rows * te.gw + 15) & ~(size_t)15) : 0) +
+                           (te.det ? (size_t)te.sort_cap * 16 : 0);
     // entries in flight per wave: bounded by the 128 VGPRs a 1024-thread workgroup leaves per lane (RotatE holds three
     // complex operand rows per entry)
     constexpr int U1 = TRILINEAR ? 8 : (MODEL == AMDKGE_ROTATE ? 2 : 4);
@@ -429,9 +538,11 @@ using namespace kge;
 
 extern "C" int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta) {
     if (validate_model(m) != AMDKGE_OK || B < 0 || B >= (1ll << 30) || eta < 1) return -1;
-    TiledPlan p;
+    TiledPlan p, pd;
     if (!make_plan(m, B, eta, p)) return 0;   // 0 = shape not supported by the owner-computes path
-    return (int64_t)p.total;
+    // one buffer serves both modes: the deterministic plan (five staged rows, smaller tiles) is the larger one where it exists
+    const size_t det_total = make_plan(m, B, eta, pd, true) ? pd.total : 0;
+    return (int64_t)(p.total > det_total ? p.total : det_total);
 }
 
 extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, const amdkge_opt* opt,
@@ -450,8 +561,10 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     if (!d_ent || !d_rel || !d_grad_rel || !d_loss_sum || !d_work) return set_error(AMDKGE_EINVAL, "train_step_tiled: NULL pointer");
     if (!d_grad_ent && (!apply_update || (flags & AMDKGE_TILED_POS_ATOMIC))) return set_error(AMDKGE_EINVAL, "train_step_tiled: d_grad_ent is required unless the step updates in place with staged positives");
     if (B < 0 || B >= (1ll << 30) || eta < 1) return set_error(AMDKGE_EINVAL, "train_step_tiled: B must be in [0, 2^30) and eta >= 1");
+    const bool det = (flags & AMDKGE_TILED_DETERMINISTIC) != 0;
+    if (det && (flags & AMDKGE_TILED_POS_ATOMIC)) return set_error(AMDKGE_EINVAL, "train_step_tiled: DETERMINISTIC excludes POS_ATOMIC (atomics add in arrival order)");
     TiledPlan p;
-    if (!make_plan(m, B, eta, p))
+    if (!make_plan(m, B, eta, p, det))
         return set_error(AMDKGE_EUNSUPPORTED, "train_step_tiled: shape not supported (stored half width not a multiple of 4 -- set k_pad = amdkge_padded_k(k) --, > 2048, or eta too large); use amdkge_train_fwdbwd + amdkge_opt_step");
     if (apply_update) {
         if (opt_nslots(opt->kind) >= 1 && !d_ent_slot0) return set_error(AMDKGE_EINVAL, "train_step_tiled: optimizer slot 0 is NULL");
@@ -481,7 +594,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     f.sc = SampleCfg{sample_base, (uint32_t)sample_range, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step,
                      (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
     f.mc = model_const(m); f.loss = *loss;
-    f.touched = touched;
+    f.touched = touched; f.ns = p.ns; f.det = det ? 1 : 0;
     f.stage_rows = stage_rows; f.st_lists = lists; f.st_ovf = ovf; f.st_counters = counters;
     f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap;
 #ifdef KGE_ABLATE
@@ -490,7 +603,8 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
 
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
-    te.rel_cs = rel_cs; te.lazy = lazy ? 1 : 0; te.touched = touched;
+    te.rel_cs = rel_cs; te.lazy = lazy ? 1 : 0; te.touched = touched; te.ns = p.ns; te.det = det ? 1 : 0; te.sort_cap = p.sort_cap;
+    te.n_rels = m->n_rels;
     te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = ks; te.K = K; te.k_live = m->k; te.nq = ks / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;
@@ -530,4 +644,19 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     ro.reg_lambda = rel_reg_lambda;
     ro.row_floats = K;
     return amdkge_opt_step(&ro, d_rel, d_grad_rel, d_rel_slot0, d_rel_slot1, (int64_t)m->n_rels * K, d_reg_loss, stream);
+}
+
+extern "C" int amdkge_train_tiled_status(const amdkge_model* m, int64_t B, int32_t eta, int32_t flags, void* d_work, int32_t* status, void* stream) {
+    if (int rc = validate_model(m)) return rc;
+    if (!d_work || !status) return set_error(AMDKGE_EINVAL, "train_tiled_status: NULL pointer");
+    *status = 0;
+    TiledPlan p;
+    if (!make_plan(m, B, eta, p, (flags & AMDKGE_TILED_DETERMINISTIC) != 0)) return set_error(AMDKGE_EUNSUPPORTED, "train_tiled_status: shape not supported");
+    char* w = (char*)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    int* flag = (int*)(w + p.off_cnt) + (size_t)(p.n_tiles + 2) * 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipError_t e = hipMemcpyAsync(status, flag, sizeof(int), hipMemcpyDeviceToHost, st)) return set_error_hip(e, "hipMemcpyAsync(status)");
+    if (hipError_t e = hipStreamSynchronize(st)) return set_error_hip(e, "hipStreamSynchronize");
+    if (*status) { if (hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st)) return set_error_hip(e, "hipMemsetAsync(status)"); }
+    return AMDKGE_OK;
 }

@@ -158,12 +158,18 @@ class KgeEngine:
 
     def train_step_tiled(self, triples, eta, loss, opt_desc, seed, step, reg_e=0.0, reg_r=0.0, sample_base=0,
                          sample_range=None, row_offset=0, b_global=0, neg_override=None, pos_scores=None,
-                         neg_scores=None, grad_only=False, pos_atomic=False):
+                         neg_scores=None, grad_only=False, pos_atomic=False, deterministic=False):
         """Owner-computes step (kge_train_tiled.hip).  grad_only=False: the COMPLETE step -- entity table
         from the LDS tiles, relation table by the fused sweep; g_ent / g_rel (zero on entry) are left zero.
         grad_only=True (data-parallel): g_ent / g_rel (zero on entry) receive the gradients; nothing is updated.
-        pos_atomic: skewed graphs, see AMDKGE_TILED_POS_ATOMIC in include/amdkge.h."""
+        pos_atomic: skewed graphs, see AMDKGE_TILED_POS_ATOMIC in include/amdkge.h; deterministic: AMDKGE_TILED_DETERMINISTIC
+        (bitwise reproducible tables: sorted tile accumulation, staged relation gradient; excludes pos_atomic)."""
         B = int(triples.shape[0])
+        flags = (1 if pos_atomic else 0) | (2 if deterministic else 0)
+        if getattr(self, "_twork_flags", flags) & 2 != flags & 2:
+            self._twork = None   # the two modes lay out the bookkeeping differently: a workspace serves one of them
+        self._twork_flags = flags
+        self._last_tiled = (B, int(eta), flags)
         need = int(self.lib.amdkge_train_tiled_workspace_bytes(C.byref(self.model), B, int(eta)))
         if need <= 0:
             raise ValueError("shape not supported by the owner-computes path")
@@ -181,12 +187,21 @@ class KgeEngine:
                 C.byref(self.model), C.byref(loss), C.byref(opt_desc), _ptr(self.ent), _ptr(self.rel), _ptr(s0), _ptr(s1),
                 _ptr(r0), _ptr(r1), float(reg_r), _ptr(triples), B, int(eta), int(sample_base), int(sample_range),
                 int(seed), int(step), int(row_offset), int(b_global), _ptr(neg_override),
-                _ptr(self.g_ent), _ptr(self.g_rel), 0 if grad_only else 1, 1 if pos_atomic else 0,
+                _ptr(self.g_ent), _ptr(self.g_rel), 0 if grad_only else 1, flags,
                 C.c_void_p(self.loss_acc.data_ptr()), C.c_void_p(self.loss_acc.data_ptr() + 8),
                 _ptr(pos_scores), _ptr(neg_scores), _ptr(self._twork), _stream()))
         except Exception:
             self._twork = None   # bookkeeping may be dirty after a failed launch: start from a fresh zeroed buffer
             raise
+
+    def tiled_status(self):
+        """!= 0 if a DETERMINISTIC step fell back to unsorted accumulation in some tile since the last query (synchronises)."""
+        if self._twork is None or not hasattr(self, "_last_tiled") or not (self._last_tiled[2] & 2):
+            return 0
+        st = C.c_int32(0)
+        B, eta, flags = self._last_tiled
+        check(self.lib.amdkge_train_tiled_status(C.byref(self.model), B, eta, flags, _ptr(self._twork), C.byref(st), _stream()))
+        return int(st.value)
 
     def opt_step(self, opt_desc, reg_e=0.0, reg_r=0.0, rows_e=None, reg_slots=(1, 1)):
         """Dense sweep over both tables (optimizer + regulariser + gradient reset).  rows_e limits the entity

@@ -93,12 +93,13 @@ class ScoringBasedEmbeddingModel:
         [entity_init, relation_init]; regularizer: None | 'LP'/'l1'/'l2'/'l3' | LPRegularizer | pair.
 
         Extra keywords of this engine: optimizer_mode="dense" (default, the reference's semantics) | "lazy" (touched rows
-        only; see amdkge_opt.lazy).  Multi-GPU, one process per GPU under torch.distributed:
+        only; see amdkge_opt.lazy); deterministic=True: bitwise reproducible training (AMDKGE_TILED_DETERMINISTIC).  Multi-GPU, one process per GPU under torch.distributed:
         entity_sharding="replicated" (default: tables replicated, gradient all-reduce) | "rows" (entity table
         row-sharded over the ranks, ampligraph_amd/sharded.py); sharded_negatives="local" | "global"."""
         optimizer_mode = kwargs.pop("optimizer_mode", "dense")
         if optimizer_mode not in ("dense", "lazy"):
             raise ValueError("optimizer_mode must be 'dense' (the reference's behaviour) or 'lazy' (touched rows only)")
+        self._deterministic = bool(kwargs.pop("deterministic", False))
         self._sharding = kwargs.pop("entity_sharding", "replicated")
         self._sharded_negatives = kwargs.pop("sharded_negatives", "local")
         if self._sharding not in ("replicated", "rows"):
@@ -235,6 +236,8 @@ class ScoringBasedEmbeddingModel:
             loop = StepLoop(self._engine, self.eta, self.loss, self.optimizer, reg, self.seed, self._dist())
         if reg is not None and self._regularizers[1].lam != reg.lam:
             loop.lam_rel = self._regularizers[1].lam   # [entity_reg, relation_reg] pair with different lambdas
+        if getattr(self, "_deterministic", False):
+            loop.deterministic = True   # AMDKGE_TILED_DETERMINISTIC: bitwise reproducible tables (include/amdkge.h)
         return loop
 
     def _entity_table(self):

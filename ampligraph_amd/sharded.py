@@ -137,6 +137,9 @@ class ShardedStepLoop:
         self.use_tiled = prefer_tiled(engine)
         self.kernel_hook = None   # bench.py: callable(i) recording HIP events at the phase boundaries (PHASES)
         self._route_counts = None
+        import os
+
+        self.deterministic = os.environ.get("AMDKGE_DETERMINISTIC", "0") == "1"   # see trainer.StepLoop
         engine.prepare_training(optimizer.name)
 
     @staticmethod
@@ -203,7 +206,9 @@ class ShardedStepLoop:
             kw = dict(row_offset=lo, b_global=bg, neg_override=nl)
             if nl is None:   # shard-local negatives: replacement rows are local rows [0, n_local)
                 kw.update(sample_base=0, sample_range=sp.n_local)
-            if self.use_tiled and eng.tiled_supported(b, self.eta):
+            if (self.use_tiled or self.deterministic) and eng.tiled_supported(b, self.eta):
+                if self.deterministic:
+                    kw["deterministic"] = True
                 eng.train_step_tiled(xl, self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step, grad_only=True, **kw)
             else:
                 eng.train_fwdbwd(xl, self.eta, self.loss_ffi, self.seed, rng_step, **kw)
@@ -212,7 +217,11 @@ class ShardedStepLoop:
         # ---- 3. gradients of fetched copies go home; relation gradient is summed over ranks ----------------
         back = eng._buf("grads_back", tuple(g_scratch.shape), g_scratch.dtype)
         self.dist.all_to_all_single(back.reshape(-1), g_scratch.reshape(-1))
-        eng.scatter_add_rows(eng.g_ent, recv_ids, back)
+        if self.deterministic:   # one peer's list holds distinct rows: peer after peer, every row's additions in rank order
+            for q in range(W):
+                eng.scatter_add_rows(eng.g_ent, recv_ids[q * cap:(q + 1) * cap], back[q * cap:(q + 1) * cap])
+        else:
+            eng.scatter_add_rows(eng.g_ent, recv_ids, back)
         eng.zero_(g_scratch)   # (the atomic-scatter train path accumulates into these rows)
         self.dist.all_reduce(eng.g_rel)
         if hook is not None:

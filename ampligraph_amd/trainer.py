@@ -97,6 +97,9 @@ class StepLoop:
         self.n_steps = 0
         self.use_tiled = prefer_tiled(engine)
         self.pos_atomic = False   # see configure_for_data
+        # bitwise reproducible tables (AMDKGE_TILED_DETERMINISTIC): compile(deterministic=True) or AMDKGE_DETERMINISTIC=1,
+        # read once here.  Needs the owner-computes path (any k <= 2048); the merged DP sweep already sums in rank order.
+        self.deterministic = os.environ.get("AMDKGE_DETERMINISTIC", "0") == "1"
         self.kernel_hook = None   # bench.py: callable(i) recording HIP events at the phase boundaries (PHASES)
         engine.prepare_training(optimizer.name)
         if self.merge == "sharded" and self.world > 1 and int(engine.g_flat.numel()) % self.world != 0:
@@ -105,7 +108,7 @@ class StepLoop:
     def configure_for_data(self, triples, batch_size):
         """Pick the owner-computes variant for this training set (host-side, once per fit): skewed graphs route the
         positives' own s / o gradient rows through atomics (AMDKGE_TILED_POS_ATOMIC)."""
-        self.pos_atomic = hot_row_entries(triples, -(-int(batch_size) // self.world)) > HOT_ROW_THRESHOLD
+        self.pos_atomic = (not self.deterministic) and hot_row_entries(triples, -(-int(batch_size) // self.world)) > HOT_ROW_THRESHOLD
         return self.pos_atomic
 
     def step(self, global_batch, rng_step, focus=None):
@@ -131,13 +134,15 @@ class StepLoop:
         opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2)
         # owner-computes path (kge_train_tiled.hip) whenever the shape allows it: no global atomics, no dense
         # entity gradient; data-parallel runs take its gradient-only form and keep the dense sweep
-        tiled = self.use_tiled and hi > lo and eng.tiled_supported(hi - lo, self.eta)
+        tiled = (self.use_tiled or self.deterministic) and hi > lo and eng.tiled_supported(hi - lo, self.eta)
+        if self.deterministic and hi > lo and not tiled:
+            raise ValueError("deterministic mode needs the owner-computes train path (k <= 2048)")
         if self.kernel_hook is not None:
             self.kernel_hook(0)
         if tiled:
             eng.train_step_tiled(global_batch[lo:hi], self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step,
                                  reg_e=lam, reg_r=lam_r, row_offset=lo, b_global=bg, grad_only=self.world > 1,
-                                 pos_atomic=self.pos_atomic)
+                                 pos_atomic=self.pos_atomic, **({"deterministic": True} if self.deterministic else {}))
         elif hi > lo:
             eng.train_fwdbwd(global_batch[lo:hi], self.eta, self.loss_ffi, self.seed, rng_step,
                              row_offset=lo, b_global=bg)
@@ -290,6 +295,9 @@ class StepLoop:
         data loss + regulariser loss) / #batches.  The data loss is summed over ranks; the regulariser
         term is identical on every rank (replicated tables, all-reduce merge: counted once) or split over the
         ranks' slices (sharded merge: summed)."""
+        if self.deterministic and hasattr(self.engine, "tiled_status") and self.engine.tiled_status():
+            raise RuntimeError("deterministic mode: a tile received more entries than its sort buffer holds (very hot rows); "
+                               "this epoch's sums were not all added in canonical order")
         acc = self.engine.loss_acc.clone()
         if self.world > 1 and self.merge == "sharded":
             both = acc[0:2].clone()

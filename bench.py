@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--optimizer-mode", default=None, choices=["dense", "lazy"],
                     help="dense = the reference's Keras-legacy behaviour (every row every step); lazy = touched rows only "
                          "(amdkge_opt.lazy, a documented deviation)")
+    ap.add_argument("--deterministic", action="store_true", help="AMDKGE_TILED_DETERMINISTIC: bitwise reproducible tables (sorted tile "
+                    "accumulation, staged relation gradient); reports its cost")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -228,6 +230,7 @@ def main():
 
     B = args.batch
     Bg = B * world
+    loop.deterministic = bool(args.deterministic) or loop.deterministic
     if hasattr(loop, "configure_for_data") and data["train"] is not None:
         loop.configure_for_data(data["train"], Bg)
     # the training set lives in HBM; a global batch is a contiguous slice (reference order: sequential,
@@ -322,7 +325,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.dataset} ({args.popularity}, seed 0) {args.model} k={args.k} eta={args.eta} "
                                    f"{args.loss} adam lr=1e-3, {B} positives/GPU/step, tables resident in HBM, {opt_txt}",
-                       "preset": args.preset, "optimizer_mode": args.optimizer_mode,
+                       "preset": args.preset, "optimizer_mode": args.optimizer_mode, "deterministic": bool(loop.deterministic),
                        "global_batch": Bg, "n_ents": N, "n_rels": R, "row_floats": eng.K, "stored_row_floats": eng.Ks,
                        "parallelism": par, "merge_ms_per_step_measured": getattr(loop, "merge_report", None)},
             "mean_batch_loss": loss_mean,

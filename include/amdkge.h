@@ -199,7 +199,19 @@ int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_s
  *                its FIRST use; the library leaves its bookkeeping region zeroed after every successful call, so
  *                one buffer (sized for the largest B) serves every later step of the same model. */
 #define AMDKGE_TILED_POS_ATOMIC 1
+/* AMDKGE_TILED_DETERMINISTIC: bitwise reproducible tables and optimizer state from run to run.  Without it the order of the
+ * fp32 additions into a gradient row is the arrival order of its contributions (bucket slots are handed out by a returning
+ * atomic, the relation-row gradient uses fp32 atomics), as in the reference's GPU kernels.  With it every tile sorts its entries
+ * into a canonical order (their full 128-bit content) in LDS before adding them, and the relation-row gradient is staged per
+ * positive and added per relation in batch order by a second kernel: no atomics touch a gradient.  Costs a smaller tile (the LDS
+ * is shared with the sort buffer), the sort, and a fifth staged row per positive.  Excludes POS_ATOMIC.  A tile whose entries
+ * exceed the sort buffer (an extremely hot tile) is processed unsorted and reported by amdkge_train_tiled_status.
+ * (The fp64 loss accumulators still use atomics: they agree to ~1e-15 relative and feed nothing back into the tables.) */
+#define AMDKGE_TILED_DETERMINISTIC 2
 int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta);
+/* status != 0 after a DETERMINISTIC step: some tile fell back to unsorted accumulation since the last query (flag is cleared).
+ * Synchronises the stream. */
+int amdkge_train_tiled_status(const amdkge_model* m, int64_t B, int32_t eta, int32_t flags, void* d_work, int32_t* status, void* stream);
 int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, const amdkge_opt* opt,
                             float* d_ent, float* d_rel, float* d_ent_slot0, float* d_ent_slot1,
                             float* d_rel_slot0, float* d_rel_slot1, float rel_reg_lambda,

@@ -202,6 +202,7 @@ class OracleEngine:
         """amdkge_train_step_tiled: grad_only stores the entity gradient (overwrite) and adds the relation
         gradient; otherwise it is the complete step (both tables updated, gradients left zero)."""
         kw.pop("pos_atomic", None)
+        kw.pop("deterministic", None)
         if grad_only:
             self.g_ent.zero_()   # staged positives: the entity gradient is stored, not added
         self.train_fwdbwd(triples, eta, loss, seed, step, row_offset=row_offset, b_global=b_global, **kw)
