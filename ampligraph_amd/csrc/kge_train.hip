@@ -40,6 +40,22 @@ __global__ void sample_kernel(const int32_t* triples, int64_t B, int eta, Sample
     out[3 * r + 2] = keep ? repl : o;
 }
 
+__global__ void loss_fold_kernel(double* parts, double* loss_sum) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) fold_loss_parts(parts, loss_sum);
+}
+
+// per-device scratch of the atomic path (it has no workspace argument): LOSS_PARTS partial sums, zero between calls
+static double* loss_parts_of_current_device() {
+    static double* parts[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!parts[dev]) {
+        if (hipMalloc((void**)&parts[dev], (size_t)LOSS_PARTS * LOSS_PART_STRIDE * sizeof(double)) != hipSuccess) { parts[dev] = nullptr; return nullptr; }
+        if (hipMemset(parts[dev], 0, (size_t)LOSS_PARTS * LOSS_PART_STRIDE * sizeof(double)) != hipSuccess) return nullptr;
+    }
+    return parts[dev];
+}
+
 template <int MODEL, int VEC, int W>
 static int launch_train_w(const TrainArgs& a, int CH, hipStream_t st) {
     const int slots = 4 / W;
@@ -131,11 +147,17 @@ extern "C" int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* los
     { const char* e = getenv("AMDKGE_DEBUG"); a.dbg = e ? atoi(e) : 0; }
 #endif
     hipStream_t st = (hipStream_t)stream;
+    a.loss_parts = loss_parts_of_current_device();
+    if (!a.loss_parts) return set_error(AMDKGE_ENOMEM, "train: cannot allocate the loss scratch");
+    int rc;
     switch (m->scoring_type) {
-        case AMDKGE_TRANSE: return launch_train_m<AMDKGE_TRANSE>(a, st);
-        case AMDKGE_DISTMULT: return launch_train_m<AMDKGE_DISTMULT>(a, st);
-        case AMDKGE_COMPLEX: return launch_train_m<AMDKGE_COMPLEX>(a, st);
-        case AMDKGE_HOLE: return launch_train_m<AMDKGE_COMPLEX>(a, st);  // HolE = ComplEx * fp32(2/k), via ModelConst
-        default: return launch_train_m<AMDKGE_ROTATE>(a, st);
+        case AMDKGE_TRANSE: rc = launch_train_m<AMDKGE_TRANSE>(a, st); break;
+        case AMDKGE_DISTMULT: rc = launch_train_m<AMDKGE_DISTMULT>(a, st); break;
+        case AMDKGE_COMPLEX: rc = launch_train_m<AMDKGE_COMPLEX>(a, st); break;
+        case AMDKGE_HOLE: rc = launch_train_m<AMDKGE_COMPLEX>(a, st); break;  // HolE = ComplEx * fp32(2/k), via ModelConst
+        default: rc = launch_train_m<AMDKGE_ROTATE>(a, st); break;
     }
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(64), 0, st, a.loss_parts, d_loss_sum);
+    return check_launch("loss_fold");
 }

@@ -15,6 +15,12 @@ struct __attribute__((aligned(16))) StageEntry {
     uint32_t dest;   // global row id
 };
 
+// Per-block loss partials.  Thousands of blocks adding an fp64 atomic to ONE address serialise at the L2 (measured: 19 of the
+// 46 us of a C1 forward kernel, 5 us at C2); spread over LOSS_PARTS cache lines they do not, and a single thread folds the
+// partials into the caller's accumulator afterwards (the tile kernel's last workgroup, or loss_fold_kernel on the atomic path).
+constexpr int LOSS_PARTS = 64;
+constexpr int LOSS_PART_STRIDE = 16;   // doubles
+
 struct TrainArgs {
     const float* ent;
     const float* rel;
@@ -23,6 +29,7 @@ struct TrainArgs {
     float* g_ent;
     float* g_rel;
     double* loss_sum;
+    double* loss_parts;      // [LOSS_PARTS] partial sums, 128-byte stride: blocks add here, one thread folds them into loss_sum
     float* pos_scores;
     float* neg_scores;
     int64_t B;
@@ -55,6 +62,18 @@ struct TrainArgs {
 #else
 #define KGE_DBG(a, bit) false
 #endif
+
+// fold the per-block partials into the caller's accumulator and leave them zero (one thread, fixed order)
+// (atomic exchanges: the partials may have been written by other CUs of the SAME launch -- the tile kernel's regulariser
+// terms -- and must be read from the L2, not from this CU's L1)
+__device__ __forceinline__ void fold_loss_parts(double* parts, double* loss_sum, int lane_in_slot = 0) {
+    double t = 0.0;
+    for (int i = 0; i < LOSS_PARTS; ++i) {
+        const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(parts + (size_t)i * LOSS_PART_STRIDE + lane_in_slot), 0ull);
+        t += __longlong_as_double((long long)old);
+    }
+    if (loss_sum && t != 0.0) atomicAdd(loss_sum, t);
+}
 
 __device__ __forceinline__ float log_sigmoid(float x) {
     // -softplus(-x), stable on both tails
@@ -829,11 +848,11 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 
     // ---- per-block loss: one fp64 atomic -------------------------------------------------------
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && !KGE_DBG(a, 128)) {
         double t = 0.0;
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) t += sh_loss[q];
-        atomicAdd(a.loss_sum, t);
+        atomicAdd(a.loss_parts + (size_t)(blockIdx.x & (LOSS_PARTS - 1)) * LOSS_PART_STRIDE, t);
     }
 
     // ---- resident rows: one atomic row-add each, or (STAGE) plain 16-byte stores for the owner kernel ----

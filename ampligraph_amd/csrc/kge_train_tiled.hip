@@ -62,7 +62,9 @@ struct TileArgs {
     const float* stage_rows;  // [B][4][K]
     const StageEntry* lists;  // [n_tiles][cap]
     const StageEntry* ovf;    // overflow entries
-    int* counters;            // [(n_tiles + 2) * 32]: bucket fills, overflow count, finished-tiles ticket
+    int* counters;            // [(n_tiles + 3) * 32]: bucket fills, overflow count, finished-tiles ticket, det-sort overflow flag
+    double* loss_parts;       // the forward kernel's per-block loss partials, folded into loss_sum by the last tile
+    double* loss_sum;
     double* reg_loss;
     OptArgs rel_opt;          // fused relation-table sweep (rel_blocks > 0): blocks [n_tiles, n_tiles + rel_blocks)
     int rel_blocks;
@@ -353,8 +355,9 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     KGE_OPT_DISPATCH(a.opt.kind, KGE_FLUSH)
 #undef KGE_FLUSH
     if (a.apply_update && a.reg_loss && a.opt.lam != 0.f) {
+        // per-wave regulariser terms go to the partial slots as well (second double of a slot), folded by the last tile
         const float w = wave_sum(reg_acc);
-        if (lane == 0) atomicAdd(a.reg_loss, (double)a.opt.lam * (double)w);
+        if (lane == 0) atomicAdd(a.loss_parts + (size_t)((tile * TILE_WAVES + wv) & (LOSS_PARTS - 1)) * LOSS_PART_STRIDE + 1, (double)a.opt.lam * (double)w);
     }
     // ---- leave the bookkeeping zeroed for the next step: own bucket now, overflow count by the last tile ----
     __syncthreads();
@@ -366,6 +369,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         if (atomicAdd(a.counters + (size_t)(a.n_tiles + 1) * 32, 1) == a.n_tiles - 1) {
             a.counters[a.n_tiles * 32] = 0;
             a.counters[(a.n_tiles + 1) * 32] = 0;
+            fold_loss_parts(a.loss_parts, a.loss_sum);   // (the forward kernel finished before this launch started)
+            fold_loss_parts(a.loss_parts, a.reg_loss, 1);   // every tile's waves added theirs before taking the ticket
         }
     }
 }
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict_
 struct TiledPlan {
     int tile_rows, n_tiles, cap, ovf_cap;
     int ns, sort_cap;   // deterministic mode: 5 staged rows per positive, LDS sort buffer entries (0 otherwise)
-    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, total;
+    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, total;
 };
 
 // rows per tile: as many as fit the LDS budget, then shrunk so that the tiles fill whole waves of 256 CUs evenly
@@ -464,6 +469,7 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     p.ovf_cap = (int)(entries > 0 ? entries : 1);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
+    p.off_loss = o; o += up((size_t)LOSS_PARTS * LOSS_PART_STRIDE * 8);   // first: the same place in every plan (kept zero between steps)
     p.off_cnt = o; o += up((size_t)(p.n_tiles + 3) * 32 * 4);   // bucket fills, overflow count, finished-tiles ticket, det-sort overflow flag
     p.off_lists = o; o += up((size_t)p.n_tiles * p.cap * sizeof(StageEntry));
     p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
@@ -595,6 +601,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
                      (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
     f.mc = model_const(m); f.loss = *loss;
     f.touched = touched; f.ns = p.ns; f.det = det ? 1 : 0;
+    f.loss_parts = (double*)(w + p.off_loss);
     f.stage_rows = stage_rows; f.st_lists = lists; f.st_ovf = ovf; f.st_counters = counters;
     f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap;
 #ifdef KGE_ABLATE
@@ -604,7 +611,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
     te.rel_cs = rel_cs; te.lazy = lazy ? 1 : 0; te.touched = touched; te.ns = p.ns; te.det = det ? 1 : 0; te.sort_cap = p.sort_cap;
-    te.n_rels = m->n_rels;
+    te.n_rels = m->n_rels; te.loss_parts = f.loss_parts; te.loss_sum = d_loss_sum;
     te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = ks; te.K = K; te.k_live = m->k; te.nq = ks / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;
