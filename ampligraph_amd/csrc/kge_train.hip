@@ -41,7 +41,7 @@ __global__ void sample_kernel(const int32_t* triples, int64_t B, int eta, Sample
 }
 
 __global__ void loss_fold_kernel(double* parts, double* loss_sum) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) fold_loss_parts(parts, loss_sum);
+    fold_loss_parts(parts, loss_sum, threadIdx.x);   // one wave
 }
 
 // per-device scratch of the atomic path (it has no workspace argument): LOSS_PARTS partial sums, zero between calls
@@ -57,12 +57,19 @@ static double* loss_parts_of_current_device() {
 }
 
 template <int MODEL, int VEC, int W>
-static int launch_train_w(const TrainArgs& a, int CH, hipStream_t st) {
+static int launch_train_w(TrainArgs& a, int CH, hipStream_t st) {
     const int slots = 4 / W;
-    const size_t shmem = (size_t)slots * slot_lds_bytes(a.eta, W) + slots * sizeof(double) + (VEC == 4 ? 4 * (size_t)a.K * 4 : 0);
-    if (shmem > 64 * 1024) return set_error(AMDKGE_EUNSUPPORTED, "train: eta too large for the LDS score buffer");
+    size_t shmem = (size_t)slots * slot_lds_bytes(a.eta, W) + slots * sizeof(double) + (VEC == 4 ? 4 * (size_t)a.K * 4 : 0);
+    a.sign_off = (int)shmem;
+    if (VEC == 4) shmem += sign_stash_bytes(MODEL, a.eta, CH);
+    if (shmem > 150 * 1024) return set_error(AMDKGE_EUNSUPPORTED, "train: eta too large for the LDS score buffer");
     const unsigned grid = (unsigned)((a.B + slots - 1) / slots);
-#define KGE_LAUNCH(CC) hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, VEC, W, CC>), dim3(grid), dim3(256), shmem, st, a)
+#define KGE_LAUNCH(CC) do { \
+        if (shmem > 64 * 1024) { \
+            if (hipError_t e = hipFuncSetAttribute((const void*)train_fwdbwd_kernel<MODEL, VEC, W, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) \
+                return set_error_hip(e, "hipFuncSetAttribute(train_fwdbwd)"); \
+        } \
+        hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, VEC, W, CC>), dim3(grid), dim3(256), shmem, st, a); } while (0)
     switch (CH) {
         case 1: KGE_LAUNCH(1); break;
         case 2: KGE_LAUNCH(2); break;
@@ -79,7 +86,7 @@ static int launch_train_w(const TrainArgs& a, int CH, hipStream_t st) {
 // operations/s whatever the number of dwords per line, so the 16-byte-per-lane layout (8 active
 // dwords per line) makes the gradient scatter 4.4x slower than the lane-contiguous one.
 template <int MODEL, int VEC>
-static int launch_train_mv(const TrainArgs& a, hipStream_t st) {
+static int launch_train_mv(TrainArgs& a, hipStream_t st) {
     int W = 1;
     while (W < 4 && (a.nq + 64 * W - 1) / (64 * W) > 8) W *= 2;
     int ch = (a.nq + 64 * W - 1) / (64 * W);

@@ -44,6 +44,7 @@ struct TrainArgs {
     // owner-computes (STAGE) outputs: see kge_train_tiled.hip
     float* stage_rows;       // [B][4][K]: gradient rows of the positive's s and o (unless pos_atomic), then the side rows A, B
     int pos_atomic;          // the positives' own s / o rows go through atomics into g_ent (skewed graphs)
+    int sign_off;            // TransE: byte offset of the sign stash in dynamic LDS (see SIGNSTASH in the kernel)
     int ns;                  // staged rows per positive: 4, or 5 in deterministic mode (the relation-row gradient is staged too)
     int det;                 // deterministic mode (AMDKGE_TILED_DETERMINISTIC): no atomics on any gradient
     uint8_t* touched;        // pos_atomic + lazy optimizer: byte per entity row, set for rows that received an atomic row-add
@@ -66,13 +67,14 @@ struct TrainArgs {
 // fold the per-block partials into the caller's accumulator and leave them zero (one thread, fixed order)
 // (atomic exchanges: the partials may have been written by other CUs of the SAME launch -- the tile kernel's regulariser
 // terms -- and must be read from the L2, not from this CU's L1)
-__device__ __forceinline__ void fold_loss_parts(double* parts, double* loss_sum, int lane_in_slot = 0) {
-    double t = 0.0;
-    for (int i = 0; i < LOSS_PARTS; ++i) {
-        const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(parts + (size_t)i * LOSS_PART_STRIDE + lane_in_slot), 0ull);
-        t += __longlong_as_double((long long)old);
-    }
-    if (loss_sum && t != 0.0) atomicAdd(loss_sum, t);
+// Called by ONE whole wave: lane i takes partial i (LOSS_PARTS == 64), the wave adds them up in a fixed butterfly order.
+__device__ __forceinline__ void fold_loss_parts(double* parts, double* loss_sum, int lane, int lane_in_slot = 0) {
+    static_assert(LOSS_PARTS == KGE_WAVE, "one partial per lane");
+    const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(parts + (size_t)lane * LOSS_PART_STRIDE + lane_in_slot), 0ull);
+    double t = __longlong_as_double((long long)old);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0 && loss_sum && t != 0.0) atomicAdd(loss_sum, t);
 }
 
 __device__ __forceinline__ float log_sigmoid(float x) {
@@ -321,6 +323,13 @@ __device__ __forceinline__ void onepass_finish(const amdkge_loss& L, float P, fl
     }
 }
 
+// TransE keeps, per corruption and unit, only sign(s + p - o) for its backward pass (the gradient of |x|): 2 bits per unit,
+// one byte per lane and quad, stashed in LDS by the scoring pass so that the replacement rows are read from memory ONCE
+// (measured at the C2 shape, k = 200: forward kernel 66.7 -> 54 us).
+__host__ __device__ inline size_t sign_stash_bytes(int model, int eta, int CH) {
+    return model == AMDKGE_TRANSE ? (size_t)256 * eta * CH : 0;
+}
+
 __host__ __device__ inline size_t slot_lds_bytes(int eta, int W) {
     // neg[eta+1], repl[eta+1], keep[eta+1], then part[W][eta+1] (W>1) or perm[eta+1] (W==1), dfac[eta+1] (FocusE),
     // rounded to 8 bytes
@@ -485,6 +494,10 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 
     // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
     constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
+    // (folding TransE into the single-pass framework -- accumulate c_j sign(d_j) while the rows stream by -- was built and
+    // measured: no faster at k = 200, slower at k = 350 (register pressure); the sign stash below is what stayed)
+    constexpr bool SIGNSTASH = (MODEL == AMDKGE_TRANSE) && (STAGE || VEC == 4);   // (the scalar-load geometries keep the two-pass form)
+    unsigned char* sh_sign = reinterpret_cast<unsigned char*>(smem) + a.sign_off;
     float av1[2][CH][VEC][NC], av2[2][CH][VEC][NC];   // [0]: sum c_j e_j over object-replaced rows, [1]: subject-replaced
     OnePassState ops{-INFINITY, 0.f, 0.f, 0.f};
     if constexpr (ONEPASS) {
@@ -641,9 +654,21 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 float acc = 0.f;
+                if constexpr (SIGNSTASH) {
+                    // TransE.py:51-53 with the signs of s + p - o kept for the backward pass (same operations as score_unit)
+                    unsigned code = 0;
 #pragma unroll
-                for (int u = 0; u < VEC; ++u)
-                    acc += keepv[f] ? score_unit<MODEL>(s[c][u], p[c][u], e[f][c][u]) : score_unit<MODEL>(e[f][c][u], p[c][u], o[c][u]);
+                    for (int u = 0; u < VEC; ++u) {
+                        const float d = keepv[f] ? (s[c][u][0] + p[c][u][0] - e[f][c][u][0]) : (e[f][c][u][0] + p[c][u][0] - o[c][u][0]);
+                        acc += fabsf(d);
+                        code |= ((d > 0.f) ? 1u : ((d < 0.f) ? 2u : 0u)) << (2 * u);
+                    }
+                    if (j >= 0) sh_sign[((size_t)j * CH + c) * 256 + tid] = (unsigned char)code;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < VEC; ++u)
+                        acc += keepv[f] ? score_unit<MODEL>(s[c][u], p[c][u], e[f][c][u]) : score_unit<MODEL>(e[f][c][u], p[c][u], o[c][u]);
+                }
                 part += qok[c] ? acc : 0.f;
             }
             const float tot = wave_sum(part);
@@ -808,7 +833,30 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
             }
     }
     const bool do_neg_atomics = active && !KGE_DBG(a, 1);
-    for (int j0 = 0; j0 < ((ONEPASS || KGE_DBG(a, 4)) ? 0 : eta); j0 += PF) {
+    if constexpr (SIGNSTASH) {
+        // TransE backward from the stashed signs: no second read of the replacement rows.  Same additions, in the same
+        // order (j ascending), as the generic loop below performs through grad_unit.
+        for (int j = 0; j < eta; ++j) {
+            const int keep = __builtin_amdgcn_readfirstlane(sh_keep[j]);
+            const float g = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh_neg[j]))) * sgn_scale;
+            float gr[CH][VEC][NC];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const unsigned code = sh_sign[((size_t)j * CH + c) * 256 + tid];
+#pragma unroll
+                for (int u = 0; u < VEC; ++u) {
+                    const unsigned b = (code >> (2 * u)) & 3u;
+                    const float sg = (b == 1u) ? g : ((b == 2u) ? -g : 0.f);   // g * sign(d)
+                    if (keep) { gs[c][u][0] += sg; gp[c][u][0] += sg; gr[c][u][0] = -sg; }
+                    else { go[c][u][0] += -sg; gp[c][u][0] += sg; gr[c][u][0] = sg; }
+                }
+            }
+            if constexpr (!STAGE) {
+                if (do_neg_atomics) emit_row(a.g_ent + (int64_t)__builtin_amdgcn_readfirstlane(sh_repl[j]) * a.K, gr, a.K, 1.f);
+            }
+        }
+    }
+    for (int j0 = 0; j0 < ((ONEPASS || SIGNSTASH || KGE_DBG(a, 4)) ? 0 : eta); j0 += PF) {
         float e[PF][CH][VEC][NC];
         int keepv[PF];
         int64_t erv[PF];

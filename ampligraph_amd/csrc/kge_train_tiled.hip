@@ -43,6 +43,13 @@ namespace kge {
 
 constexpr int TILE_THREADS = 1024;
 constexpr int TILE_WAVES = TILE_THREADS / 64;
+constexpr int TILE_QCAP = 128;                                              // entries of a wave's LDS queue (tile_backward_kernel)
+constexpr size_t TILE_QUEUE_BYTES = (size_t)TILE_WAVES * TILE_QCAP * 16;    // 32 KB behind the accumulators
+// which instantiations of tile_backward_kernel collect their entries in the LDS queue first (see the kernel); CH = quads per lane
+__host__ __device__ constexpr bool tile_queued(int model, int CH) {
+    return model == AMDKGE_TRANSE || model == AMDKGE_ROTATE || (model == AMDKGE_DISTMULT && CH == 1);
+}
+static inline int tile_ch_of(int nq) { return (nq <= 64 || nq > 128) ? 1 : 2; }   // the CH run_tiled picks for the tile kernel
 
 struct TileArgs {
     float* x;                 // entity table (updated in place when g_out == NULL)
@@ -77,6 +84,9 @@ struct TileArgs {
                               // waves, each lane one quad), rows are owned by wave GROUPS: TILE_WAVES / gw owners per tile
     ModelConst mc;
     OptArgs opt;
+#ifdef KGE_ABLATE
+    int dbg;                  // development ablation build only: 256 no own-row loads, 512 no relation-row loads in the tile pass
+#endif
 };
 
 // LDS accumulators: [tile_rows][K] in table layout.  ds_add_f32 turned out to be far too slow for this
@@ -92,6 +102,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* acc = reinterpret_cast<float*>(smem);
 
+    __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tile = blockIdx.x;
     if (tile >= a.n_tiles) {
@@ -164,8 +175,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                 for (int c = 0; c < CH; ++c)
 #pragma unroll
                     for (int h = 0; h < NC; ++h) {
-                        pv[c][h] = *reinterpret_cast<const float4*>(rp + qoff[c] + h * a.k);
-                        ev[c][h] = *reinterpret_cast<const float4*>(re + qoff[c] + h * a.k);
+                        pv[c][h] = KGE_DBG(a, 512) ? make_float4(.1f, .2f, .3f, .4f) : *reinterpret_cast<const float4*>(rp + qoff[c] + h * a.k);
+                        ev[c][h] = KGE_DBG(a, 256) ? make_float4(.4f, .3f, .2f, .1f) : *reinterpret_cast<const float4*>(re + qoff[c] + h * a.k);
                     }
             }
         }
@@ -297,20 +308,82 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             if (in) { const uint4 e = sbuf[base + lane]; mine = StageEntry{e.x, e.y, __uint_as_float(e.z), e.w}; }
             process(mine, __ballot(in && (int)((mine.meta >> 2) % G) == grp));
         }
+    } else if constexpr (!tile_queued(MODEL, CH)) {
+        // Trilinear models with rows beyond 1 KB (ComplEx, DistMult k > 256) keep the chunk-by-chunk form: they are bandwidth-
+        // bound as they are (5.9 TB/s at C2), the queued form's operand sets do not fit the 128 VGPRs a 1024-thread workgroup
+        // leaves per lane (ComplEx: arrays went to scratch, 6x slower), and its 32 KB of LDS would shrink their tiles
+        // (measured: C3 and C4 7-8 % slower).
+        for (int base = 0; base < cnt; base += 64) {
+            StageEntry mine{0u, 0u, 0.f, 0u};
+            const bool in = base + lane < cnt;
+            if (in) mine = list[base + lane];
+            process(mine, __ballot(in && (int)((mine.meta >> 2) % G) == grp));
+        }
+        for (int base = 0; base < on; base += 64) {   // overflow list (entries of buckets that were full): every tile filters all of it
+            StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
+            if (base + lane < on) mine = a.ovf[base + lane];
+            const bool hit = (int64_t)mine.dest >= t0 && (int64_t)mine.dest < t1;
+            process(mine, __ballot(hit && (int)((mine.meta >> 2) % G) == grp));
+        }
     } else {
-    for (int base = 0; base < cnt; base += 64) {
-        StageEntry mine{0u, 0u, 0.f, 0u};
-        const bool in = base + lane < cnt;
-        if (in) mine = list[base + lane];
-        process(mine, __ballot(in && (int)((mine.meta >> 2) % G) == grp));
+    // Two phases per wave.  Scanning a 64-entry chunk yields only ~64/16 entries for this wave: processed chunk by chunk, a
+    // wave had 4 operand rows in flight and the chunk loads were serialised behind them (narrow rows -- TransE, DistMult
+    // k <= 256, C1 -- ran at a fraction of the fabric bandwidth: the pass took the same ~66 us whatever the row width).
+    // Now the wave first COLLECTS its entries into a private LDS queue (chunk loads software-pipelined, no row traffic),
+    // then drains the queue UNROLL entries at a time with all operand loads of a batch in flight.
+    uint4* queue = reinterpret_cast<uint4*>(smem + (((size_t)a.tile_rows * a.K * 4 + (a.lazy ? (size_t)a.tile_rows * gw : 0) + 15) & ~(size_t)15)) +
+                   (size_t)wv * TILE_QCAP;
+    int qn = 0;
+    auto drain = [&]() {
+        for (int i0 = 0; i0 < qn; i0 += UNROLL) {
+            uint32_t meta[UNROLL];
+            float g[UNROLL];
+            float4 v[UNROLL][CH][NC], pv[UNROLL][CH][NX], ev[UNROLL][CH][NX];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (i0 + u < qn) {
+                    const uint4 e = queue[i0 + u];   // same address in every lane: one LDS broadcast read, then scalars
+                    meta[u] = __builtin_amdgcn_readfirstlane(e.y);
+                    g[u] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.z));
+                    load_ops(__builtin_amdgcn_readfirstlane(e.x), meta[u], (int)__builtin_amdgcn_readfirstlane(e.w), v[u], pv[u], ev[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                if (i0 + u < qn) add_entry(meta[u], g[u], v[u], pv[u], ev[u]);
+        }
+        qn = 0;
+    };
+    auto collect = [&](const StageEntry& mine, bool sel) {
+        const unsigned long long mask = __ballot(sel);
+        if (!mask) return;
+        if (qn + 64 > TILE_QCAP) drain();
+        if (sel) {
+            uint32_t pp = 0;   // relation id of the entry's positive (TransE / RotatE), carried in place of `dest`
+            if constexpr (!TRILINEAR) pp = (uint32_t)a.triples[3 * (int64_t)mine.pos + 1];
+            queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))] =
+                make_uint4(mine.pos, mine.meta, __float_as_uint(mine.g), pp);
+        }
+        qn += __popcll(mask);
+    };
+    {
+        StageEntry next{0u, 0u, 0.f, 0u};
+        if (lane < cnt) next = list[lane];
+        for (int base = 0; base < cnt; base += 64) {
+            const StageEntry mine = next;
+            const bool in = base + lane < cnt;
+            if (base + 64 + lane < cnt) next = list[base + 64 + lane];   // the next chunk is in flight while this one is filed
+            collect(mine, in && (int)((mine.meta >> 2) % G) == grp);
+        }
     }
     // ---- overflow list (entries of buckets that were full): every tile filters all of it ----
     for (int base = 0; base < on; base += 64) {
         StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
         if (base + lane < on) mine = a.ovf[base + lane];
         const bool hit = (int64_t)mine.dest >= t0 && (int64_t)mine.dest < t1;
-        process(mine, __ballot(hit && (int)((mine.meta >> 2) % G) == grp));
+        collect(mine, hit && (int)((mine.meta >> 2) % G) == grp);
     }
+    drain();
     }
 
     // ---- flush: the tile's rows leave LDS exactly once ------------------------------------------------
@@ -366,12 +439,17 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     if (tid == 0) {
         a.counters[tile * 32] = 0;
         __threadfence();
+        s_last = 0;
         if (atomicAdd(a.counters + (size_t)(a.n_tiles + 1) * 32, 1) == a.n_tiles - 1) {
             a.counters[a.n_tiles * 32] = 0;
             a.counters[(a.n_tiles + 1) * 32] = 0;
-            fold_loss_parts(a.loss_parts, a.loss_sum);   // (the forward kernel finished before this launch started)
-            fold_loss_parts(a.loss_parts, a.reg_loss, 1);   // every tile's waves added theirs before taking the ticket
+            s_last = 1;
         }
+    }
+    __syncthreads();
+    if (s_last && wv == 0) {   // the last tile to finish folds the loss partials (one wave, one partial per lane)
+        fold_loss_parts(a.loss_parts, a.loss_sum, lane);      // (the forward kernel finished before this launch started)
+        fold_loss_parts(a.loss_parts, a.reg_loss, lane, 1);   // every tile's waves added theirs before taking the ticket
     }
 }
 
@@ -445,14 +523,17 @@ static int pick_tile_rows(int64_t n_rows, int K, size_t budget = 150 * 1024) {  
 static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p, bool det = false) {
     const int ks = stored_k(m), K = row_floats(m);
     if (ks % 4 != 0 || ks > 2048) return false;   // 16-byte layout; one wave (k <= 512) or one workgroup (k <= 2048) per positive
-    if ((ks <= 512 ? (size_t)4 * slot_lds_bytes(eta, 1) + 32 + 16 * (size_t)K : slot_lds_bytes(eta, 4) + 8 + 4 * (size_t)K) > 150 * 1024) return false;
+    if ((ks <= 512 ? (size_t)4 * slot_lds_bytes(eta, 1) + 32 + 16 * (size_t)K : slot_lds_bytes(eta, 4) + 8 + 4 * (size_t)K) +
+            sign_stash_bytes(m->scoring_type, eta, 2) > 150 * 1024) return false;
     const int64_t entries = B * (eta + 2);
     if (entries >= (1ll << 31)) return false;
     p.ns = det ? 5 : 4;
     p.sort_cap = 0;
     // deterministic mode shares the LDS between the accumulators and the sort buffer: shrink the tiles until a bucket
     // (+ slack for overflow entries) fits the buffer next to them
-    for (size_t budget = det ? 96 * 1024 : 150 * 1024;; budget = budget * 3 / 4) {
+    const int model_t = m->scoring_type == AMDKGE_HOLE ? AMDKGE_COMPLEX : m->scoring_type;
+    const size_t queue_bytes = tile_queued(model_t, tile_ch_of(ks / 4)) ? TILE_QUEUE_BYTES : 0;
+    for (size_t budget = det ? 96 * 1024 : 150 * 1024 - queue_bytes;; budget = budget * 3 / 4) {
         p.tile_rows = pick_tile_rows(m->n_ents, K, budget);
         if (p.tile_rows < 1) return false;
         p.n_tiles = (int)((m->n_ents + p.tile_rows - 1) / p.tile_rows);
@@ -493,11 +574,13 @@ static int launch_tile(const TileArgs& a, size_t shmem, hipStream_t st) {
 }
 
 template <int MODEL, int W, int CHF>
-static int launch_forward(const TrainArgs& f, hipStream_t st) {
+static int launch_forward(TrainArgs& f, hipStream_t st) {
     constexpr int slots = 4 / W;
     // LDS: per-slot score / id arrays, per-slot loss, and the transpose rows of emit_row (one per wave, or one per
     // workgroup when a positive spans the whole workgroup)
-    const size_t shmem = (size_t)slots * slot_lds_bytes(f.eta, W) + slots * sizeof(double) + (W == 1 ? 4 : 1) * (size_t)f.K * 4;
+    size_t shmem = (size_t)slots * slot_lds_bytes(f.eta, W) + slots * sizeof(double) + (W == 1 ? 4 : 1) * (size_t)f.K * 4;
+    f.sign_off = (int)shmem;
+    shmem += sign_stash_bytes(MODEL, f.eta, CHF);
     if (shmem > 64 * 1024) {
         static bool attr = false;
         if (!attr) {
@@ -528,8 +611,9 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     }
     // T: entity tiles (the owner applies the optimizer)
     te.gw = f.nq <= 128 ? 1 : (f.nq <= 256 ? 4 : 8);
-    const size_t shmem_t = (size_t)te.tile_rows * te.K * 4 + ((te.lazy || te.det) ? (((size_t)te.tile_rows * te.gw + 15) & ~(size_t)15) : 0) +
-                           (te.det ? (size_t)te.sort_cap * 16 : 0);
+    const size_t shmem_t = te.det ? (((size_t)te.tile_rows * te.K * 4 + (size_t)te.tile_rows * te.gw + 15) & ~(size_t)15) + (size_t)te.sort_cap * 16
+                                  : (((size_t)te.tile_rows * te.K * 4 + (te.lazy ? (size_t)te.tile_rows * te.gw : 0) + 15) & ~(size_t)15) +
+                                        (tile_queued(MODEL, tile_ch_of(f.nq)) ? TILE_QUEUE_BYTES : 0);
     // entries in flight per wave: bounded by the 128 VGPRs a 1024-thread workgroup leaves per lane (RotatE holds three
     // complex operand rows per entry)
     constexpr int U1 = TRILINEAR ? 8 : (MODEL == AMDKGE_ROTATE ? 2 : 4);
@@ -612,6 +696,9 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
     te.rel_cs = rel_cs; te.lazy = lazy ? 1 : 0; te.touched = touched; te.ns = p.ns; te.det = det ? 1 : 0; te.sort_cap = p.sort_cap;
     te.n_rels = m->n_rels; te.loss_parts = f.loss_parts; te.loss_sum = d_loss_sum;
+#ifdef KGE_ABLATE
+    te.dbg = f.dbg;
+#endif
     te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = ks; te.K = K; te.k_live = m->k; te.nq = ks / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;

@@ -245,6 +245,14 @@ class StepLoop:
                     self.dist.reduce_scatter_tensor(b[:4], a)
                 if coll != "alltoall" or not hasattr(self.dist, "batch_isend_irecv"):
                     self.dist.all_gather_into_tensor(b, b[self.rank * 4:(self.rank + 1) * 4])
+                else:   # the point-to-point return of _gather_slices, on the scratch tensor
+                    ops = []
+                    for q in range(W):
+                        if q != self.rank:
+                            ops.append(self.dist.P2POp(self.dist.isend, b[self.rank * 4:(self.rank + 1) * 4], q))
+                            ops.append(self.dist.P2POp(self.dist.irecv, b[q * 4:(q + 1) * 4], q))
+                    for req in self.dist.batch_isend_irecv(ops):
+                        req.wait()
             except RuntimeError:
                 return False
             return True
