@@ -46,8 +46,9 @@ constexpr int TILE_WAVES = TILE_THREADS / 64;
 constexpr int TILE_QCAP = 128;                                              // entries of a wave's LDS queue (tile_backward_kernel)
 constexpr size_t TILE_QUEUE_BYTES = (size_t)TILE_WAVES * TILE_QCAP * 16;    // 32 KB behind the accumulators
 // which instantiations of tile_backward_kernel collect their entries in the LDS queue first (see the kernel); CH = quads per lane
-__host__ __device__ constexpr bool tile_queued(int model, int CH) {
-    return model == AMDKGE_TRANSE || model == AMDKGE_ROTATE || (model == AMDKGE_DISTMULT && CH == 1);
+// (rows beyond 2 KB are bandwidth-bound chunk by chunk, and the queue's 32 KB of LDS would shrink their tiles: C5 5 % slower)
+__host__ __device__ constexpr bool tile_queued(int model, int CH, int K) {
+    return ((model == AMDKGE_TRANSE || model == AMDKGE_ROTATE) && K <= 512) || (model == AMDKGE_DISTMULT && CH == 1);
 }
 static inline int tile_ch_of(int nq) { return (nq <= 64 || nq > 128) ? 1 : 2; }   // the CH run_tiled picks for the tile kernel
 
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             if (in) { const uint4 e = sbuf[base + lane]; mine = StageEntry{e.x, e.y, __uint_as_float(e.z), e.w}; }
             process(mine, __ballot(in && (int)((mine.meta >> 2) % G) == grp));
         }
-    } else if constexpr (!tile_queued(MODEL, CH)) {
+    } else if (!tile_queued(MODEL, CH, a.K)) {
         // Trilinear models with rows beyond 1 KB (ComplEx, DistMult k > 256) keep the chunk-by-chunk form: they are bandwidth-
         // bound as they are (5.9 TB/s at C2), the queued form's operand sets do not fit the 128 VGPRs a 1024-thread workgroup
         // leaves per lane (ComplEx: arrays went to scratch, 6x slower), and its 32 KB of LDS would shrink their tiles
@@ -532,7 +533,7 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     // deterministic mode shares the LDS between the accumulators and the sort buffer: shrink the tiles until a bucket
     // (+ slack for overflow entries) fits the buffer next to them
     const int model_t = m->scoring_type == AMDKGE_HOLE ? AMDKGE_COMPLEX : m->scoring_type;
-    const size_t queue_bytes = tile_queued(model_t, tile_ch_of(ks / 4)) ? TILE_QUEUE_BYTES : 0;
+    const size_t queue_bytes = tile_queued(model_t, tile_ch_of(ks / 4), K) ? TILE_QUEUE_BYTES : 0;
     for (size_t budget = det ? 96 * 1024 : 150 * 1024 - queue_bytes;; budget = budget * 3 / 4) {
         p.tile_rows = pick_tile_rows(m->n_ents, K, budget);
         if (p.tile_rows < 1) return false;
@@ -613,7 +614,7 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     te.gw = f.nq <= 128 ? 1 : (f.nq <= 256 ? 4 : 8);
     const size_t shmem_t = te.det ? (((size_t)te.tile_rows * te.K * 4 + (size_t)te.tile_rows * te.gw + 15) & ~(size_t)15) + (size_t)te.sort_cap * 16
                                   : (((size_t)te.tile_rows * te.K * 4 + (te.lazy ? (size_t)te.tile_rows * te.gw : 0) + 15) & ~(size_t)15) +
-                                        (tile_queued(MODEL, tile_ch_of(f.nq)) ? TILE_QUEUE_BYTES : 0);
+                                        (tile_queued(MODEL, tile_ch_of(f.nq), te.K) ? TILE_QUEUE_BYTES : 0);
     // entries in flight per wave: bounded by the 128 VGPRs a 1024-thread workgroup leaves per lane (RotatE holds three
     // complex operand rows per entry)
     constexpr int U1 = TRILINEAR ? 8 : (MODEL == AMDKGE_ROTATE ? 2 : 4);

@@ -209,6 +209,16 @@ class KgeEngine:
         rows); reg_slots = loss_acc slots receiving the entity / relation regulariser values."""
         n_e = self.ent.numel() if rows_e is None else int(rows_e) * self.Ks
         opt_desc.row_floats = self.Ks
+        if rows_e is None and float(reg_e) == float(reg_r) and reg_slots[0] == reg_slots[1] and not opt_desc.lazy:
+            # both tables in ONE launch: they live in one flat allocation (the padding between / behind them holds zero
+            # parameters and zero gradients, which every rule maps to zero) -- one launch less on launch-bound shapes (C1)
+            opt_desc.reg_lambda = float(reg_e)
+            names = _ffi.OPT_SLOTS[self.opt_kind]
+            sl = [self.slot_flat[n] for n in names] + [None, None]
+            n_all = self._off + self._nr
+            check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(self.p_flat), _ptr(self.g_flat), _ptr(sl[0]), _ptr(sl[1]), n_all,
+                                           C.c_void_p(self.loss_acc.data_ptr() + 8 * int(reg_slots[0])), _stream()))
+            return
         for x, g, table, lam, n_el, slot in ((self.ent, self.g_ent, "e", reg_e, n_e, reg_slots[0]),
                                              (self.rel, self.g_rel, "r", reg_r, self.rel.numel(), reg_slots[1])):
             reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(slot))
