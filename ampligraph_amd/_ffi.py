@@ -95,6 +95,7 @@ SIGNATURES = {
     "amdkge_train_step_tiled": (C.c_int, [C.POINTER(Model), C.POINTER(Loss), C.POINTER(Opt), P, P, P, P, P, P, C.c_float,
                                           P, I64, I32,
                                           I64, I64, U64, U64, I64, I64, P, P, P, I32, I32, P, P, P, P, P, P]),
+    "amdkge_train_tiled_set_hot_rows": (C.c_int, [C.POINTER(Model), P, P, I32, P]),
     "amdkge_train_tiled_status": (C.c_int, [C.POINTER(Model), I64, I32, I32, P, C.POINTER(C.c_int32), P]),
     "amdkge_rank_workspace_bytes": (I64, [C.POINTER(Model), I64]),
     "amdkge_rank_counts": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, I64, I64, P, P, P]),

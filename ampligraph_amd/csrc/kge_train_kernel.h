@@ -21,6 +21,29 @@ struct __attribute__((aligned(16))) StageEntry {
 constexpr int LOSS_PARTS = 64;
 constexpr int LOSS_PART_STRIDE = 16;   // doubles
 
+// Hot rows (skewed graphs).  An entity that is the s / o of thousands of positives of one batch would put thousands of entries
+// on one row of one tile (one wave adds them one after the other) or, through POS_ATOMIC, thousands of atomic row-adds on the
+// same addresses.  Up to HOT_MAX such rows, named by the host, are instead spread over HOT_REPL replica rows: positive i adds
+// its s / o gradient row atomically into replica (block index mod HOT_REPL), the owning tile sums the replicas when it flushes
+// the row.  Every other row keeps the atomic-free staged path.
+// Block-interleaved row ownership of the tile pass: rows are dealt to the tiles in blocks of TILE_RB consecutive rows
+// (block b -> tile b % n_tiles).  See tile_backward_kernel.
+#ifndef KGE_TILE_RB
+#define KGE_TILE_RB 8
+#endif
+constexpr uint32_t TILE_RB = KGE_TILE_RB;   // (a plan uses fewer when the LDS cannot hold TILE_RB rows: rb = min(TILE_RB, tile_rows))
+__host__ __device__ __forceinline__ void tile_of_row(uint32_t row, uint32_t n_tiles, uint32_t rb, uint32_t& tile, uint32_t& local) {
+    const uint32_t blk = row / rb;
+    tile = blk % n_tiles;
+    local = (blk / n_tiles) * rb + row % rb;
+}
+__host__ __device__ __forceinline__ int64_t row_of_tile(uint32_t tile, uint32_t local, uint32_t n_tiles, uint32_t rb) {
+    return ((int64_t)(local / rb) * n_tiles + tile) * rb + local % rb;
+}
+
+constexpr int HOT_MAX = 64;
+constexpr int HOT_REPL = 16;
+
 struct TrainArgs {
     const float* ent;
     const float* rel;
@@ -47,11 +70,13 @@ struct TrainArgs {
     int sign_off;            // TransE: byte offset of the sign stash in dynamic LDS (see SIGNSTASH in the kernel)
     int ns;                  // staged rows per positive: 4, or 5 in deterministic mode (the relation-row gradient is staged too)
     int det;                 // deterministic mode (AMDKGE_TILED_DETERMINISTIC): no atomics on any gradient
+    const uint8_t* hot_map;  // AMDKGE_TILED_HOT_ROWS: byte per entity row, slot + 1 of a hot row, 0 otherwise (NULL: feature off)
+    float* hot_buf;          // [HOT_MAX][HOT_REPL][K]: replicas the gradient rows of hot entities are spread over
     uint8_t* touched;        // pos_atomic + lazy optimizer: byte per entity row, set for rows that received an atomic row-add
     StageEntry* st_lists;    // [n_tiles][cap] buckets of row-gradient entries, by owning tile
     StageEntry* st_ovf;      // overflow of full buckets
     int* st_counters;        // [(n_tiles + 1) * 32] bucket fill counts (128-byte stride), last = overflow count
-    int st_tile_rows, st_n_tiles, st_cap, st_ovf_cap;
+    int st_tile_rows, st_n_tiles, st_cap, st_ovf_cap, st_rb;
 #ifdef KGE_ABLATE
     int dbg;     // development ablation build only (make EXTRA=-DKGE_ABLATE, env AMDKGE_DEBUG): 1 no neg-row atomics, 2 no s/p/o atomics, 4 no pass 2, 32 no bucket appends, 64 no staged-row stores
 #endif
@@ -741,8 +766,10 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 if (j < eta) { dest = (uint32_t)sh_repl[j]; role = sh_keep[j] ? 0u : 1u; g = sh_neg[j] * sgn_scale; }
                 else { dest = (uint32_t)(j == eta ? ps : po); role = (j == eta) ? 2u : 3u; g = 1.f; }
                 if (g == 0.f) continue;   // inactive margin / clipped corruption: contributes nothing
-                const uint32_t tile = dest / (uint32_t)a.st_tile_rows;
-                StageEntry en{(uint32_t)i, role | ((dest - tile * (uint32_t)a.st_tile_rows) << 2), g, dest};
+                if (j >= eta && a.hot_map && a.hot_map[dest]) continue;   // hot row: went to its replicas (below), no entry
+                uint32_t tile, local;
+                tile_of_row(dest, (uint32_t)a.st_n_tiles, (uint32_t)a.st_rb, tile, local);   // block-interleaved ownership, see tile_backward_kernel
+                StageEntry en{(uint32_t)i, role | (local << 2), g, dest};
                 const int slotpos = atomicAdd(a.st_counters + (size_t)tile * 32, 1);
                 if (slotpos < a.st_cap) {
                     a.st_lists[(size_t)tile * a.st_cap + slotpos] = en;
@@ -916,6 +943,11 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 emit_row(a.g_ent + (int64_t)po * a.K, go, a.K, 1.f);
                 if (a.touched && ts == 0) { a.touched[ps] = 1; a.touched[po] = 1; }   // same value from every writer
             } else {
+                if (a.hot_map) {   // (wave-uniform branches: ps, po are per slot)
+                    const int hs = a.hot_map[ps], ho = a.hot_map[po];
+                    if (hs) emit_row(a.hot_buf + ((int64_t)(hs - 1) * HOT_REPL + (blockIdx.x & (HOT_REPL - 1))) * a.K, gs, a.K, 1.f);
+                    if (ho) emit_row(a.hot_buf + ((int64_t)(ho - 1) * HOT_REPL + (blockIdx.x & (HOT_REPL - 1))) * a.K, go, a.K, 1.f);
+                }
                 float* ps_ = a.stage_rows + ((int64_t)i * a.ns + 0) * a.K;
                 float* po_ = a.stage_rows + ((int64_t)i * a.ns + 1) * a.K;
 #pragma unroll

@@ -63,6 +63,8 @@ struct TileArgs {
     int det;                  // deterministic mode: the tile's entries are sorted into a canonical order before they are added
     int sort_cap;             // det: entries the LDS sort buffer holds (power of two)
     int lazy;                 // touched-rows optimizer mode (amdkge_opt.lazy): rows without an entry keep their bits
+    const uint8_t* hot_map;   // AMDKGE_TILED_HOT_ROWS (see HOT_MAX in kge_train_kernel.h); NULL = off
+    float* hot_buf;
     uint8_t* touched;         // lazy + pos_atomic: rows the forward kernel's atomics touched (read, then cleared here)
     const float* rel;         // live relation table (TransE / RotatE side of the gradient)
     const float* rel_cs;      // RotatE: [R][cos(phase) || sin(phase)] of this step's relation table (rel_phase_kernel)
@@ -81,6 +83,7 @@ struct TileArgs {
     int k, K, nq;             // stored half width, floats per stored row, quads per half
     int k_live;               // the model's k (RotatE: units behind it are zero padding, see grad_unit)
     int tile_rows, n_tiles, cap, ovf_cap;
+    int rb;                   // rows per ownership block (block-interleaved tiles)
     int gw;                   // waves that share one row (1: a wave covers the row; 4 / 8: long rows are split over a group of
                               // waves, each lane one quad), rows are owned by wave GROUPS: TILE_WAVES / gw owners per tile
     ModelConst mc;
@@ -123,9 +126,17 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     // workgroup barrier at the end of the kernel (the library keeps them zero between steps)
     const int cnt = min(a.counters[tile * 32], a.cap);
     const int on = min(a.counters[a.n_tiles * 32], a.ovf_cap);
-    const int64_t t0 = (int64_t)tile * a.tile_rows;
-    const int64_t t1 = min(a.n_rows, t0 + a.tile_rows);
-    const int nrow = (int)(t1 - t0);
+    // BLOCK-INTERLEAVED ownership: the table is cut into blocks of TILE_RB consecutive rows and block b belongs to tile
+    // b % n_tiles (local row r <-> table row row_of_tile(tile, r)).  Real graphs number their hubs first (ids are handed out
+    // first-seen), so contiguous row ranges give the first tiles several times the entries of the others and the tile pass is
+    // as slow as its busiest tile (zipf graph); dealing the blocks round the tiles spreads every popularity class.  Blocks
+    // rather than single rows keep the optimizer's streams (x, m, v of a tile) in runs of TILE_RB rows: with single rows a
+    // large table (C4: 123 k rows) lost 12 % to page locality.  Rows beyond the table in a tile's last block are skipped.
+    const uint32_t NT = (uint32_t)a.n_tiles;
+    const int nrow = a.tile_rows;
+    const uint32_t RB = (uint32_t)a.rb;
+    auto row_of = [&](int r) -> int64_t { return row_of_tile((uint32_t)tile, (uint32_t)r, NT, RB); };
+    auto row_ok = [&](int r) -> bool { return row_of(r) < a.n_rows; };
 
     // Row ownership.  Short rows: wave wv owns local rows r with r % 16 == wv and covers the whole row (CH quads per lane).
     // Long rows (gw > 1): a GROUP of gw waves owns the row and each wave covers its 64-quad slice, so that the few entries
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     uint8_t* tflag = reinterpret_cast<uint8_t*>(acc + (size_t)a.tile_rows * a.K);
     if (a.lazy)
         for (int r = grp + G * lane; r < nrow; r += G * 64)
-            tflag[r * gw + wg] = (a.touched && a.touched[t0 + r]) ? 1 : 0;
+            tflag[r * gw + wg] = (a.touched && row_ok(r) && a.touched[row_of(r)]) ? 1 : 0;
 
     // side-row loads of one staged entry.  All arguments are wave-uniform.
     // Operand loads of one staged entry (all arguments wave-uniform): the staged side row and, for TransE / RotatE
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                 // RotatE: cos / sin of the relation phases come from a per-step table (one sincos per relation unit
                 // instead of one per bucket entry: at k = 1000, eta = 64 that is 1e6 instead of 4.3e9 evaluations)
                 const float* rp = (MODEL == AMDKGE_ROTATE ? a.rel_cs : a.rel) + (int64_t)pp * a.K;
-                const float* re = a.x + (t0 + (int)(meta >> 2)) * a.K;
+                const float* re = a.x + row_of((int)(meta >> 2)) * a.K;
 #pragma unroll
                 for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         for (int base = 0; base < on; base += TILE_THREADS) {
             uint4 e = make_uint4(0, 0, 0, 0xFFFFFFFFu);
             if (base + tid < on) e = reinterpret_cast<const uint4*>(a.ovf)[base + tid];
-            if ((int64_t)e.w >= t0 && (int64_t)e.w < t1) {   // .w = dest
+            if (e.w != 0xFFFFFFFFu && (e.w / RB) % NT == (uint32_t)tile) {   // .w = dest
                 const int at = atomicAdd(&s_total, 1);
                 if (at < a.sort_cap) sbuf[at] = e;
             }
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         for (int base = 0; base < on; base += 64) {   // overflow list (entries of buckets that were full): every tile filters all of it
             StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
             if (base + lane < on) mine = a.ovf[base + lane];
-            const bool hit = (int64_t)mine.dest >= t0 && (int64_t)mine.dest < t1;
+            const bool hit = mine.dest != 0xFFFFFFFFu && (mine.dest / RB) % NT == (uint32_t)tile;
             process(mine, __ballot(hit && (int)((mine.meta >> 2) % G) == grp));
         }
     } else {
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     for (int base = 0; base < on; base += 64) {
         StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
         if (base + lane < on) mine = a.ovf[base + lane];
-        const bool hit = (int64_t)mine.dest >= t0 && (int64_t)mine.dest < t1;
+        const bool hit = mine.dest != 0xFFFFFFFFu && (mine.dest / RB) % NT == (uint32_t)tile;
         collect(mine, hit && (int)((mine.meta >> 2) % G) == grp);
     }
     drain();
@@ -394,15 +405,26 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     constexpr int KIND = decltype(kind_c)::value;
     for (int r = grp; r < nrow; r += G) {
         const float* arow = acc + (size_t)r * a.K;
-        if (a.lazy && a.apply_update && !tflag[r * gw + wg]) continue;   // untouched row: x, slots, regulariser stay as they are
+        if (!row_ok(r)) continue;
+        const int hot = a.hot_map ? a.hot_map[row_of(r)] : 0;   // a hot row's own-gradient rows wait in its replicas (always "touched")
+        if (a.lazy && a.apply_update && !hot && !tflag[r * gw + wg]) continue;   // untouched row: x, slots, regulariser stay as they are
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if (!qok[c]) continue;
 #pragma unroll
             for (int h = 0; h < NC; ++h) {
                 float4 g = *reinterpret_cast<const float4*>(arow + qoff[c] + h * a.k);
-                const int64_t off = (t0 + r) * a.K + qoff[c] + h * a.k;
+                const int64_t off = row_of(r) * a.K + qoff[c] + h * a.k;
                 float4* gp4 = reinterpret_cast<float4*>(a.g_ent + off);
+                if (hot) {   // sum the replicas in fixed order and leave them zero for the next step
+                    float4* hp = reinterpret_cast<float4*>(a.hot_buf + (int64_t)(hot - 1) * HOT_REPL * a.K + qoff[c] + h * a.k);
+#pragma unroll 4
+                    for (int q = 0; q < HOT_REPL; ++q) {
+                        const float4 t = hp[(size_t)q * (a.K >> 2)];
+                        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                        hp[(size_t)q * (a.K >> 2)] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
                 if (a.pos_atomic) {   // rows of the positives' own s / o
                     const float4 gd = *gp4;
                     g.x += gd.x; g.y += gd.y; g.z += gd.z; g.w += gd.w;
@@ -436,7 +458,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     // ---- leave the bookkeeping zeroed for the next step: own bucket now, overflow count by the last tile ----
     __syncthreads();
     if (a.touched)   // every wave has read its flags: clear the forward kernel's marks for the next step
-        for (int r = tid; r < nrow; r += TILE_THREADS) a.touched[t0 + r] = 0;
+        for (int r = tid; r < nrow; r += TILE_THREADS)
+            if (row_ok(r)) a.touched[row_of(r)] = 0;
     if (tid == 0) {
         a.counters[tile * 32] = 0;
         __threadfence();
@@ -505,9 +528,9 @@ __global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict_
 
 // ---- plan: tile size, bucket capacity and workspace layout (shared by the two entry points) ------------------
 struct TiledPlan {
-    int tile_rows, n_tiles, cap, ovf_cap;
+    int tile_rows, n_tiles, cap, ovf_cap, rb;
     int ns, sort_cap;   // deterministic mode: 5 staged rows per positive, LDS sort buffer entries (0 otherwise)
-    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, total;
+    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, off_hot_map, off_hot_buf, total;
 };
 
 // rows per tile: as many as fit the LDS budget, then shrunk so that the tiles fill whole waves of 256 CUs evenly
@@ -535,9 +558,28 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     const int model_t = m->scoring_type == AMDKGE_HOLE ? AMDKGE_COMPLEX : m->scoring_type;
     const size_t queue_bytes = tile_queued(model_t, tile_ch_of(ks / 4), K) ? TILE_QUEUE_BYTES : 0;
     for (size_t budget = det ? 96 * 1024 : 150 * 1024 - queue_bytes;; budget = budget * 3 / 4) {
-        p.tile_rows = pick_tile_rows(m->n_ents, K, budget);
-        if (p.tile_rows < 1) return false;
-        p.n_tiles = (int)((m->n_ents + p.tile_rows - 1) / p.tile_rows);
+        // Whole ownership blocks per tile (block-interleaved ownership, see tile_backward_kernel).  The block size is the largest
+        // power of two <= TILE_RB that still lets the tiles fill the 256 CUs evenly: a tile's rows come in multiples of the
+        // block, and at C2 (14 505 rows, ~57 per tile) blocks of 8 would leave 11 % of the CUs without a tile.
+        const int fit = (int)(budget / ((size_t)K * 4));
+        if (fit < 1) return false;
+        double best_eff = -1.0;
+        for (int rb = (int)TILE_RB; rb >= 1; rb >>= 1) {
+            if (rb > fit) continue;
+            const int64_t blocks = (m->n_ents + rb - 1) / rb;
+            int64_t per = 0;
+            for (int64_t mm = 1;; ++mm) {   // smallest number of CU rounds whose tile fits the LDS
+                per = (blocks + 256 * mm - 1) / (256 * mm);
+                if (per * rb <= fit && per * rb <= 4096) break;
+            }
+            const int64_t nt = (blocks + per - 1) / per, rounds = (nt + 255) / 256;
+            const double eff = (double)m->n_ents / (double)(per * rb) / (double)(rounds * 256);
+            if (eff > best_eff + 0.03 || best_eff < 0) {   // a smaller block must buy at least 3 % of the chip
+                best_eff = eff; p.rb = rb; p.tile_rows = (int)(per * rb); p.n_tiles = (int)nt;
+            }
+            if (eff >= 0.97) break;
+        }
+        if (best_eff < 0) return false;
         // bucket capacity: twice the mean + slack (Poisson tail; anything beyond goes to the overflow list)
         const int64_t mean = (entries + p.n_tiles - 1) / p.n_tiles;
         p.cap = (int)(2 * mean + (mean >= 224 ? 256 : 32 + mean));
@@ -552,6 +594,8 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
     p.off_loss = o; o += up((size_t)LOSS_PARTS * LOSS_PART_STRIDE * 8);   // first: the same place in every plan (kept zero between steps)
+    p.off_hot_map = o; o += up((size_t)m->n_ents);                        // hot-row map and replicas: also independent of B / eta / mode,
+    p.off_hot_buf = o; o += up((size_t)HOT_MAX * HOT_REPL * K * 4);       // written by amdkge_train_tiled_set_hot_rows
     p.off_cnt = o; o += up((size_t)(p.n_tiles + 3) * 32 * 4);   // bucket fills, overflow count, finished-tiles ticket, det-sort overflow flag
     p.off_lists = o; o += up((size_t)p.n_tiles * p.cap * sizeof(StageEntry));
     p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
@@ -685,10 +729,12 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     f.sc = SampleCfg{sample_base, (uint32_t)sample_range, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step,
                      (uint32_t)(step >> 32), row_offset, b_global > 0 ? b_global : B};
     f.mc = model_const(m); f.loss = *loss;
+    const bool hot = (flags & AMDKGE_TILED_HOT_ROWS) && !det && !(flags & AMDKGE_TILED_POS_ATOMIC);
+    f.hot_map = hot ? (const uint8_t*)(w + p.off_hot_map) : nullptr; f.hot_buf = (float*)(w + p.off_hot_buf);
     f.touched = touched; f.ns = p.ns; f.det = det ? 1 : 0;
     f.loss_parts = (double*)(w + p.off_loss);
     f.stage_rows = stage_rows; f.st_lists = lists; f.st_ovf = ovf; f.st_counters = counters;
-    f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap;
+    f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap; f.st_rb = p.rb;
 #ifdef KGE_ABLATE
     { const char* e = getenv("AMDKGE_DEBUG"); f.dbg = e ? atoi(e) : 0; }
 #endif
@@ -696,13 +742,13 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
     te.rel_cs = rel_cs; te.lazy = lazy ? 1 : 0; te.touched = touched; te.ns = p.ns; te.det = det ? 1 : 0; te.sort_cap = p.sort_cap;
-    te.n_rels = m->n_rels; te.loss_parts = f.loss_parts; te.loss_sum = d_loss_sum;
+    te.n_rels = m->n_rels; te.loss_parts = f.loss_parts; te.loss_sum = d_loss_sum; te.hot_map = f.hot_map; te.hot_buf = f.hot_buf;
 #ifdef KGE_ABLATE
     te.dbg = f.dbg;
 #endif
     te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = ks; te.K = K; te.k_live = m->k; te.nq = ks / 4;
-    te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.mc = f.mc;
+    te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.rb = p.rb; te.mc = f.mc;
     fill_opt_args(te.opt, opt);
     // Whole step in two launches when nothing in the tile pass reads the live relation table (trilinear models)
     // and the tables are updated in place: the relation sweep rides in extra workgroups of the tile kernel.
@@ -753,5 +799,29 @@ extern "C" int amdkge_train_tiled_status(const amdkge_model* m, int64_t B, int32
     if (hipError_t e = hipMemcpyAsync(status, flag, sizeof(int), hipMemcpyDeviceToHost, st)) return set_error_hip(e, "hipMemcpyAsync(status)");
     if (hipError_t e = hipStreamSynchronize(st)) return set_error_hip(e, "hipStreamSynchronize");
     if (*status) { if (hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st)) return set_error_hip(e, "hipMemsetAsync(status)"); }
+    return AMDKGE_OK;
+}
+
+namespace kge {
+__global__ void hot_map_kernel(const int32_t* ids, int n, int64_t n_ents, uint8_t* map) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ids[i] >= 0 && ids[i] < n_ents) map[ids[i]] = (uint8_t)(i + 1);
+}
+}  // namespace kge
+
+extern "C" int amdkge_train_tiled_set_hot_rows(const amdkge_model* m, void* d_work, const int32_t* d_hot_ids, int32_t n_hot, void* stream) {
+    if (int rc = validate_model(m)) return rc;
+    if (!d_work || n_hot < 0 || n_hot > HOT_MAX || (n_hot > 0 && !d_hot_ids)) return set_error(AMDKGE_EINVAL, "set_hot_rows: bad arguments (at most 64 hot rows)");
+    TiledPlan p;
+    if (!make_plan(m, 1, 1, p)) return set_error(AMDKGE_EUNSUPPORTED, "set_hot_rows: shape not supported by the owner-computes path");
+    char* w = (char*)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    hipStream_t st = (hipStream_t)stream;
+    const int K = row_floats(m);
+    if (hipError_t e = hipMemsetAsync(w + p.off_hot_map, 0, (size_t)m->n_ents, st)) return set_error_hip(e, "hipMemsetAsync(hot map)");
+    if (hipError_t e = hipMemsetAsync(w + p.off_hot_buf, 0, (size_t)HOT_MAX * HOT_REPL * K * 4, st)) return set_error_hip(e, "hipMemsetAsync(hot replicas)");
+    if (n_hot > 0) {
+        hipLaunchKernelGGL(hot_map_kernel, dim3(1), dim3(64), 0, st, d_hot_ids, (int)n_hot, (int64_t)m->n_ents, (uint8_t*)(w + p.off_hot_map));
+        return check_launch("set_hot_rows");
+    }
     return AMDKGE_OK;
 }

@@ -165,7 +165,8 @@ class KgeEngine:
         pos_atomic: skewed graphs, see AMDKGE_TILED_POS_ATOMIC in include/amdkge.h; deterministic: AMDKGE_TILED_DETERMINISTIC
         (bitwise reproducible tables: sorted tile accumulation, staged relation gradient; excludes pos_atomic)."""
         B = int(triples.shape[0])
-        flags = (1 if pos_atomic else 0) | (2 if deterministic else 0)
+        hot = getattr(self, "_hot_ids", None) is not None and not pos_atomic and not deterministic
+        flags = (1 if pos_atomic else 0) | (2 if deterministic else 0) | (4 if hot else 0)
         if getattr(self, "_twork_flags", flags) & 2 != flags & 2:
             self._twork = None   # the two modes lay out the bookkeeping differently: a workspace serves one of them
         self._twork_flags = flags
@@ -176,6 +177,11 @@ class KgeEngine:
         if self._twork is None or self._twork.numel() < need:
             # zero-filled once; the library keeps its bookkeeping region zero between steps
             self._twork = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            self._hot_applied = False
+        if hot and not getattr(self, "_hot_applied", False):
+            check(self.lib.amdkge_train_tiled_set_hot_rows(C.byref(self.model), _ptr(self._twork), _ptr(self._hot_ids),
+                                                           int(self._hot_ids.shape[0]), _stream()))
+            self._hot_applied = True
         if sample_range is None:
             sample_range = self.n_ents
         s0, s1 = self._slots_of("e")
@@ -193,6 +199,16 @@ class KgeEngine:
         except Exception:
             self._twork = None   # bookkeeping may be dirty after a failed launch: start from a fresh zeroed buffer
             raise
+
+    def set_hot_rows(self, ids):
+        """Declare up to 64 hot entity rows (AMDKGE_TILED_HOT_ROWS: skewed graphs); None / empty switches the feature off."""
+        if ids is None or len(ids) == 0:
+            self._hot_ids = None
+        else:
+            self._hot_ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32)[:64]).to(self.device)
+        self._hot_applied = False
+        if self._hot_ids is None and self._twork is not None:   # clear a map an earlier fit left in the workspace
+            check(self.lib.amdkge_train_tiled_set_hot_rows(C.byref(self.model), _ptr(self._twork), None, 0, _stream()))
 
     def tiled_status(self):
         """!= 0 if a DETERMINISTIC step fell back to unsorted accumulation in some tile since the last query (synchronises)."""

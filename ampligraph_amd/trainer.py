@@ -39,6 +39,21 @@ def prefer_tiled(engine):
     return True
 
 
+def hot_rows(triples, batch_size, threshold, limit=64):
+    """Entity ids expected to receive more than `threshold` own-row gradients (as s or o of a positive) per batch of
+    `batch_size` positives, most frequent first, at most `limit` -- and the expected count of the first entity beyond them."""
+    import numpy as np
+
+    t = np.asarray(triples)
+    if t.shape[0] == 0:
+        return np.zeros(0, dtype=np.int32), 0.0
+    cnt = np.bincount(np.concatenate([t[:, 0], t[:, 2]]).astype(np.int64)).astype(np.float64) * (float(batch_size) / float(t.shape[0]))
+    order = np.argsort(-cnt, kind="stable")
+    n = int((cnt[order] > threshold).sum())
+    rest = float(cnt[order[limit]]) if n > limit and len(order) > limit else 0.0
+    return order[:min(n, limit)].astype(np.int32), rest
+
+
 def hot_row_entries(triples, batch_size):
     """Expected number of gradient rows ONE entity receives from the positives of one batch, for the most frequent
     entity of `triples` (numpy (n,3) ids): (count as subject + count as object) / n * batch_size."""
@@ -52,6 +67,7 @@ def hot_row_entries(triples, batch_size):
 
 
 HOT_ROW_THRESHOLD = 256.0   # expected entries on one row per batch beyond which the positives' rows go atomic
+HOT_ROW_REPLICA_THRESHOLD = 48.0   # expected own-row gradients per batch beyond which an entity gets replica rows
 
 
 class StepLoop:
@@ -108,7 +124,16 @@ class StepLoop:
     def configure_for_data(self, triples, batch_size):
         """Pick the owner-computes variant for this training set (host-side, once per fit): skewed graphs route the
         positives' own s / o gradient rows through atomics (AMDKGE_TILED_POS_ATOMIC)."""
-        self.pos_atomic = (not self.deterministic) and hot_row_entries(triples, -(-int(batch_size) // self.world)) > HOT_ROW_THRESHOLD
+        per_rank = -(-int(batch_size) // self.world)
+        self.pos_atomic = False
+        if self.deterministic or not hasattr(self.engine, "set_hot_rows"):
+            self.pos_atomic = (not self.deterministic) and hot_row_entries(triples, per_rank) > HOT_ROW_THRESHOLD
+            return self.pos_atomic
+        # skewed graphs: the (up to 64) entities that are the s / o of many positives of a batch get replica rows
+        # (AMDKGE_TILED_HOT_ROWS); only if even the 65th entity is that hot do ALL positives' rows go through atomics
+        ids, rest = hot_rows(triples, per_rank, HOT_ROW_REPLICA_THRESHOLD)
+        self.engine.set_hot_rows(ids)
+        self.pos_atomic = rest > HOT_ROW_THRESHOLD
         return self.pos_atomic
 
     def step(self, global_batch, rng_step, focus=None):

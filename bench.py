@@ -68,6 +68,9 @@ def parse():
                          "(amdkge_opt.lazy, a documented deviation)")
     ap.add_argument("--deterministic", action="store_true", help="AMDKGE_TILED_DETERMINISTIC: bitwise reproducible tables (sorted tile "
                     "accumulation, staged relation gradient); reports its cost")
+    ap.add_argument("--skew-mode", default="auto", choices=["auto", "none", "atomic", "hot"],
+                    help="development: how the positives' own rows of hot entities are handled (auto = configure_for_data decides; none = all "
+                         "staged; atomic = AMDKGE_TILED_POS_ATOMIC; hot = replica rows for the hot entities only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -233,6 +236,11 @@ def main():
     loop.deterministic = bool(args.deterministic) or loop.deterministic
     if hasattr(loop, "configure_for_data") and data["train"] is not None:
         loop.configure_for_data(data["train"], Bg)
+    if args.skew_mode != "auto" and hasattr(loop, "pos_atomic"):
+        from ampligraph_amd.trainer import HOT_ROW_REPLICA_THRESHOLD, hot_rows
+
+        loop.pos_atomic = args.skew_mode == "atomic"
+        eng.set_hot_rows(hot_rows(data["train"], B, HOT_ROW_REPLICA_THRESHOLD)[0] if args.skew_mode == "hot" else None)
     # the training set lives in HBM; a global batch is a contiguous slice (reference order: sequential,
     # un-shuffled, graph_data_loader.py:472-523); each rank takes its share of it inside the step loop
     if stream is None:

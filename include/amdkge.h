@@ -208,9 +208,18 @@ int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_s
  * exceed the sort buffer (an extremely hot tile) is processed unsorted and reported by amdkge_train_tiled_status.
  * (The fp64 loss accumulators still use atomics: they agree to ~1e-15 relative and feed nothing back into the tables.) */
 #define AMDKGE_TILED_DETERMINISTIC 2
+/* AMDKGE_TILED_HOT_ROWS: skewed graphs.  Up to 64 "hot" entity rows, declared beforehand with amdkge_train_tiled_set_hot_rows,
+ * receive the gradient rows of the positives whose s / o they are through atomic row-adds spread over 16 replica rows each
+ * (summed by the owning tile); every other row keeps the atomic-free staged path.  Replaces POS_ATOMIC where a few entities
+ * dominate (zipf: the top entity is the s or o of ~10 % of a batch).  Ignored with DETERMINISTIC / POS_ATOMIC.  Hot rows count
+ * as touched in the lazy optimizer mode.  Results are identical up to fp32 summation order. */
+#define AMDKGE_TILED_HOT_ROWS 4
 int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta);
 /* status != 0 after a DETERMINISTIC step: some tile fell back to unsorted accumulation since the last query (flag is cleared).
  * Synchronises the stream. */
+/* Declares the hot rows of a workspace (d_hot_ids: device int32 [n_hot], n_hot <= 64; n_hot = 0 clears them).  The map and the
+ * replicas live at offsets of d_work that do not depend on B / eta / flags, so one call serves every later step on that buffer. */
+int amdkge_train_tiled_set_hot_rows(const amdkge_model* m, void* d_work, const int32_t* d_hot_ids, int32_t n_hot, void* stream);
 int amdkge_train_tiled_status(const amdkge_model* m, int64_t B, int32_t eta, int32_t flags, void* d_work, int32_t* status, void* stream);
 int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss* loss, const amdkge_opt* opt,
                             float* d_ent, float* d_rel, float* d_ent_slot0, float* d_ent_slot1,

@@ -329,7 +329,8 @@ def test_tiled_step_in_place_parity(gpu_lib, opt, model, reg, pos_atomic):
         assert np.abs(e - st.ent).max() < 2.5e-2   # a sign flip of a ~0 gradient moves Adam by at most 2*lr
         for nme in st.slots:
             # RMSprop-with-momentum's lr*g/sqrt(r + eps) is as ill-conditioned at g ~ 0 as Adam's update: bulk comparison
-            ok = np.isclose(dense(eng, eng.slots[nme]), st.slots[nme], rtol=1e-3, atol=1e-6)
+            # (elements that cancel to ~0 carry the absolute noise of their terms: floor relative to the tensor's magnitude)
+            ok = np.isclose(dense(eng, eng.slots[nme]), st.slots[nme], rtol=1e-3, atol=1e-6 + 2e-5 * np.abs(st.slots[nme]).max())
             assert ok.mean() > (0.99 if opt == "rmsprop_mom" and nme.startswith("mom") else 0.9999), (nme, t, ok.mean())
 
 
@@ -660,3 +661,51 @@ def test_filter_ranges_kernel_equals_host_lookup(gpu_lib):
             lo, hi = fn(T)
             l2, h2, ids = fi.device_filter(eng, dev(T), sd)
             assert np.array_equal(lo, l2.cpu().numpy()) and np.array_equal(hi, h2.cpu().numpy()), sd
+
+
+@pytest.mark.parametrize("model,k", [("ComplEx", 16), ("TransE", 50), ("RotatE", 9), ("DistMult", 600)])
+def test_tiled_hot_rows_parity(gpu_lib, model, k):
+    """AMDKGE_TILED_HOT_ROWS: a few entities are the s / o of most positives; their own-row gradients go through replica rows
+    (atomics spread over 16 rows, summed by the owning tile), everything else stays staged.  Gradient-only and in-place forms
+    against the oracle, two steps on one workspace (the replicas must come back zero), then the feature switched off again."""
+    from ampligraph_amd import _ffi
+
+    N, R, eta, B = 300, 3, 3, 2000
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.4 if k < 100 else 0.05)
+    rng = np.random.default_rng(8)
+    X = rand_triples(rng, B, N, R)
+    X[: B // 2, 0] = 7
+    X[::5, 2] = 7
+    X[1::7, 2] = 11
+    eng.set_hot_rows([7, 11, 299])          # 299: declared hot but (almost) unused
+    for loss in ("self_adversarial", "pairwise"):
+        L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, loss, "sum", 5, 2)
+        assert eng._last_tiled[2] & 4
+        negs = O.generate_corruptions(X, N, eta, 5, 2)
+        total, Te, Tr, _ = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, "sum", R)
+        assert abs(L - float(total)) <= 2e-5 * max(1.0, abs(L))
+        assert_grads_close(Ge, Te, tol=1e-4)   # thousands of fp32 terms per hot row, unordered
+        assert_grads_close(Gr, Tr, tol=1e-4)
+    # complete steps in place (dense and touched-rows optimizer)
+    for lazy in (False, True):
+        eng2, _, _ = make_engine(model, k, N, R, scale=0.4 if k < 100 else 0.05)
+        eng2.set_hot_rows([7, 11])
+        w, mk = make_optimizer("adam", {})
+        w.lazy = lazy
+        eng2.prepare_training(w.name)
+        st = mk(ent, rel)
+        for t in range(1, 3):
+            Xt = X[rng.permutation(B)]
+            eng2.loss_acc.zero_()
+            eng2.train_step_tiled(dev(Xt), eta, loss_desc("self_adversarial"), w.to_ffi(t, 2), 77, t)
+            ref_loss = float(O.train_step(st, model, Xt, eta, "self_adversarial", 77, t, max_rel_size=R, lazy=lazy))
+            torch.cuda.synchronize()
+            got_loss = float(eng2.loss_acc[0].item()) + float(eng2.loss_acc[1].item())
+            assert abs(got_loss - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss)), (t, got_loss, ref_loss)
+            e, r = eng2.get_tables()
+            # (a hot row sums ~1 000 fp32 terms in arrival order; where they cancel, Adam's m / sqrt(v) amplifies the noise)
+            assert (np.abs(e - st.ent) <= 1e-5 + 1e-4 * np.abs(st.ent)).mean() > (0.94 if model == "TransE" else 0.97) and np.abs(e - st.ent).max() < 2.5e-2
+    eng.set_hot_rows(None)
+    L2, Ge2, _, _, _ = run_tiled_grads(eng, X, eta, "pairwise", "sum", 5, 2)
+    assert not (eng._last_tiled[2] & 4) and abs(L2 - L) <= 1e-6 * abs(L)
+    assert_grads_close(Ge2, Te, tol=1e-4)
