@@ -118,6 +118,7 @@ SIGNATURES = {
     "amdkge_session_set_rows": (C.c_int, [P, I32, I64, I64, P]),
     "amdkge_session_get_rows": (C.c_int, [P, I32, P, I64, I64, P]),
     "amdkge_session_train_step": (C.c_int, [P, P, I64, P, C.POINTER(C.c_double)]),
+    "amdkge_session_set_hot_rows": (C.c_int, [P, P, I32]),
     "amdkge_session_score": (C.c_int, [P, P, I64, P]),
     "amdkge_session_rank": (C.c_int, [P, P, I64, P, P, P, P, P, I64, I32, I32, P]),
 }

@@ -27,6 +27,8 @@ struct amdkge_session {
     int64_t buf_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t step = 0;
     int64_t iteration = 0;
+    std::vector<int32_t> hot_ids;   // AMDKGE_TILED_HOT_ROWS: declared hot rows, (re)applied whenever the workspace is (re)allocated
+    bool hot_dirty = false;
 };
 
 namespace {
@@ -204,14 +206,32 @@ extern "C" int amdkge_session_train_step(amdkge_session* s, const int32_t* tripl
             KGE_HIP(hipMalloc(&s->twork, (size_t)need), "hipMalloc(twork)");
             KGE_HIP(hipMemsetAsync(s->twork, 0, (size_t)need, s->st), "hipMemsetAsync(twork)");
             s->twork_bytes = need;
+            s->hot_dirty = !s->hot_ids.empty();
         }
+        int32_t step_flags = s->cfg.flags;
+        if (s->hot_dirty) {
+            void* d_hot;
+            KGE_RC(upload(s, 1, s->hot_ids.data(), (int64_t)(s->hot_ids.size() * sizeof(int32_t)), &d_hot));
+            KGE_RC(amdkge_train_tiled_set_hot_rows(m, s->twork, (const int32_t*)d_hot, (int32_t)s->hot_ids.size(), s->st));
+            s->hot_dirty = false;
+            if (focus_w) { KGE_RC(upload(s, 1, focus_w, B * (int64_t)sizeof(float), &d_fw)); loss.d_focus_w = (const float*)d_fw; }   // slot 1 was reused
+        }
+        if (!s->hot_ids.empty()) step_flags |= AMDKGE_TILED_HOT_ROWS;
         const int rc = amdkge_train_step_tiled(m, &loss, &opt, s->tab[0], s->tab[1], s->tab[2], s->tab[3], s->tab[4], s->tab[5],
                                                s->cfg.rel_reg_lambda, (const int32_t*)d_tri, B, s->cfg.eta, 0, m->n_ents, s->cfg.seed,
-                                               s->step, 0, 0, nullptr, s->g_ent, s->g_rel, 1, s->cfg.flags, s->acc, s->acc + 1,
+                                               s->step, 0, 0, nullptr, s->g_ent, s->g_rel, 1, step_flags, s->acc, s->acc + 1,
                                                nullptr, nullptr, s->twork, s->st);
         if (rc != AMDKGE_OK) {   // bookkeeping may be dirty after a failed launch: start from a fresh zeroed buffer next time
             (void)hipFree(s->twork); s->twork = nullptr; s->twork_bytes = 0;
             return rc;
+        }
+        if (step_flags & AMDKGE_TILED_DETERMINISTIC) {   // a tile beyond its sort buffer fell back to arrival order: say so
+            int32_t st_flag = 0;
+            KGE_RC(amdkge_train_tiled_status(m, B, s->cfg.eta, step_flags, s->twork, &st_flag, s->st));
+            if (st_flag) {
+                s->step += 1; s->iteration += 1;   // the step itself was carried out
+                return set_error(AMDKGE_EUNSUPPORTED, "session_train_step: deterministic mode -- a tile received more entries than its sort buffer holds (a very hot row); this step's sums were not all added in canonical order");
+            }
         }
     } else {          // shapes the pair does not cover: atomic forward/backward + dense sweeps
         KGE_RC(amdkge_train_fwdbwd(m, &loss, s->tab[0], s->tab[1], (const int32_t*)d_tri, B, s->cfg.eta, 0, m->n_ents, s->cfg.seed,
@@ -315,5 +335,16 @@ extern "C" int amdkge_session_rank(amdkge_session* s, const int32_t* triples, in
     }
     KGE_HIP(hipMemcpyAsync(ranks_out, d_ranks, (size_t)n * (two_cols ? 2 : 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
     KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_set_hot_rows(amdkge_session* s, const int32_t* ids, int32_t n) {
+    if (!s || n < 0 || n > 64 || (n > 0 && !ids)) return set_error(AMDKGE_EINVAL, "session_set_hot_rows: bad arguments (at most 64 rows)");
+    for (int32_t i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= s->cfg.model.n_ents) return set_error(AMDKGE_EINVAL, "session_set_hot_rows: row id outside the entity table");
+    KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+    s->hot_ids.assign(ids, ids + n);
+    if (n == 0 && s->twork) KGE_RC(amdkge_train_tiled_set_hot_rows(&s->cfg.model, s->twork, nullptr, 0, s->st));   // clear the map
+    s->hot_dirty = n > 0;
     return AMDKGE_OK;
 }

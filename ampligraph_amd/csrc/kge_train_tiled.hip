@@ -533,17 +533,6 @@ struct TiledPlan {
     size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, off_hot_map, off_hot_buf, total;
 };
 
-// rows per tile: as many as fit the LDS budget, then shrunk so that the tiles fill whole waves of 256 CUs evenly
-static int pick_tile_rows(int64_t n_rows, int K, size_t budget = 150 * 1024) {   // accumulators; up to 4 KB of row flags sit behind them
-    int fit = (int)(budget / ((size_t)K * 4));
-    if (fit < 1) return 0;
-    if (fit > 4096) fit = 4096;
-    for (int64_t m = 1;; ++m) {   // smallest number of block waves m whose tile size fits
-        const int64_t r = (n_rows + 256 * m - 1) / (256 * m);
-        if (r <= fit) return (int)(r < 1 ? 1 : r);
-    }
-}
-
 static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p, bool det = false) {
     const int ks = stored_k(m), K = row_floats(m);
     if (ks % 4 != 0 || ks > 2048) return false;   // 16-byte layout; one wave (k <= 512) or one workgroup (k <= 2048) per positive
@@ -586,8 +575,13 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
         if (!det) break;
         int sc = 64;
         while (sc < p.cap + 64) sc <<= 1;
-        const size_t lds = (size_t)p.tile_rows * K * 4 + 4096 + 16 + (size_t)sc * 16;
-        if (lds <= 158 * 1024) { p.sort_cap = sc; break; }
+        const size_t fixed = (size_t)p.tile_rows * K * 4 + 4096 + 16;
+        if (fixed + (size_t)sc * 16 <= 158 * 1024) {
+            // take what the LDS still offers (up to 8192 entries): a hub's tile receives many times the mean
+            while (sc < 8192 && fixed + (size_t)sc * 2 * 16 <= 158 * 1024) sc <<= 1;
+            p.sort_cap = sc;
+            break;
+        }
         if (p.tile_rows == 1) return false;   // one row per tile and its bucket still does not fit: not a shape for this mode
     }
     p.ovf_cap = (int)(entries > 0 ? entries : 1);

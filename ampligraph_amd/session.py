@@ -28,7 +28,7 @@ def _p(a):
 
 class Session:
     def __init__(self, scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer=None, rel_regularizer=None, seed=0,
-                 device=0, pos_atomic=False, focus_nonlinearity=None):
+                 device=0, pos_atomic=False, focus_nonlinearity=None, deterministic=False):
         self.lib = _ffi.lib()
         self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], int(k)))
         self.n_ents, self.n_rels = int(n_ents), int(n_rels)
@@ -41,7 +41,7 @@ class Session:
         cfg.opt.reg_lambda = regularizer.lam if regularizer is not None else 0.0
         rr = rel_regularizer if rel_regularizer is not None else regularizer
         cfg.rel_reg_lambda = rr.lam if rr is not None else 0.0
-        cfg.eta, cfg.seed, cfg.device, cfg.flags = int(eta), int(seed), int(device), 1 if pos_atomic else 0
+        cfg.eta, cfg.seed, cfg.device, cfg.flags = int(eta), int(seed), int(device), (1 if pos_atomic else 0) | (2 if deterministic else 0)
         self._h = C.c_void_p()
         check(self.lib.amdkge_session_create(C.byref(cfg), C.byref(self._h)))
 
@@ -73,6 +73,11 @@ class Session:
         out = np.empty((int(nrows), self.K), dtype=np.float32)
         check(self.lib.amdkge_session_get_rows(self._h, _ffi.TABLES[table], None, int(row0), int(nrows), _p(out)))
         return out
+
+    def set_hot_rows(self, ids):
+        """Skewed graphs: up to 64 hot entity rows get replica rows (amdkge_session_set_hot_rows); None / [] switches it off."""
+        a = _i32(ids if ids is not None else [])
+        check(self.lib.amdkge_session_set_hot_rows(self._h, _p(a) if a.shape[0] else None, int(a.shape[0])))
 
     def train_step(self, triples, focus_w=None):
         t = _i32(triples)

@@ -365,7 +365,8 @@ typedef struct amdkge_session_config {
     int32_t eta;               /* corruptions per positive */
     uint64_t seed;             /* negatives: Philox key; step counter = number of train steps done so far */
     int32_t device;            /* HIP device ordinal */
-    int32_t flags;             /* AMDKGE_TILED_POS_ATOMIC for skewed graphs, else 0 */
+    int32_t flags;             /* AMDKGE_TILED_* of the train steps: 0, POS_ATOMIC (skewed graphs, all positives' rows through
+                                * atomics) or DETERMINISTIC; HOT_ROWS is switched on by amdkge_session_set_hot_rows */
 } amdkge_session_config;
 
 enum { AMDKGE_TABLE_ENT = 0, AMDKGE_TABLE_REL = 1, AMDKGE_TABLE_ENT_SLOT0 = 2, AMDKGE_TABLE_ENT_SLOT1 = 3,
@@ -383,6 +384,8 @@ int amdkge_session_get_rows(amdkge_session* s, int32_t table, const int32_t* ids
 /* One training step on B positives (host int32 [B,3]); focus_w: NULL or host fp32 [B] (FocusE, needs
  * cfg.loss.focus_nonlinearity); *loss_out (may be NULL) = data loss + regulariser terms of this batch. */
 int amdkge_session_train_step(amdkge_session* s, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out);
+/* Skewed graphs: declare up to 64 hot entity rows (AMDKGE_TILED_HOT_ROWS); n = 0 switches the feature off again. */
+int amdkge_session_set_hot_rows(amdkge_session* s, const int32_t* ids, int32_t n);
 int amdkge_session_score(amdkge_session* s, const int32_t* triples, int64_t n, float* scores_out);
 /* Ranks of n test triples.  Filters: CSR over the test triples, fs_off / fo_off host int64 [n + 1] into fs_ids / fo_ids
  * (true subjects / objects of each triple; NULL offsets = unfiltered side).  ent_subset: NULL or n_subset entity ids

@@ -55,6 +55,10 @@ def test_session_train_score_rank_against_oracle(gpu_lib, model, k, opt):
     ref = O.evaluate_ranks(model, e, r, T, fs, fo, "s,o", "worst", max_rel_size=R)
     got = s.rank(T, _csr(fs), _csr(fo), corrupt_side="s,o")
     assert got.shape == (40, 2) and (np.abs(got - ref) <= 1).mean() > 0.97
+    if model != "RotatE":   # identical to the oracle's declared-order fp32 mode (RotatE: hardware cos / sin / sqrt)
+        from oracle import rank_ordered as RO
+
+        assert np.array_equal(got, RO.evaluate_ranks(model, e, r, T, fs, fo, "s,o", "worst", max_rel_size=R))
     both = s.rank(T, _csr(fs), _csr(fo), corrupt_side="s+o")
     assert both.shape == (40, 1) and np.array_equal(both[:, 0], got[:, 0] + got[:, 1] - 1)
     assert np.array_equal(s.rank(T, None, _csr(fo), corrupt_side="o")[:, 0], got[:, 1])
@@ -67,3 +71,39 @@ def test_session_train_score_rank_against_oracle(gpu_lib, model, k, opt):
     assert rs.max() <= len(sub) + 1 and rs.min() >= 1 and (np.abs(rs - ref_sub) <= 1).mean() > 0.97
     s.close()
     s.close()   # idempotent
+
+
+def test_session_deterministic_and_hot_rows(gpu_lib):
+    """cfg.flags = AMDKGE_TILED_DETERMINISTIC: two sessions fed the same steps hold bitwise equal tables; hot rows declared on a
+    session give the same step as the default path up to fp32 summation order."""
+    from ampligraph_amd.latent_features import loss_functions, optimizers
+    from ampligraph_amd.session import Session
+
+    rng = np.random.default_rng(3)
+    N, R, k, B, eta = 120, 3, 10, 600, 4
+    ent = (rng.normal(size=(N, 2 * k)) * 0.3).astype(np.float32)
+    rel = (rng.normal(size=(R, 2 * k)) * 0.3).astype(np.float32)
+    X = np.stack([rng.integers(0, N, 3 * B), rng.integers(0, R, 3 * B), rng.integers(0, N, 3 * B)], 1).astype(np.int32)
+    X[::2, 0] = 5                                   # one hub entity
+    outs = {}
+    for name, kw, hot in (("det1", dict(deterministic=True), None), ("det2", dict(deterministic=True), None), ("plain", {}, None),
+                          ("hot", {}, [5, 7])):
+        s = Session("ComplEx", k, N, R, eta, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}), seed=1, **kw)
+        s.set_rows("ent", ent)
+        s.set_rows("rel", rel)
+        if hot:
+            s.set_hot_rows(hot)
+        losses = [s.train_step(X[t * B:(t + 1) * B]) for t in range(3)]
+        outs[name] = (s.get_rows("ent"), s.get_rows("rel"), s.get_rows("ent_slot1"), losses)
+        s.close()
+    for a, b in zip(outs["det1"][:3], outs["det2"][:3]):
+        assert np.array_equal(a, b)
+    for other in ("plain", "hot"):
+        assert np.allclose(outs[other][3], outs["det1"][3], rtol=1e-6)
+        assert np.mean(np.abs(outs[other][0] - outs["det1"][0]) <= 1e-5 + 1e-3 * np.abs(outs["det1"][0])) > 0.97
+    with pytest.raises(Exception):
+        s = Session("ComplEx", k, N, R, eta, loss_functions.get("nll"), optimizers.get("adam"))
+        try:
+            s.set_hot_rows([N + 3])
+        finally:
+            s.close()
