@@ -48,32 +48,50 @@ __device__ __forceinline__ int64_t route_id_at(const RouteArgs& a, int64_t t) {
     return a.negs[3 * (t >> 1) + ((t & 1) ? 2 : 0)];
 }
 
-// pass 1: first writer of a remote id claims a request slot at its owner
+// pass 1: first writer of a remote id claims a request slot at its owner.  Slots are handed out per WAVE: with two ranks every
+// remote id has the same owner, and one returning atomic per id on that owner's counter serialised at the L2 (measured 92 us
+// for the 16 384 ids of a C4 step); a wave now counts its claims per owner with a ballot and its first lane takes them all.
 __global__ __launch_bounds__(256) void route_insert_kernel(RouteArgs a) {
     const int64_t n = 2 * (a.b + a.nneg);
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t id = route_id_at(a, t);
-        if (id >= a.lo && id < a.hi) continue;
-        uint32_t h = hash_id((uint32_t)id) & a.hmask;
-        const int32_t key = (int32_t)id + 1;
-        for (;;) {
-            const int32_t prev = atomicCAS(a.hkey + h, 0, key);
-            if (prev == 0) {   // claimed: allocate the request slot
-                const int owner = (int)(id / a.rows_per);
-                const int pos = atomicAdd(a.counts + owner, 1);
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x; t0 < n; t0 += stride) {   // (wave-uniform trip count: ballots below)
+        const int64_t t = t0 + threadIdx.x;
+        int64_t id = -1;
+        bool claimed = false;
+        uint32_t h = 0;
+        if (t < n) {
+            id = route_id_at(a, t);
+            if (id < a.lo || id >= a.hi) {
+                h = hash_id((uint32_t)id) & a.hmask;
+                const int32_t key = (int32_t)id + 1;
+                for (;;) {
+                    const int32_t prev = atomicCAS(a.hkey + h, 0, key);
+                    if (prev == 0) { claimed = true; break; }
+                    if (prev == key) break;   // somebody else owns the entry
+                    h = (h + 1) & a.hmask;
+                }
+            }
+        }
+        const int owner = claimed ? (int)(id / a.rows_per) : -1;
+        for (int q = 0; q < a.world; ++q) {
+            const unsigned long long m = __ballot(owner == q);
+            if (!m) continue;
+            int base = 0;
+            if (lane == __builtin_ctzll(m)) base = atomicAdd(a.counts + q, __popcll(m));
+            base = __shfl(base, __builtin_ctzll(m), 64);
+            if (owner == q) {
+                const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
                 int slot;
                 if (pos < a.cap) {
-                    slot = owner * a.cap + pos;
-                    a.send_ids[slot] = (int32_t)(id - (int64_t)owner * a.rows_per);
+                    slot = q * a.cap + pos;
+                    a.send_ids[slot] = (int32_t)(id - (int64_t)q * a.rows_per);
                 } else {       // this peer's list is full: flag it (the host raises), keep indices in range
                     atomicExch(a.counts + a.world, 1);
-                    slot = owner * a.cap;
+                    slot = q * a.cap;
                 }
                 a.hval[h] = slot;
-                break;
             }
-            if (prev == key) break;   // somebody else owns the entry
-            h = (h + 1) & a.hmask;
         }
     }
 }
