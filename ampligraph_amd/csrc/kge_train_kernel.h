@@ -47,6 +47,8 @@ constexpr int HOT_REPL = 16;
 struct TrainArgs {
     const float* ent;
     const float* rel;
+    const float* rel_cs;     // RotatE, owner-computes path: [R][cos(phase) || sin(phase)] of this step's relation table (rel_phase_kernel);
+                             // NULL: the kernel evaluates cos / sin itself (prep_rel)
     const int32_t* triples;
     const int32_t* neg_override;
     float* g_ent;
@@ -433,7 +435,11 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 
     // ---- resident quads of s, p, o ------------------------------------------------------------
     const float* rs = a.ent + (int64_t)ps * a.K;
-    const float* rp = a.rel + (int64_t)pp * a.K;
+    // RotatE with the per-step phase table: the relation "row" is (cos, sin) as rel_phase_kernel computed them with the same
+    // prep_rel -- one sincos per relation unit and step instead of one per positive and unit (libm range reduction: ~20 % of
+    // the forward kernel's VALU work at k = 200)
+    const bool rel_is_cs = (MODEL == AMDKGE_ROTATE) && a.rel_cs != nullptr;
+    const float* rp = (rel_is_cs ? a.rel_cs : a.rel) + (int64_t)pp * a.K;
     const float* ro = a.ent + (int64_t)po * a.K;
     float s[CH][VEC][NC], p[CH][VEC][NC], o[CH][VEC][NC];
     bool qok[CH];
@@ -453,8 +459,10 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 s[c][u][h] = vs.v[u]; p[c][u][h] = vp.v[u]; o[c][u][h] = vo.v[u];
             }
         }
+        if (!rel_is_cs) {
 #pragma unroll
-        for (int u = 0; u < VEC; ++u) prep_rel<MODEL>(a.mc, p[c][u]);
+            for (int u = 0; u < VEC; ++u) prep_rel<MODEL>(a.mc, p[c][u]);
+        }
     }
     // RotatE on a padded row layout: 1 for the zero-padding units behind k_live (see grad_unit); folds away elsewhere
     float pad1[CH][VEC];
@@ -657,8 +665,10 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
                 for (int u = 0; u < VEC; ++u) { s[c][u][h] = vs.v[u]; p[c][u][h] = vp.v[u]; o[c][u][h] = vo.v[u]; }
             }
+            if (!rel_is_cs) {
 #pragma unroll
-            for (int u = 0; u < VEC; ++u) prep_rel<MODEL>(a.mc, p[c][u]);
+                for (int u = 0; u < VEC; ++u) prep_rel<MODEL>(a.mc, p[c][u]);
+            }
         }
     }
     for (int j0 = -1; j0 < (ONEPASS ? -1 : eta); j0 += PF) {

@@ -725,6 +725,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     f.mc = model_const(m); f.loss = *loss;
     const bool hot = (flags & AMDKGE_TILED_HOT_ROWS) && !det && !(flags & AMDKGE_TILED_POS_ATOMIC);
     f.hot_map = hot ? (const uint8_t*)(w + p.off_hot_map) : nullptr; f.hot_buf = (float*)(w + p.off_hot_buf);
+    f.rel_cs = (m->scoring_type == AMDKGE_ROTATE && B > 0) ? rel_cs : nullptr;   // filled by rel_phase_kernel below, before F
     f.touched = touched; f.ns = p.ns; f.det = det ? 1 : 0;
     f.loss_parts = (double*)(w + p.off_loss);
     f.stage_rows = stage_rows; f.st_lists = lists; f.st_ovf = ovf; f.st_counters = counters;
