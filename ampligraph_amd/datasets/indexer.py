@@ -93,6 +93,22 @@ class DataIndexer:
             return out[ok]
         return raw[X.reshape(-1).astype(np.int64)]
 
+    def get_invalid_keys(self, X, data_type="raw", **kwargs):
+        """(invalid subjects, invalid predicates, invalid objects) among the triples X -- data_indexer.py:551-610: raw labels
+        unknown to the maps (data_type="raw") or indexes outside them (data_type="ind"), in order of appearance."""
+        X = np.asarray(X)
+        if data_type == "raw":
+            bad = [~self._lookup(k, i, X[:, c])[1] for c, (k, i) in ((0, (self._ent_sorted, self._ent_ids)),
+                                                                  (1, (self._rel_sorted, self._rel_ids)),
+                                                                  (2, (self._ent_sorted, self._ent_ids)))]
+        elif data_type == "ind":
+            Xi = X.astype(np.int64)
+            ne, nr = self.get_entities_count(), self.get_relations_count()
+            bad = [(Xi[:, 0] < 0) | (Xi[:, 0] >= ne), (Xi[:, 1] < 0) | (Xi[:, 1] >= nr), (Xi[:, 2] < 0) | (Xi[:, 2] >= ne)]
+        else:
+            raise Exception("No such order available options: ind, raw, instead got {}.".format(data_type))
+        return X[bad[0], 0], X[bad[1], 1], X[bad[2], 2]
+
     def valid_row_mask(self, X):
         """Rows of raw triples whose three keys are all known (the rows get_indexes keeps)."""
         X = np.asarray(X)

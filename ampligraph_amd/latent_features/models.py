@@ -86,6 +86,27 @@ class ScoringBasedEmbeddingModel:
         self._dist_override = None   # tests: an object with the torch.distributed collective surface
         self._full_ent = None        # row-sharded mode: cached gathered entity table
 
+    # ------------------------------------------------------------------------------------ config (:56-98)
+    @classmethod
+    def from_config(cls, config):
+        return cls(**config)
+
+    def get_config(self):
+        """The constructor arguments, like the reference's Keras config (:84-98)."""
+        return {"eta": self.eta, "k": self.k, "scoring_type": self.scoring_type, "seed": self.seed,
+                "max_ent_size": self.max_ent_size, "max_rel_size": self.max_rel_size}
+
+    def get_invalid_keys(self, X, data_type="raw", **kwargs):
+        """:2279-2306 -- subjects / predicates / objects of X that the model's id maps do not know."""
+        return self.data_indexer.get_invalid_keys(X, data_type, **kwargs)
+
+    def save(self, filepath, **kwargs):
+        """Keras' model.save(filepath) in the reference (SavedModel directory + metadata, :1002-1044): here the same directory
+        form written by ampligraph_amd.utils.save_model (flat .npz / .json)."""
+        from ..utils.model_utils import save_model
+
+        save_model(self, filepath)
+
     # ------------------------------------------------------------------------------------ compile
     def compile(self, optimizer="adam", loss=None, entity_relation_initializer="glorot_uniform",
                 entity_relation_regularizer=None, **kwargs):
@@ -716,7 +737,9 @@ class ScoringBasedEmbeddingModel:
                 "optimizer": self.optimizer.get_config() if self.is_compiled else None,
                 "iterations": self.optimizer.iterations if self.is_compiled else 0,
                 "loss": {"name": self.loss.name, "params": self.loss._loss_parameters} if self.is_compiled else None,
-                "calibration": self.calibration_parameters if self.is_calibrated else None}
+                "calibration": self.calibration_parameters if self.is_calibrated else None,
+                "regularizer": ([None if r is None else {"p": r.p, "lambda": r.lam} for r in self._regularizers]
+                                if self.is_compiled else None)}
         with open(filepath + ".json.tmp", "w") as f:
             json.dump(meta, f)
         os.replace(filepath + ".json.tmp", filepath + ".json")

@@ -4,6 +4,8 @@ rule and the dense sweep runs in HIP (ampligraph_amd/csrc/kge_opt.hip).  Support
 the Keras legacy namespace (:57-67): adam, adagrad, sgd (+ momentum / nesterov), rmsprop (+ momentum), adadelta, adamax, with
 Keras legacy defaults (epsilon 1e-7, Adagrad accumulator 0.1, rho 0.9 / 0.95).  Not supported (three state tensors per table
 or scalar schedules): amsgrad, centered RMSprop, Nadam, Ftrl -- rejected with ValueError."""
+import numpy as np
+
 from .. import _ffi
 
 
@@ -32,6 +34,62 @@ class OptimizerWrapper:
         # touched-rows mode: an opt-in that deviates from the reference's dense optimizer (optimizers.py:136-168), see
         # amdkge_opt.lazy in include/amdkge.h; set by compile(optimizer_mode="lazy") or OptimizerWrapper(lazy=True)
         self.lazy = bool(lazy)
+        self.num_optimized_vars = 2          # entity and relation tables (optimizers.py:112)
+        self.is_partitioned_training = False
+        self._engine = None                   # bound by the step loop: where the state tensors live (HBM)
+
+    # ---- state access with the reference's names and ordering (optimizers.py:133,177-239): Keras' optimizer.get_weights() is
+    # [iterations, slot0(ent), slot0(rel), slot1(ent), slot1(rel)]; here the state tensors are the engine's optimizer slots
+    def set_partitioned_training(self, value=True):
+        self.is_partitioned_training = value
+
+    def bind(self, engine):
+        self._engine = engine
+
+    def get_hyperparam_count(self):
+        """Number of state tensors per optimized variable (Adam: m and v -> 2; optimizers.py:177-182)."""
+        return len(_ffi.OPT_SLOTS[self.name])
+
+    def get_iterations(self):
+        return int(self.iterations)
+
+    def get_weights(self):
+        """[iterations, then per state tensor: entity part, relation part] as dense numpy arrays."""
+        out = [np.int64(self.iterations)]
+        eng = self._engine
+        if eng is None or not getattr(eng, "slots", None):
+            return out
+        for nme in _ffi.OPT_SLOTS[self.name]:
+            for tab in ("e", "r"):
+                t = eng.slots[f"{nme}_{tab}"]
+                out.append(eng.unpack(t).cpu().numpy() if hasattr(eng, "unpack") else np.array(t))
+        return out
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        names = _ffi.OPT_SLOTS[self.name]
+        if len(weights) != 1 + 2 * len(names):
+            raise ValueError(f"expected {1 + 2 * len(names)} arrays (iterations + {len(names)} state tensors x entity / relation)")
+        self.iterations = int(weights[0])
+        eng = self._engine
+        i = 1
+        for nme in names:
+            for tab in ("e", "r"):
+                if eng is None:
+                    raise RuntimeError("optimizer is not bound to an engine yet (no training step has been set up)")
+                eng.pack(np.asarray(weights[i], dtype=np.float32), out=eng.slots[f"{nme}_{tab}"])
+                i += 1
+
+    def get_entity_relation_hyperparams(self):
+        """(entity-table state tensors, relation-table state tensors), optimizers.py:184-201."""
+        w = self.get_weights()
+        return [w[i] for i in range(1, len(w), 2)], [w[i + 1] for i in range(1, len(w), 2)]
+
+    def set_entity_relation_hyperparams(self, ent_hyperparams, rel_hyperparams):
+        w = self.get_weights()
+        for j, i in enumerate(range(1, len(w), 2)):
+            w[i], w[i + 1] = ent_hyperparams[j], rel_hyperparams[j]
+        self.set_weights(w)
 
     def to_ffi(self, iteration, reg_p=2):
         b1, b2 = self.beta_1, self.beta_2

@@ -141,6 +141,8 @@ class ShardedStepLoop:
 
         self.deterministic = os.environ.get("AMDKGE_DETERMINISTIC", "0") == "1"   # see trainer.StepLoop
         engine.prepare_training(optimizer.name)
+        if hasattr(optimizer, "bind"):
+            optimizer.bind(engine)   # get_weights() / set_weights() of the wrapper read and write the engine's state tensors
 
     @staticmethod
     def peer_capacity(batch_per_rank, eta, negatives, world=1, n_ents=None):

@@ -118,6 +118,8 @@ class StepLoop:
         self.deterministic = os.environ.get("AMDKGE_DETERMINISTIC", "0") == "1"
         self.kernel_hook = None   # bench.py: callable(i) recording HIP events at the phase boundaries (PHASES)
         engine.prepare_training(optimizer.name)
+        if hasattr(optimizer, "bind"):
+            optimizer.bind(engine)   # get_weights() / set_weights() of the wrapper read and write the engine's state tensors
         if self.merge == "sharded" and self.world > 1 and int(engine.g_flat.numel()) % self.world != 0:
             self.merge = "allreduce"   # the flat buffers split evenly over 1, 2, 4, 8, 16 ranks; other counts all-reduce
 

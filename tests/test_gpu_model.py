@@ -775,3 +775,64 @@ def test_dp_fit_with_measured_merge_schedule(gpu_lib, monkeypatch):
 
     a, b = ThreadedWorld(2).run(body)
     assert a == b
+
+
+def test_optimizer_wrapper_state_access(gpu_lib):
+    """The reference's structural optimizer tests (tests/ampligraph/latent_features/test_optimizers.py:16-84): weights list =
+    iterations + state tensors x (entity, relation), get/set round trip, iteration count, entity / relation accessors."""
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers
+
+    X = toy_graph(7)
+    for name, n_state in (("adam", 2), ("adagrad", 1), ("sgd", 0)):
+        opt = optimizers.get(name)
+        opt.set_partitioned_training()
+        m = ScoringBasedEmbeddingModel(eta=2, k=5, scoring_type="DistMult", seed=0)
+        m.compile(optimizer=opt, loss="nll")
+        m.fit(X[:100], batch_size=100, epochs=1, verbose=False)
+        w = opt.get_weights()
+        assert len(w) == 1 + opt.get_hyperparam_count() * opt.num_optimized_vars and opt.get_hyperparam_count() == n_state
+        assert opt.get_iterations() == 1
+        opt.set_weights(w)
+        assert all(np.all(a == b) for a, b in zip(w, opt.get_weights()))
+        ent_h, rel_h = opt.get_entity_relation_hyperparams()
+        assert len(ent_h) == len(rel_h) == n_state
+        if n_state == 2:
+            assert (w[1] == ent_h[0]).all() and (w[3] == ent_h[1]).all() and (w[2] == rel_h[0]).all() and (w[4] == rel_h[1]).all()
+            assert w[1].shape == (m._n_ents, 5) and w[2].shape == (m._n_rels, 5) and np.abs(w[1]).max() > 0
+            opt.set_entity_relation_hyperparams([np.zeros_like(ent_h[0]), ent_h[1]], rel_h)
+            assert np.abs(opt.get_weights()[1]).max() == 0 and (opt.get_weights()[3] == w[3]).all()
+
+
+def test_save_model_restore_model_roundtrip(gpu_lib, tmp_path):
+    """ampligraph.utils.save_model / restore_model (utils/model_utils.py:29-129) on the engine's own format: same predictions
+    and ranks after the round trip, optimizer state and regulariser restored (continued training == uninterrupted), config."""
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers, regularizers
+    from ampligraph_amd.utils import restore_model, save_model
+
+    X = toy_graph(9, n=600)
+
+    def make():
+        m = ScoringBasedEmbeddingModel(eta=3, k=6, scoring_type="ComplEx", seed=2)
+        m.compile(optimizer=optimizers.get("adam", {"learning_rate": 1e-2}), loss="self_adversarial",
+                  entity_relation_regularizer=regularizers.get("LP", {"p": 3, "lambda": 1e-3}))
+        return m
+
+    full = make()
+    h_full = full.fit(X, batch_size=200, epochs=4, verbose=False)
+    m = make()
+    m.fit(X, batch_size=200, epochs=2, verbose=False)
+    path = str(tmp_path / "saved_model")
+    save_model(m, path)
+    save_model(m, path)                       # an existing path is overwritten
+    m.save(str(tmp_path / "saved_via_method"))
+    r = restore_model(path)
+    assert r.get_config() == m.get_config() and ScoringBasedEmbeddingModel.from_config(m.get_config()).k == 6
+    assert np.array_equal(r.predict(X[:50]), m.predict(X[:50]))
+    assert np.array_equal(r.evaluate(X[:40], use_filter={"train": X}, verbose=False), m.evaluate(X[:40], use_filter={"train": X}, verbose=False))
+    assert r.optimizer.iterations == m.optimizer.iterations and r._regularizers[0].p == 3
+    h = r.fit(X, batch_size=200, epochs=4, initial_epoch=2, verbose=False)
+    assert np.allclose(h.history["loss"], h_full.history["loss"][2:], rtol=1e-4)
+    s, p, o = r.get_invalid_keys(np.array([["e1", "r0", "nope"], ["zzz", "r9", "e2"]]))
+    assert list(s) == ["zzz"] and list(p) == ["r9"] and list(o) == ["nope"]
+    with pytest.raises(FileNotFoundError):
+        restore_model(str(tmp_path / "missing"))

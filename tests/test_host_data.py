@@ -199,3 +199,24 @@ def test_select_best_model_ranking_with_a_stub_model():
     # nothing trainable: NaN metrics, no model
     none = select_best_model_ranking("ComplEx", Xtr, Xva, Xte, {"k": 13}, _model_factory=Stub)
     assert none[0] is None and np.isnan(none[4]["mrr"]) and len(none[5]) == 1
+
+
+def test_get_invalid_keys_docstring_example():
+    """data_indexer.py:563-565 (the reference's docstring KAT) and the index form."""
+    import numpy as np
+
+    from ampligraph_amd.datasets.indexer import DataIndexer
+
+    train = np.array([["subj_a", "rel_a", "obj_b"], ["subj_c", "rel_b", "obj_c"], ["subj_a", "rel_b", "subj_c"]])
+    ix = DataIndexer(train)
+    X = np.array([["subj_a", "foo", "subj_c"], ["rel_a", "rel_b", "bar"], ["baz", "obj_b", "obj_c"]])
+    s, p, o = ix.get_invalid_keys(X, data_type="raw")
+    # ("rel_a" is no entity and "obj_b" no relation either: the reference's docstring lists only the obviously foreign keys)
+    assert list(s) == ["rel_a", "baz"] and list(p) == ["foo", "obj_b"] and list(o) == ["bar"]
+    Xi = np.array([[0, 0, 1], [99, 1, 2], [1, 7, -1]])
+    s, p, o = ix.get_invalid_keys(Xi, data_type="ind")
+    assert list(s) == [99] and list(p) == [7] and list(o) == [-1]
+    import pytest
+
+    with pytest.raises(Exception):
+        ix.get_invalid_keys(X, data_type="nope")
