@@ -211,10 +211,9 @@ extern "C" int amdkge_session_train_step(amdkge_session* s, const int32_t* tripl
         int32_t step_flags = s->cfg.flags;
         if (s->hot_dirty) {
             void* d_hot;
-            KGE_RC(upload(s, 1, s->hot_ids.data(), (int64_t)(s->hot_ids.size() * sizeof(int32_t)), &d_hot));
+            KGE_RC(upload(s, 6, s->hot_ids.data(), (int64_t)(s->hot_ids.size() * sizeof(int32_t)), &d_hot));   // (scratch slot of its own)
             KGE_RC(amdkge_train_tiled_set_hot_rows(m, s->twork, (const int32_t*)d_hot, (int32_t)s->hot_ids.size(), s->st));
             s->hot_dirty = false;
-            if (focus_w) { KGE_RC(upload(s, 1, focus_w, B * (int64_t)sizeof(float), &d_fw)); loss.d_focus_w = (const float*)d_fw; }   // slot 1 was reused
         }
         if (!s->hot_ids.empty()) step_flags |= AMDKGE_TILED_HOT_ROWS;
         const int rc = amdkge_train_step_tiled(m, &loss, &opt, s->tab[0], s->tab[1], s->tab[2], s->tab[3], s->tab[4], s->tab[5],
