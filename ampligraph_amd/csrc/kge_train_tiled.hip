@@ -164,7 +164,6 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         for (int r = grp + G * lane; r < nrow; r += G * 64)
             tflag[r * gw + wg] = (a.touched && row_ok(r) && a.touched[row_of(r)]) ? 1 : 0;
 
-    // side-row loads of one staged entry.  All arguments are wave-uniform.
     // Operand loads of one staged entry (all arguments wave-uniform): the staged side row and, for TransE / RotatE
     // corruption entries, the relation row (RotatE: its cos / sin from the per-step table) and the tile's own live row.
     // Kept apart from the arithmetic so that the loads of UNROLL entries are in flight together.
@@ -590,12 +589,12 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     p.off_loss = o; o += up((size_t)LOSS_PARTS * LOSS_PART_STRIDE * 8);   // first: the same place in every plan (kept zero between steps)
     p.off_hot_map = o; o += up((size_t)m->n_ents);                        // hot-row map and replicas: also independent of B / eta / mode,
     p.off_hot_buf = o; o += up((size_t)HOT_MAX * HOT_REPL * K * 4);       // written by amdkge_train_tiled_set_hot_rows
+    p.off_touch = o; o += up((size_t)m->n_ents);                          // byte per entity row (lazy optimizer + POS_ATOMIC), kept zero between steps
     p.off_cnt = o; o += up((size_t)(p.n_tiles + 3) * 32 * 4);   // bucket fills, overflow count, finished-tiles ticket, det-sort overflow flag
     p.off_lists = o; o += up((size_t)p.n_tiles * p.cap * sizeof(StageEntry));
     p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
     p.off_rows = o; o += up((size_t)B * p.ns * K * 4);
     p.off_cs = o; o += up(m->scoring_type == AMDKGE_ROTATE ? (size_t)m->n_rels * K * 4 : 0);
-    p.off_touch = o; o += up((size_t)m->n_ents);   // byte per entity row (lazy optimizer + POS_ATOMIC), kept zero between steps
     p.total = o + 256;
     return true;
 }
