@@ -237,9 +237,12 @@ __device__ __forceinline__ float fast_exp(float x) {
 // sigma(y) and log sigma(-y) = -softplus(y) from one exponential
 __device__ __forceinline__ void fast_sig_logsig(float y, float& sig, float& logsig_neg) {
     const float t = fast_exp(-fabsf(y));
-    const float r = __builtin_amdgcn_rcpf(1.f + t);
+    const float u = 1.f + t;
+    const float r = __builtin_amdgcn_rcpf(u);
     sig = (y >= 0.f) ? r : t * r;
-    logsig_neg = fminf(-y, 0.f) - __builtin_amdgcn_logf(1.f + t) * 0.6931471805599453f;
+    // log1p(t) = log(u) + (t - (u - 1)) / u: the second term restores what the rounding of 1 + t dropped (for t < 6e-8 it is
+    // all of t; TransE scores of -20 and below live there, and their dL/dscore is exactly these tails)
+    logsig_neg = fminf(-y, 0.f) - (__builtin_amdgcn_logf(u) * 0.6931471805599453f + (t - (u - 1.f)) * r);
 }
 
 // Coefficients of up to 64 rows at once: lane f holds the score n of one row (valid == false: no row).  Returns the
@@ -380,6 +383,9 @@ __device__ __forceinline__ void slot_sync() {
 // (Forcing 4 waves/SIMD with __launch_bounds__(256, 4) was measured: no gain over the natural 3 -- the row gather is
 // bound by fabric bandwidth, not by loads in flight -- and it costs spills.)
 template <int MODEL, int VEC, int W, int CH, bool STAGE = false>
+#ifdef KGE_F_WAVES   // development builds: force an occupancy
+__attribute__((amdgpu_waves_per_eu(KGE_F_WAVES, KGE_F_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     using T = ModelTraits<MODEL>;
     constexpr int NC = T::NC;
@@ -526,10 +532,9 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     };
 
     // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
-    constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
-    // (folding TransE into the single-pass framework -- accumulate c_j sign(d_j) while the rows stream by -- was built and
-    // measured: no faster at k = 200, slower at k = 350 (register pressure); the sign stash below is what stayed)
-    constexpr bool SIGNSTASH = (MODEL == AMDKGE_TRANSE) && (STAGE || VEC == 4);   // (the scalar-load geometries keep the two-pass form)
+    constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX || MODEL == AMDKGE_TRANSE);
+    // TransE outside the single-pass geometry (rows shared by four waves, atomic path): signs stashed by the scoring pass
+    constexpr bool SIGNSTASH = (MODEL == AMDKGE_TRANSE) && !ONEPASS && (STAGE || VEC == 4);   // (the scalar-load geometries keep the two-pass form)
     unsigned char* sh_sign = reinterpret_cast<unsigned char*>(smem) + a.sign_off;
     float av1[2][CH][VEC][NC], av2[2][CH][VEC][NC];   // [0]: sum c_j e_j over object-replaced rows, [1]: subject-replaced
     OnePassState ops{-INFINITY, 0.f, 0.f, 0.f};
@@ -538,7 +543,13 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         // (score(s,p,e) = <A, e>, score(e,p,o) = <B, e>: the query-vector form the reference itself uses for
         // corruption scores, ComplEx.py:93-107,138-150), and sum_j c_j e_j accumulated while the rows stream by.
         // s, p, o are dead inside the loop (reloaded afterwards): the loop lives on A, B, PF rows and 4 accumulators.
+        //
+        // TransE (score = -sum |d|, d = s + p - o): d(score)/d(s, p, o) = -/+ sign(d_j), so what must be accumulated per
+        // side is sum_j c_j sign(d_j) -- the coefficient with the sign bit of d_j xor-ed in (one v_bitop3 per unit), no
+        // second pass and no stash.  sign(0) = 0 is kept exact: a group of rows with an exact zero in a live unit (a
+        // wave-uniform test on compare masks) takes the select form instead.
         float qa[CH][VEC][NC], qb[CH][VEC][NC];
+        unsigned long long live_m[CH][VEC];   // TransE: lanes whose unit u of quad c is a unit of the model (not row padding)
         float part = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -546,7 +557,12 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
             for (int u = 0; u < VEC; ++u) {
                 float ds[NC], dp[NC], dd[NC];
-                grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], 1.f, ds, dp, dd);
+                if constexpr (MODEL == AMDKGE_TRANSE) {
+                    ds[0] = 0.f; dd[0] = s[c][u][0] + p[c][u][0];   // the reference's first rounding of (s + p) - e, TransE.py:51-53
+                    live_m[c][u] = __ballot(qok[c] && qoff[c] + u < a.k_live);
+                } else {
+                    grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], 1.f, ds, dp, dd);
+                }
 #pragma unroll
                 for (int h = 0; h < NC; ++h) {
                     qa[c][u][h] = dd[h]; qb[c][u][h] = ds[h];
@@ -590,20 +606,32 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
                 for (int f = 0; f < PF; ++f) {
                     jv[f] = __builtin_amdgcn_readfirstlane(sh_perm[min(p0 + f, p_end - 1)]);   // past the end: reload the last row
-                    load_row(a.ent + (int64_t)__builtin_amdgcn_readfirstlane(sh_repl[jv[f]]) * a.K, e[f]);
+                    load_row(a.ent + (int64_t)(KGE_DBG(a, 8) ? ps : __builtin_amdgcn_readfirstlane(sh_repl[jv[f]])) * a.K, e[f]);   // (ablation 8: cache-hot row)
                 }
                 float nv = 0.f;   // lane f: score of row p0 + f
                 int jl = 0;       // lane f: its corruption index
+                unsigned long long zero_m = 0ull;   // TransE: lanes holding an exact zero of d in a live unit of this group
 #pragma unroll
                 for (int f = 0; f < PF; ++f) {
                     float acc = 0.f;
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
                         float t = 0.f;
+                        if constexpr (MODEL == AMDKGE_TRANSE) {
 #pragma unroll
-                        for (int u = 0; u < VEC; ++u)
+                            for (int u = 0; u < VEC; ++u) {
+                                // d of the corrupted triple in the reference's operation order; kept in place of the row
+                                const float dj = (d == 0) ? (qa[c][u][0] - e[f][c][u][0]) : ((e[f][c][u][0] + p[c][u][0]) - o[c][u][0]);
+                                e[f][c][u][0] = dj;
+                                t += fabsf(dj);
+                                zero_m |= __ballot(dj == 0.f) & live_m[c][u];
+                            }
+                        } else {
 #pragma unroll
-                            for (int h = 0; h < NC; ++h) t = fmaf(d == 0 ? qa[c][u][h] : qb[c][u][h], e[f][c][u][h], t);
+                            for (int u = 0; u < VEC; ++u)
+#pragma unroll
+                                for (int h = 0; h < NC; ++h) t = fmaf(d == 0 ? qa[c][u][h] : qb[c][u][h], e[f][c][u][h], t);
+                        }
                         acc += qok[c] ? t : 0.f;
                     }
                     const float n = sgn_scale * wave_sum(acc);
@@ -636,6 +664,30 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                     // rows past the end had invalid lanes: their coefficients are 0 and add nothing
                     const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1l), f));
                     const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2l), f));
+                    if constexpr (MODEL == AMDKGE_TRANSE) {
+                        if (zero_m == 0ull) {   // c * sign(d) for d != 0: the coefficient with d's sign bit xor-ed in
+#pragma unroll
+                            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                                for (int u = 0; u < VEC; ++u) {
+                                    // (d & sign bit) ^ c in one v_bitop3_b32 (truth table 0x6a = (a & b) ^ c)
+                                    const unsigned db = __float_as_uint(e[f][c][u][0]);
+                                    av1[d][c][u][0] += __uint_as_float(__builtin_amdgcn_bitop3_b32(db, 0x80000000u, __float_as_uint(c1), 0x6a));
+                                    if (two) av2[d][c][u][0] += __uint_as_float(__builtin_amdgcn_bitop3_b32(db, 0x80000000u, __float_as_uint(c2), 0x6a));
+                                }
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                                for (int u = 0; u < VEC; ++u) {
+                                    const float dj = e[f][c][u][0];
+                                    const float sg = (dj > 0.f) ? 1.f : ((dj < 0.f) ? -1.f : 0.f);
+                                    av1[d][c][u][0] += c1 * sg;
+                                    if (two) av2[d][c][u][0] += c2 * sg;
+                                }
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -860,6 +912,13 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 for (int h = 0; h < NC; ++h) {
                     eo[h] = k1 * av1[0][c][u][h] + k2 * av2[0][c][u][h];
                     es[h] = k1 * av1[1][c][u][h] + k2 * av2[1][c][u][h];
+                }
+                if constexpr (MODEL == AMDKGE_TRANSE) {
+                    // eo / es = sum_j g'_j sign(d_j) per side (g' includes the score sign); padding units stay zero
+                    const bool lv = qoff[c] + u < a.k_live;
+                    const float Go = lv ? eo[0] : 0.f, Gs = lv ? es[0] : 0.f;
+                    gs[c][u][0] += Go; gp[c][u][0] += Go + Gs; go[c][u][0] -= Gs;
+                    continue;
                 }
                 grad_unit<MODEL>(s[c][u], p[c][u], eo, 1.f, ds, dp, dd);   // corruptions (s, p, e_j)
 #pragma unroll

@@ -89,7 +89,8 @@ struct TileArgs {
     ModelConst mc;
     OptArgs opt;
 #ifdef KGE_ABLATE
-    int dbg;                  // development ablation build only: 256 no own-row loads, 512 no relation-row loads in the tile pass
+    int dbg;                  // development ablation build only: 1024 no flush, 2048 no accumulator zeroing, 4096 no bucket scan
+                              // (per-load switches in the entry loop were tried: they push its operand arrays to scratch)
 #endif
 };
 
@@ -124,8 +125,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     }
     // bucket fill + overflow count are read by every wave up front: the counters are reset behind the
     // workgroup barrier at the end of the kernel (the library keeps them zero between steps)
-    const int cnt = min(a.counters[tile * 32], a.cap);
-    const int on = min(a.counters[a.n_tiles * 32], a.ovf_cap);
+    const int cnt = KGE_DBG(a, 4096) ? 0 : min(a.counters[tile * 32], a.cap);
+    const int on = KGE_DBG(a, 4096) ? 0 : min(a.counters[a.n_tiles * 32], a.ovf_cap);
     // BLOCK-INTERLEAVED ownership: the table is cut into blocks of TILE_RB consecutive rows and block b belongs to tile
     // b % n_tiles (local row r <-> table row row_of_tile(tile, r)).  Real graphs number their hubs first (ids are handed out
     // first-seen), so contiguous row ranges give the first tiles several times the entries of the others and the tile pass is
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         qok[c] = q < a.nq;
         qoff[c] = (qok[c] ? q : 0) * 4;
     }
-    for (int r = grp; r < nrow; r += G)
+    for (int r = grp; r < (KGE_DBG(a, 2048) ? 0 : nrow); r += G)
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                 for (int c = 0; c < CH; ++c)
 #pragma unroll
                     for (int h = 0; h < NC; ++h) {
-                        pv[c][h] = KGE_DBG(a, 512) ? make_float4(.1f, .2f, .3f, .4f) : *reinterpret_cast<const float4*>(rp + qoff[c] + h * a.k);
-                        ev[c][h] = KGE_DBG(a, 256) ? make_float4(.4f, .3f, .2f, .1f) : *reinterpret_cast<const float4*>(re + qoff[c] + h * a.k);
+                        pv[c][h] = *reinterpret_cast<const float4*>(rp + qoff[c] + h * a.k);
+                        ev[c][h] = *reinterpret_cast<const float4*>(re + qoff[c] + h * a.k);
                     }
             }
         }
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     float reg_acc = 0.f;
     auto flush = [&](auto kind_c) {
     constexpr int KIND = decltype(kind_c)::value;
-    for (int r = grp; r < nrow; r += G) {
+    for (int r = grp; r < (KGE_DBG(a, 1024) ? 0 : nrow); r += G) {
         const float* arow = acc + (size_t)r * a.K;
         if (!row_ok(r)) continue;
         const int hot = a.hot_map ? a.hot_map[row_of(r)] : 0;   // a hot row's own-gradient rows wait in its replicas (always "touched")
@@ -618,7 +619,7 @@ static int launch_forward(TrainArgs& f, hipStream_t st) {
     // workgroup when a positive spans the whole workgroup)
     size_t shmem = (size_t)slots * slot_lds_bytes(f.eta, W) + slots * sizeof(double) + (W == 1 ? 4 : 1) * (size_t)f.K * 4;
     f.sign_off = (int)shmem;
-    shmem += sign_stash_bytes(MODEL, f.eta, CHF);
+    if (W != 1) shmem += sign_stash_bytes(MODEL, f.eta, CHF);   // (one wave per positive: TransE takes the single-pass form, no stash)
     if (shmem > 64 * 1024) {
         static bool attr = false;
         if (!attr) {
@@ -627,7 +628,7 @@ static int launch_forward(TrainArgs& f, hipStream_t st) {
             attr = true;
         }
     }
-    const unsigned grid = (unsigned)((f.B + slots - 1) / slots);
+    const unsigned grid = KGE_DBG(f, 8192) ? 0u : (unsigned)((f.B + slots - 1) / slots);   // (ablation 8192: no forward launch)
     if (grid) hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, 4, W, CHF, true>), dim3(grid), dim3(256), shmem, st, f);
     return check_launch("train_forward_stage");
 }
