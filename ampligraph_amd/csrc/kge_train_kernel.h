@@ -10,10 +10,22 @@ namespace kge {
 // one row-gradient contribution, appended by the forward kernel to the bucket of the tile owning row `dest`
 struct __attribute__((aligned(16))) StageEntry {
     uint32_t pos;    // positive (index into this launch's batch)
-    uint32_t meta;   // role | (row - first row of the tile) << 2 ; role 0/1 = corruption with object/subject replaced, 2/3 = the positive's own s/o row
+    uint32_t meta;   // role | local row of the tile << 2 [| corruption index << 16: TransE sign codes, see below];
+                     // role 0/1 = corruption with object/subject replaced, 2/3 = the positive's own s/o row
     float g;         // dL/dscore * score_sign * score_scale (1 for roles 2, 3)
     uint32_t dest;   // global row id
 };
+
+constexpr uint32_t ENTRY_LOCAL_MASK = 0x1FFFu;   // local row (tiles hold at most 4096 rows)
+__host__ __device__ __forceinline__ uint32_t entry_local(uint32_t meta) { return (meta >> 2) & ENTRY_LOCAL_MASK; }
+// TransE sign codes (one wave per positive).  The gradient of -sum |d| w.r.t. the replaced row is -/+ g sign(d_j): all the
+// tile pass needs of corruption j is the SIGN of every unit of d_j = s + p - o, which the forward kernel has in registers when
+// it scores the row.  It stores them -- the top byte of each of the lane's four d values packed into one dword, [B][eta][nq]
+// dwords -- and the tile pass reads 4 bytes per lane and entry instead of recomputing d_j from three K-float rows (staged
+// side copy, relation row, its own row: 2.4 KB per entry at k = 200).  sign(0) = 0 stays exact the slow way: the byte also
+// carries the top 7 exponent bits, and an entry with a unit of the model whose |d| is below 2^-125 (zero, or as good as) is
+// recomputed by the tile pass in the three-row form.
+constexpr int ENTRY_J_SHIFT = 16;                // corruption index (eta <= 65535 when codes are in use)
 
 // Per-block loss partials.  Thousands of blocks adding an fp64 atomic to ONE address serialise at the L2 (measured: 19 of the
 // 46 us of a C1 forward kernel, 5 us at C2); spread over LOSS_PARTS cache lines they do not, and a single thread folds the
@@ -75,6 +87,7 @@ struct TrainArgs {
     const uint8_t* hot_map;  // AMDKGE_TILED_HOT_ROWS: byte per entity row, slot + 1 of a hot row, 0 otherwise (NULL: feature off)
     float* hot_buf;          // [HOT_MAX][HOT_REPL][K]: replicas the gradient rows of hot entities are spread over
     uint8_t* touched;        // pos_atomic + lazy optimizer: byte per entity row, set for rows that received an atomic row-add
+    uint32_t* sign_codes;    // TransE, one wave per positive: [B][eta][nq] packed sign bytes of d_j (see ENTRY_J_SHIFT); NULL = off
     StageEntry* st_lists;    // [n_tiles][cap] buckets of row-gradient entries, by owning tile
     StageEntry* st_ovf;      // overflow of full buckets
     int* st_counters;        // [(n_tiles + 1) * 32] bucket fill counts (128-byte stride), last = overflow count
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     if constexpr (STAGE) {
         // side rows for the owner kernel.  Trilinear models: d(score)/d(replaced row) does not depend on the
         // replaced row, so the owner only needs g * A (A = d/do (s,p)) or g * B (B = d/ds (p,o)).
-        // TransE / RotatE: copies of s and o (the owner recomputes grad_unit with its own row).
+        // TransE: copies of s and o (the owner recomputes grad_unit with its own row); RotatE: s and o rotated onto the replaced row.
         static_assert(!STAGE || VEC == 4, "staging uses the 16-byte layout");
         constexpr bool TRILINEAR = (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
         if (active && !KGE_DBG(a, 64)) {
@@ -496,6 +509,13 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                         grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], 1.f, ds, dp, dd);
 #pragma unroll
                         for (int h = 0; h < NC; ++h) { va[h][u] = dd[h]; vb[h][u] = ds[h]; }
+                    } else if constexpr (MODEL == AMDKGE_ROTATE) {
+                        // A = s o r (the reference's own first step of s o r - e, RotatE.py:100-101: the object-side entries of
+                        // the tile pass are bit-identical to grad_unit), B = o o conj(r): |e o r - o| = |e - B| as |r| = 1, and
+                        // d|e o r - o| / de = (e - B) / |e - B| -- one side row and the tile's own row per entry, no relation row
+                        const float cs = p[c][u][0], sn = p[c][u][1];
+                        va[0][u] = s[c][u][0] * cs - s[c][u][1] * sn; va[1][u] = s[c][u][0] * sn + s[c][u][1] * cs;
+                        vb[0][u] = o[c][u][0] * cs + o[c][u][1] * sn; vb[1][u] = o[c][u][1] * cs - o[c][u][0] * sn;
                     } else {
 #pragma unroll
                         for (int h = 0; h < NC; ++h) { va[h][u] = s[c][u][h]; vb[h][u] = o[c][u][h]; }
@@ -532,8 +552,11 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     };
 
     // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
-    constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX || MODEL == AMDKGE_TRANSE);
-    // TransE outside the single-pass geometry (rows shared by four waves, atomic path): signs stashed by the scoring pass
+    // (TransE: one quad per lane only -- with two, the single pass measured 145 us against the stash form's 81 at k = 352:
+    // register pressure leaves it 2 waves per SIMD)
+    constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX || (MODEL == AMDKGE_TRANSE && CH == 1));
+    // TransE outside the single-pass geometry (two quads per lane, rows shared by four waves, atomic path): signs stashed by the
+    // scoring pass
     constexpr bool SIGNSTASH = (MODEL == AMDKGE_TRANSE) && !ONEPASS && (STAGE || VEC == 4);   // (the scalar-load geometries keep the two-pass form)
     unsigned char* sh_sign = reinterpret_cast<unsigned char*>(smem) + a.sign_off;
     float av1[2][CH][VEC][NC], av2[2][CH][VEC][NC];   // [0]: sum c_j e_j over object-replaced rows, [1]: subject-replaced
@@ -550,6 +573,8 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         // wave-uniform test on compare masks) takes the select form instead.
         float qa[CH][VEC][NC], qb[CH][VEC][NC];
         unsigned long long live_m[CH][VEC];   // TransE: lanes whose unit u of quad c is a unit of the model (not row padding)
+        // this positive's block of the sign codes ([eta][nq] dwords; eta * nq < 2^23, so row offsets are 32-bit)
+        uint32_t* const code_base = a.sign_codes + (int64_t)__builtin_amdgcn_readfirstlane((int)i) * eta * a.nq;
         float part = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -625,6 +650,14 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                                 e[f][c][u][0] = dj;
                                 t += fabsf(dj);
                                 zero_m |= __ballot(dj == 0.f) & live_m[c][u];
+                            }
+                            if (a.sign_codes && active && p0 + f < p_end && qok[c]) {
+                                // top bytes (sign + 7 exponent bits) of the four d values of this lane, one dword: 3 v_perm_b32
+                                const unsigned t01 = __builtin_amdgcn_perm(__float_as_uint(e[f][c][1][0]), __float_as_uint(e[f][c][0][0]), 0x0c0c0703u);
+                                const unsigned t23 = __builtin_amdgcn_perm(__float_as_uint(e[f][c][3][0]), __float_as_uint(e[f][c][2][0]), 0x07030c0cu);
+                                // (wave-uniform row pointer + the lane's quad index: no per-lane address arithmetic)
+                                uint32_t* crow = code_base + (uint32_t)(jv[f] * a.nq);
+                                crow[qoff[c] >> 2] = t01 | t23;
                             }
                         } else {
 #pragma unroll
@@ -744,13 +777,21 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 if constexpr (SIGNSTASH) {
                     // TransE.py:51-53 with the signs of s + p - o kept for the backward pass (same operations as score_unit)
                     unsigned code = 0;
+                    float dv[VEC];
 #pragma unroll
                     for (int u = 0; u < VEC; ++u) {
                         const float d = keepv[f] ? (s[c][u][0] + p[c][u][0] - e[f][c][u][0]) : (e[f][c][u][0] + p[c][u][0] - o[c][u][0]);
+                        dv[u] = d;
                         acc += fabsf(d);
                         code |= ((d > 0.f) ? 1u : ((d < 0.f) ? 2u : 0u)) << (2 * u);
                     }
                     if (j >= 0) sh_sign[((size_t)j * CH + c) * 256 + tid] = (unsigned char)code;
+                    if constexpr (STAGE && VEC == 4) {   // the tile pass's copy of the signs (see ENTRY_J_SHIFT)
+                        if (a.sign_codes && active && j >= 0 && qok[c])
+                            a.sign_codes[((int64_t)i * eta + j) * a.nq + (qoff[c] >> 2)] =
+                                __builtin_amdgcn_perm(__float_as_uint(dv[1]), __float_as_uint(dv[0]), 0x0c0c0703u) |
+                                __builtin_amdgcn_perm(__float_as_uint(dv[3]), __float_as_uint(dv[2]), 0x07030c0cu);
+                    }
                 } else {
 #pragma unroll
                     for (int u = 0; u < VEC; ++u)
@@ -825,13 +866,16 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
             for (int j = ts; j < eta + (a.pos_atomic ? 0 : 2); j += TS) {
                 uint32_t dest, role;
                 float g;
-                if (j < eta) { dest = (uint32_t)sh_repl[j]; role = sh_keep[j] ? 0u : 1u; g = sh_neg[j] * sgn_scale; }
+                if (j < eta) {
+                    dest = (uint32_t)sh_repl[j]; role = sh_keep[j] ? 0u : 1u; g = sh_neg[j] * sgn_scale;
+                    if (a.sign_codes) role |= (uint32_t)j << ENTRY_J_SHIFT;   // (bits above the local row)
+                }
                 else { dest = (uint32_t)(j == eta ? ps : po); role = (j == eta) ? 2u : 3u; g = 1.f; }
                 if (g == 0.f) continue;   // inactive margin / clipped corruption: contributes nothing
                 if (j >= eta && a.hot_map && a.hot_map[dest]) continue;   // hot row: went to its replicas (below), no entry
                 uint32_t tile, local;
                 tile_of_row(dest, (uint32_t)a.st_n_tiles, (uint32_t)a.st_rb, tile, local);   // block-interleaved ownership, see tile_backward_kernel
-                StageEntry en{(uint32_t)i, role | (local << 2), g, dest};
+                StageEntry en{(uint32_t)i, role | (local << 2), g, dest};   // local < 4096: below the corruption index
                 const int slotpos = atomicAdd(a.st_counters + (size_t)tile * 32, 1);
                 if (slotpos < a.st_cap) {
                     a.st_lists[(size_t)tile * a.st_cap + slotpos] = en;

@@ -39,6 +39,22 @@
 #include <type_traits>
 #include "kge_train_kernel.h"
 
+// the lambdas of the tile kernel capture its argument struct by reference: one of them left out of line puts the whole struct
+// (and the operand arrays passed to it) into scratch memory -- measured 6x on the TransE instantiation
+#ifndef KGE_TILE_INLINE
+#define KGE_TILE_INLINE __attribute__((always_inline))
+#endif
+
+// 16-byte operand load of the entry loop, as a VALUE.  Written as plain `x = *reinterpret_cast<const float4*>(p)` the RotatE
+// tile pass measured 130 us instead of 113: assigned through the reference, the compiler orders the loads of a batch against
+// the operand arrays of the previous one (more s_waitcnt, fewer loads in flight).  Found by bisection.
+#ifdef KGE_LD4_FN
+namespace kge { __device__ __forceinline__ float4 ld4_value(const float* p) { return *reinterpret_cast<const float4*>(p); } }
+#define KGE_LD4(p) kge::ld4_value(p)
+#else
+#define KGE_LD4(p) (false ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(p))
+#endif
+
 namespace kge {
 
 constexpr int TILE_THREADS = 1024;
@@ -66,6 +82,8 @@ struct TileArgs {
     const uint8_t* hot_map;   // AMDKGE_TILED_HOT_ROWS (see HOT_MAX in kge_train_kernel.h); NULL = off
     float* hot_buf;
     uint8_t* touched;         // lazy + pos_atomic: rows the forward kernel's atomics touched (read, then cleared here)
+    const uint32_t* sign_codes;   // TransE: [B][eta][nq] packed sign bytes written by the forward kernel (see ENTRY_J_SHIFT in kge_train_kernel.h); NULL = off
+    int eta;
     const float* rel;         // live relation table (TransE / RotatE side of the gradient)
     const float* rel_cs;      // RotatE: [R][cos(phase) || sin(phase)] of this step's relation table (rel_phase_kernel)
     const int32_t* triples;
@@ -136,8 +154,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     const uint32_t NT = (uint32_t)a.n_tiles;
     const int nrow = a.tile_rows;
     const uint32_t RB = (uint32_t)a.rb;
-    auto row_of = [&](int r) -> int64_t { return row_of_tile((uint32_t)tile, (uint32_t)r, NT, RB); };
-    auto row_ok = [&](int r) -> bool { return row_of(r) < a.n_rows; };
+    auto row_of = [&](int r) KGE_TILE_INLINE -> int64_t { return row_of_tile((uint32_t)tile, (uint32_t)r, NT, RB); };
+    auto row_ok = [&](int r) KGE_TILE_INLINE -> bool { return row_of(r) < a.n_rows; };
 
     // Row ownership.  Short rows: wave wv owns local rows r with r % 16 == wv and covers the whole row (CH quads per lane).
     // Long rows (gw > 1): a GROUP of gw waves owns the row and each wave covers its 64-quad slice, so that the few entries
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     // corruption entries, the relation row (RotatE: its cos / sin from the per-step table) and the tile's own live row.
     // Kept apart from the arithmetic so that the loads of UNROLL entries are in flight together.
     constexpr int NX = TRILINEAR ? 1 : NC;   // trilinear models need no relation / own-row operands
-    auto load_ops = [&](uint32_t pos, uint32_t meta, int pp, float4 (&v)[CH][NC], float4 (&pv)[CH][NX], float4 (&ev)[CH][NX]) {
+    auto load_ops = [&](uint32_t pos, uint32_t meta, int pp, float4 (&v)[CH][NC], float4 (&pv)[CH][NX], float4 (&ev)[CH][NX]) KGE_TILE_INLINE {
         const int role = meta & 3;   // 0: corruption, object replaced; 1: corruption, subject replaced; 2: own s row; 3: own o row
         const int which = (role == 0) ? 2 : (role == 1) ? 3 : (role == 2) ? 0 : 1;
         const float* src = a.stage_rows + ((int64_t)pos * a.ns + which) * a.K;
@@ -179,23 +197,24 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             for (int h = 0; h < NC; ++h) v[c][h] = *reinterpret_cast<const float4*>(src + qoff[c] + h * a.k);
         if constexpr (!TRILINEAR) {
             if (role < 2) {
-                // RotatE: cos / sin of the relation phases come from a per-step table (one sincos per relation unit
-                // instead of one per bucket entry: at k = 1000, eta = 64 that is 1e6 instead of 4.3e9 evaluations)
-                const float* rp = (MODEL == AMDKGE_ROTATE ? a.rel_cs : a.rel) + (int64_t)pp * a.K;
-                const float* re = a.x + row_of((int)(meta >> 2)) * a.K;
+                const float* re = a.x + row_of((int)entry_local(meta)) * a.K;
 #pragma unroll
                 for (int c = 0; c < CH; ++c)
 #pragma unroll
-                    for (int h = 0; h < NC; ++h) {
-                        pv[c][h] = *reinterpret_cast<const float4*>(rp + qoff[c] + h * a.k);
-                        ev[c][h] = *reinterpret_cast<const float4*>(re + qoff[c] + h * a.k);
-                    }
+                    for (int h = 0; h < NC; ++h) ev[c][h] = KGE_LD4(re + qoff[c] + h * a.k);
+                if constexpr (MODEL != AMDKGE_ROTATE) {   // (RotatE: the staged side row already carries the rotation)
+                    const float* rp = a.rel + (int64_t)pp * a.K;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+#pragma unroll
+                        for (int h = 0; h < NC; ++h) pv[c][h] = KGE_LD4(rp + qoff[c] + h * a.k);
+                }
             }
         }
     };
-    auto add_entry = [&](uint32_t meta, float g, const float4 (&v)[CH][NC], const float4 (&pv)[CH][NX], const float4 (&ev)[CH][NX]) {
+    auto add_entry = [&](uint32_t meta, float g, const float4 (&v)[CH][NC], const float4 (&pv)[CH][NX], const float4 (&ev)[CH][NX]) KGE_TILE_INLINE {
         const int role = meta & 3;
-        const int lr = (int)(meta >> 2);
+        const int lr = (int)entry_local(meta);
         float* arow = acc + (size_t)lr * a.K;
         if (a.lazy) tflag[lr * gw + wg] = 1;
         float4 out[CH][NC];
@@ -204,9 +223,22 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             for (int c = 0; c < CH; ++c)
 #pragma unroll
                 for (int h = 0; h < NC; ++h) out[c][h] = make_float4(g * v[c][h].x, g * v[c][h].y, g * v[c][h].z, g * v[c][h].w);
+        } else if constexpr (MODEL == AMDKGE_ROTATE) {
+            // both sides: g (e - S) / |e - S| with S the staged side row (A = s o r, or B = o o conj(r)) and e the tile's own
+            // row -- for object-side entries the very operations of grad_unit's dd
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dr = (&ev[c][0].x)[u] - (&v[c][0].x)[u], di = (&ev[c][1].x)[u] - (&v[c][1].x)[u];
+                    const float m = KGE_SQRT(dr * dr + di * di) + ((qoff[c] + u >= a.k_live) ? 1.f : 0.f);   // (padding units: 0 / 1)
+                    const float gm = KGE_DIV(g, m);
+                    (&out[c][0].x)[u] = gm * dr;
+                    (&out[c][1].x)[u] = gm * di;
+                }
         } else {
-            // TransE / RotatE: the gradient w.r.t. the replaced row depends on that row -> same grad_unit
-            // arithmetic as the atomic path, on (side row copy, live relation row, own live row)
+            // TransE: the gradient w.r.t. the replaced row depends on that row -> same grad_unit arithmetic as the atomic
+            // path, on (side row copy, live relation row, own live row)
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
 #pragma unroll
@@ -238,9 +270,9 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         }
     };
     // entries of `mine` selected by `mask`, UNROLL at a time so that the operand loads of several entries are in flight
-    auto process = [&](const StageEntry& mine, unsigned long long mask) {
+    auto process = [&](const StageEntry& mine, unsigned long long mask) KGE_TILE_INLINE {
         int mine_pp = 0;   // relation id of the lane's entry (TransE / RotatE): one gather per 64 entries, not one per entry
-        if constexpr (!TRILINEAR) {
+        if constexpr (MODEL == AMDKGE_TRANSE) {
             if (mask) mine_pp = a.triples[3 * (int64_t)mine.pos + 1];   // mine.pos is a valid positive index (0 for padding lanes)
         }
         while (mask) {
@@ -318,7 +350,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             StageEntry mine{0u, 0u, 0.f, 0u};
             const bool in = base + lane < total;
             if (in) { const uint4 e = sbuf[base + lane]; mine = StageEntry{e.x, e.y, __uint_as_float(e.z), e.w}; }
-            process(mine, __ballot(in && (int)((mine.meta >> 2) % G) == grp));
+            process(mine, __ballot(in && (int)(entry_local(mine.meta) % G) == grp));
         }
     } else if (!tile_queued(MODEL, CH, a.K)) {
         // Trilinear models with rows beyond 1 KB (ComplEx, DistMult k > 256) keep the chunk-by-chunk form: they are bandwidth-
@@ -329,13 +361,13 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             StageEntry mine{0u, 0u, 0.f, 0u};
             const bool in = base + lane < cnt;
             if (in) mine = list[base + lane];
-            process(mine, __ballot(in && (int)((mine.meta >> 2) % G) == grp));
+            process(mine, __ballot(in && (int)(entry_local(mine.meta) % G) == grp));
         }
         for (int base = 0; base < on; base += 64) {   // overflow list (entries of buckets that were full): every tile filters all of it
             StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
             if (base + lane < on) mine = a.ovf[base + lane];
             const bool hit = mine.dest != 0xFFFFFFFFu && (mine.dest / RB) % NT == (uint32_t)tile;
-            process(mine, __ballot(hit && (int)((mine.meta >> 2) % G) == grp));
+            process(mine, __ballot(hit && (int)(entry_local(mine.meta) % G) == grp));
         }
     } else {
     // Two phases per wave.  Scanning a 64-entry chunk yields only ~64/16 entries for this wave: processed chunk by chunk, a
@@ -346,7 +378,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     uint4* queue = reinterpret_cast<uint4*>(smem + (((size_t)a.tile_rows * a.K * 4 + (a.lazy ? (size_t)a.tile_rows * gw : 0) + 15) & ~(size_t)15)) +
                    (size_t)wv * TILE_QCAP;
     int qn = 0;
-    auto drain = [&]() {
+    auto drain = [&](const uint4* q) KGE_TILE_INLINE {
         for (int i0 = 0; i0 < qn; i0 += UNROLL) {
             uint32_t meta[UNROLL];
             float g[UNROLL];
@@ -354,7 +386,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 if (i0 + u < qn) {
-                    const uint4 e = queue[i0 + u];   // same address in every lane: one LDS broadcast read, then scalars
+                    const uint4 e = q[i0 + u];   // same address in every lane: one LDS broadcast read, then scalars
                     meta[u] = __builtin_amdgcn_readfirstlane(e.y);
                     g[u] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.z));
                     load_ops(__builtin_amdgcn_readfirstlane(e.x), meta[u], (int)__builtin_amdgcn_readfirstlane(e.w), v[u], pv[u], ev[u]);
@@ -366,42 +398,166 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         }
         qn = 0;
     };
-    auto collect = [&](const StageEntry& mine, bool sel) {
-        const unsigned long long mask = __ballot(sel);
-        if (!mask) return;
-        if (qn + 64 > TILE_QCAP) drain();
+    if constexpr (MODEL != AMDKGE_TRANSE) {
+        // (this form is kept as it was measured: restating it as the single loop below cost the RotatE instantiation 17 % of
+        // the pass -- the compiler's schedule of the drain, not its work, changed)
+        auto collect = [&](const StageEntry& mine, bool sel) KGE_TILE_INLINE {
+            const unsigned long long mask = __ballot(sel);
+            if (!mask) return;
+            if (qn + 64 > TILE_QCAP) drain(queue);
+            if (sel) {
+                uint32_t pp = 0;   // relation id of the entry's positive (TransE / RotatE), carried in place of `dest`
+                if constexpr (MODEL == AMDKGE_TRANSE) pp = (uint32_t)a.triples[3 * (int64_t)mine.pos + 1];
+                queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))] =
+                    make_uint4(mine.pos, mine.meta, __float_as_uint(mine.g), pp);
+            }
+            qn += __popcll(mask);
+        };
+        {
+            StageEntry next{0u, 0u, 0.f, 0u};
+            if (lane < cnt) next = list[lane];
+            for (int base = 0; base < cnt; base += 64) {
+                const StageEntry mine = next;
+                const bool in = base + lane < cnt;
+                if (base + 64 + lane < cnt) next = list[base + 64 + lane];   // the next chunk is in flight while this one is filed
+                collect(mine, in && (int)(entry_local(mine.meta) % G) == grp);
+            }
+        }
+        // ---- overflow list (entries of buckets that were full): every tile filters all of it ----
+        for (int base = 0; base < on; base += 64) {
+            StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
+            if (base + lane < on) mine = a.ovf[base + lane];
+            const bool hit = mine.dest != 0xFFFFFFFFu && (mine.dest / RB) % NT == (uint32_t)tile;
+            collect(mine, hit && (int)(entry_local(mine.meta) % G) == grp);
+        }
+        drain(queue);
+    } else {
+    // TransE with sign codes: an entry's whole operand is ONE dword per lane, so such entries get a queue of their own
+    // (the first TILE_QFAST slots) and are drained FAST_U at a time -- the drain is a chain of load round trips, one per batch,
+    // and the 4 entries per batch the three-row form allows left the pass latency-bound (47 of its 69 us at k = 200).
+    // Own-row entries keep the general queue (the remaining slots) and the general drain; an entry whose codes show a (near-)zero
+    // unit is redone in the three-row form on the spot.
+    constexpr int TILE_QFAST = 64, FAST_U = 16;   // (both queues hold a whole 64-entry chunk)
+    const bool coded = a.sign_codes != nullptr;
+    uint4* const queue_slow = coded ? queue + TILE_QFAST : queue;
+    const int slow_cap = coded ? TILE_QCAP - TILE_QFAST : TILE_QCAP;
+    int qf = 0;
+    uint32_t padfill[CH];   // 0x01 in the bytes of this lane's padding units (units >= k_live), 0 elsewhere
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        padfill[c] = 0u;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) padfill[c] |= (qoff[c] + x >= a.k_live) ? (1u << (8 * x)) : 0u;
+    }
+    auto drain_fast = [&]() KGE_TILE_INLINE {
+        {
+            for (int i0 = 0; i0 < qf; i0 += FAST_U) {
+                uint32_t meta[FAST_U], gb[FAST_U], cw[FAST_U][CH];
+                uint32_t redo = 0u;
+#pragma unroll
+                for (int u = 0; u < FAST_U; ++u) {
+                    if (i0 + u < qf) {
+                        const uint4 e = queue[i0 + u];
+                        meta[u] = __builtin_amdgcn_readfirstlane(e.y);
+                        gb[u] = __builtin_amdgcn_readfirstlane(e.z);
+                        const uint32_t* src = a.sign_codes + ((int64_t)__builtin_amdgcn_readfirstlane(e.x) * a.eta + (meta[u] >> ENTRY_J_SHIFT)) * a.nq;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) cw[u][c] = src[qoff[c] >> 2];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < FAST_U; ++u) {
+                    if (i0 + u < qf) {
+                        // a unit of the model whose byte shows |d| < 2^-125 (a zero byte once the sign bit is masked; padding
+                        // units are made non-zero): sign(0) = 0 must hold exactly -> the entry is redone in the three-row form
+                        bool tiny = false;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            const uint32_t t = (cw[u][c] & 0x7f7f7f7fu) | padfill[c];
+                            tiny |= qok[c] && (((t - 0x01010101u) & ~t & 0x80808080u) != 0u);
+                        }
+                        if (__ballot(tiny)) {   // rare: noted, redone behind the batch (keeps the three-row code out of this unrolled loop)
+                            redo |= 1u << u;
+                            continue;
+                        }
+                        const int lr = (int)entry_local(meta[u]);
+                        float* arow = acc + (size_t)lr * a.K;
+                        if (a.lazy) tflag[lr * gw + wg] = 1;
+                        const unsigned g2 = (meta[u] & 3u) == 0u ? gb[u] ^ 0x80000000u : gb[u];   // -/+ g sign(d): role 0 is d/do = -g sign(d) (grad_unit)
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            if (!qok[c]) continue;
+                            float4* dst = reinterpret_cast<float4*>(arow + qoff[c]);
+                            float4 t = *dst;
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) {
+                                const float y = __uint_as_float(__builtin_amdgcn_bitop3_b32(cw[u][c] << (24 - 8 * x), 0x80000000u, g2, 0x6a));
+                                (&t.x)[x] += (qoff[c] + x < a.k_live) ? y : 0.f;
+                            }
+                            *dst = t;
+                        }
+                    }
+                }
+                while (redo) {
+                    const int u = __builtin_ctz(redo);
+                    redo &= redo - 1;
+                    const uint4 e = queue[i0 + u];
+                    const uint32_t pos = __builtin_amdgcn_readfirstlane(e.x), m16 = __builtin_amdgcn_readfirstlane(e.y) & 0xFFFFu;
+                    float4 v1[CH][NC], pv1[CH][NX], ev1[CH][NX];
+                    load_ops(pos, m16, a.triples[3 * (int64_t)pos + 1], v1, pv1, ev1);
+                    add_entry(m16, __uint_as_float(__builtin_amdgcn_readfirstlane(e.z)), v1, pv1, ev1);
+                }
+            }
+        }
+        qf = 0;
+    };
+    // TransE: ONE loop over the chunks of the bucket and then of the overflow list (entries of buckets that were full: every
+    // tile filters all of it), both queues drained at a single place in it.
+    const int nb = (cnt + 63) >> 6, nch = nb + ((on + 63) >> 6);
+    auto load_chunk = [&](int it) KGE_TILE_INLINE -> StageEntry {
+        StageEntry en{0u, 0u, 0.f, 0xFFFFFFFFu};   // dest = ~0: not an entry
+        if (it < nb) { if (it * 64 + lane < cnt) en = list[it * 64 + lane]; }
+        else if (it < nch) { if ((it - nb) * 64 + lane < on) en = a.ovf[(it - nb) * 64 + lane]; }
+        return en;
+    };
+    StageEntry next = load_chunk(0);
+    for (int it = 0; it <= nch; ++it) {
+        const StageEntry mine = next;
+        next = load_chunk(it + 1);   // the next chunk is in flight while this one is filed
+        bool sel = mine.dest != 0xFFFFFFFFu && (int)(entry_local(mine.meta) % G) == grp;
+        if (it >= nb) sel = sel && (mine.dest / RB) % NT == (uint32_t)tile;
+        const bool fast = coded && sel && (mine.meta & 3u) < 2u;   // sign-coded corruption entries: the fast queue
+        sel = sel && !fast;
+        const unsigned long long mf = __ballot(fast), ms = __ballot(sel);
+        const int nf = __popcll(mf), ns = __popcll(ms);
+#ifdef KGE_DRAIN_EARLY
+        if (it == nch || qf + 64 > TILE_QFAST || qn + 64 > slow_cap) {
+#else
+        if (it == nch || qf + nf > TILE_QFAST || qn + ns > slow_cap) {
+#endif
+            drain_fast();
+            drain(queue_slow);
+        }
+        if (fast) queue[qf + __builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0))] =
+                      make_uint4(mine.pos, mine.meta, __float_as_uint(mine.g), 0u);
+        qf += nf;
         if (sel) {
             uint32_t pp = 0;   // relation id of the entry's positive (TransE / RotatE), carried in place of `dest`
-            if constexpr (!TRILINEAR) pp = (uint32_t)a.triples[3 * (int64_t)mine.pos + 1];
-            queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))] =
+            if constexpr (!TRILINEAR) {
+                if (!coded) pp = (uint32_t)a.triples[3 * (int64_t)mine.pos + 1];   // (with sign codes only own-row entries come this way)
+            }
+            queue_slow[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0))] =
                 make_uint4(mine.pos, mine.meta, __float_as_uint(mine.g), pp);
         }
-        qn += __popcll(mask);
-    };
-    {
-        StageEntry next{0u, 0u, 0.f, 0u};
-        if (lane < cnt) next = list[lane];
-        for (int base = 0; base < cnt; base += 64) {
-            const StageEntry mine = next;
-            const bool in = base + lane < cnt;
-            if (base + 64 + lane < cnt) next = list[base + 64 + lane];   // the next chunk is in flight while this one is filed
-            collect(mine, in && (int)((mine.meta >> 2) % G) == grp);
-        }
+        qn += ns;
     }
-    // ---- overflow list (entries of buckets that were full): every tile filters all of it ----
-    for (int base = 0; base < on; base += 64) {
-        StageEntry mine{0u, 0u, 0.f, 0xFFFFFFFFu};
-        if (base + lane < on) mine = a.ovf[base + lane];
-        const bool hit = mine.dest != 0xFFFFFFFFu && (mine.dest / RB) % NT == (uint32_t)tile;
-        collect(mine, hit && (int)((mine.meta >> 2) % G) == grp);
     }
-    drain();
     }
 
     // ---- flush: the tile's rows leave LDS exactly once ------------------------------------------------
     // (the optimizer kind is dispatched once, outside the row loop: one compiled flush loop per update rule)
     float reg_acc = 0.f;
-    auto flush = [&](auto kind_c) {
+    auto flush = [&](auto kind_c) KGE_TILE_INLINE {
     constexpr int KIND = decltype(kind_c)::value;
     for (int r = grp; r < (KGE_DBG(a, 1024) ? 0 : nrow); r += G) {
         const float* arow = acc + (size_t)r * a.K;
@@ -530,7 +686,8 @@ __global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict_
 struct TiledPlan {
     int tile_rows, n_tiles, cap, ovf_cap, rb;
     int ns, sort_cap;   // deterministic mode: 5 staged rows per positive, LDS sort buffer entries (0 otherwise)
-    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, off_hot_map, off_hot_buf, total;
+    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, off_hot_map, off_hot_buf, off_codes, total;
+    bool codes;         // TransE with one wave per positive: the forward kernel hands the signs of d_j to the tile pass (ENTRY_EXACT)
 };
 
 static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p, bool det = false) {
@@ -596,6 +753,9 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
     p.off_rows = o; o += up((size_t)B * p.ns * K * 4);
     p.off_cs = o; o += up(m->scoring_type == AMDKGE_ROTATE ? (size_t)m->n_rels * K * 4 : 0);
+    const size_t code_bytes = (size_t)B * eta * (ks / 4) * 4;
+    p.codes = !det && m->scoring_type == AMDKGE_TRANSE && ks <= 512 && eta <= 65535 && code_bytes <= ((size_t)8 << 30);   // (det: sorted path, three-row form)
+    p.off_codes = o; o += up(p.codes ? code_bytes : 0);
     p.total = o + 256;
     return true;
 }
@@ -619,7 +779,7 @@ static int launch_forward(TrainArgs& f, hipStream_t st) {
     // workgroup when a positive spans the whole workgroup)
     size_t shmem = (size_t)slots * slot_lds_bytes(f.eta, W) + slots * sizeof(double) + (W == 1 ? 4 : 1) * (size_t)f.K * 4;
     f.sign_off = (int)shmem;
-    if (W != 1) shmem += sign_stash_bytes(MODEL, f.eta, CHF);   // (one wave per positive: TransE takes the single-pass form, no stash)
+    if (W != 1 || CHF != 1) shmem += sign_stash_bytes(MODEL, f.eta, CHF);   // (one wave per positive, one quad per lane: TransE takes the single-pass form, no stash)
     if (shmem > 64 * 1024) {
         static bool attr = false;
         if (!attr) {
@@ -653,10 +813,10 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     const size_t shmem_t = te.det ? (((size_t)te.tile_rows * te.K * 4 + (size_t)te.tile_rows * te.gw + 15) & ~(size_t)15) + (size_t)te.sort_cap * 16
                                   : (((size_t)te.tile_rows * te.K * 4 + (te.lazy ? (size_t)te.tile_rows * te.gw : 0) + 15) & ~(size_t)15) +
                                         (tile_queued(MODEL, tile_ch_of(f.nq), te.K) ? TILE_QUEUE_BYTES : 0);
-    // entries in flight per wave: bounded by the 128 VGPRs a 1024-thread workgroup leaves per lane (RotatE holds three
-    // complex operand rows per entry)
-    constexpr int U1 = TRILINEAR ? 8 : (MODEL == AMDKGE_ROTATE ? 2 : 4);
-    constexpr int U2 = TRILINEAR ? 4 : (MODEL == AMDKGE_ROTATE ? 1 : 2);
+    // entries in flight per wave: bounded by the 128 VGPRs a 1024-thread workgroup leaves per lane (TransE holds three operand
+    // rows per entry, RotatE two complex ones)
+    constexpr int U1 = TRILINEAR ? 8 : 4;
+    constexpr int U2 = TRILINEAR ? 4 : 2;
     if (f.nq <= 64 || f.nq > 128) return launch_tile<MODEL, 1, U1>(te, shmem_t, st);
     return launch_tile<MODEL, 2, U2>(te, shmem_t, st);
 }
@@ -727,6 +887,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     f.hot_map = hot ? (const uint8_t*)(w + p.off_hot_map) : nullptr; f.hot_buf = (float*)(w + p.off_hot_buf);
     f.rel_cs = (m->scoring_type == AMDKGE_ROTATE && B > 0) ? rel_cs : nullptr;   // filled by rel_phase_kernel below, before F
     f.touched = touched; f.ns = p.ns; f.det = det ? 1 : 0;
+    f.sign_codes = p.codes ? (uint32_t*)(w + p.off_codes) : nullptr;
     f.loss_parts = (double*)(w + p.off_loss);
     f.stage_rows = stage_rows; f.st_lists = lists; f.st_ovf = ovf; f.st_counters = counters;
     f.st_tile_rows = p.tile_rows; f.st_n_tiles = p.n_tiles; f.st_cap = p.cap; f.st_ovf_cap = p.ovf_cap; f.st_rb = p.rb;
@@ -737,6 +898,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
     te.rel_cs = rel_cs; te.lazy = lazy ? 1 : 0; te.touched = touched; te.ns = p.ns; te.det = det ? 1 : 0; te.sort_cap = p.sort_cap;
+    te.sign_codes = f.sign_codes; te.eta = eta;
     te.n_rels = m->n_rels; te.loss_parts = f.loss_parts; te.loss_sum = d_loss_sum; te.hot_map = f.hot_map; te.hot_buf = f.hot_buf;
 #ifdef KGE_ABLATE
     te.dbg = f.dbg;

@@ -230,6 +230,32 @@ def test_tiled_gradients_parity(gpu_lib, model, loss, pos_atomic):
         assert_grads_close(Gr, Tr)
 
 
+@pytest.mark.parametrize("k", [32, 50, 300])   # 50: padded rows (the padding units are exact zeros of another kind)
+@pytest.mark.parametrize("loss", ["self_adversarial", "pairwise"])
+def test_tiled_transe_exact_zero_units(gpu_lib, k, loss):
+    """TransE with tables on a coarse grid: s + p - o is EXACTLY zero in many units, where the gradient of |.| is 0
+    (sign(0) = 0, the oracle's and the reference's convention).  The single-pass forward kernel and the sign codes it hands
+    to the tile pass take their exact forms for such rows / entries; gradients == oracle."""
+    from ampligraph_amd.engine import KgeEngine
+
+    N, R, B, eta = 120, 3, 200, 7
+    eng = KgeEngine("TransE", k, N, R, max_rel_size=R)
+    rng = np.random.default_rng(12)
+    ent = (rng.integers(-2, 3, size=(N, k)) * 0.25).astype(np.float32)
+    rel = (rng.integers(-1, 2, size=(R, k)) * 0.25).astype(np.float32)
+    eng.set_tables(ent, rel)
+    X = rand_triples(rng, B, N, R)
+    negs = O.generate_corruptions(X, N, eta, 5, 2)
+    s, p, o = O.lookup(ent, rel, negs)
+    assert 0.05 < np.mean((s + p - o) == 0) < 0.9          # the case is what it claims to be
+    L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, loss, "sum", seed=5, step=2)
+    total, Te, Tr, (sp, sn, per) = O.dense_gradients("TransE", ent, rel, X, negs, eta, loss, None, "sum", R)
+    assert np.allclose(ns, sn, rtol=1e-5, atol=1e-5 * np.abs(sn).max())
+    assert abs(L - float(per.astype(np.float64).sum())) <= 1e-5 * max(1.0, abs(L))
+    assert_grads_close(Ge, Te)
+    assert_grads_close(Gr, Tr)
+
+
 @pytest.mark.parametrize("model,k,N", [("ComplEx", 200, 700), ("DistMult", 400, 5000), ("ComplEx", 352, 300),
                                          ("TransE", 52, 40000), ("RotatE", 260, 200), ("HolE", 100, 64),
                                          ("DistMult", 4, 3), ("TransE", 512, 1000),
