@@ -554,7 +554,8 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
     // (TransE: one quad per lane only -- with two, the single pass measured 145 us against the stash form's 81 at k = 352:
     // register pressure leaves it 2 waves per SIMD)
-    constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX || (MODEL == AMDKGE_TRANSE && CH == 1));
+    constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX ||
+                                                 ((MODEL == AMDKGE_TRANSE || MODEL == AMDKGE_ROTATE) && CH == 1));
     // TransE outside the single-pass geometry (two quads per lane, rows shared by four waves, atomic path): signs stashed by the
     // scoring pass
     constexpr bool SIGNSTASH = (MODEL == AMDKGE_TRANSE) && !ONEPASS && (STAGE || VEC == 4);   // (the scalar-load geometries keep the two-pass form)
@@ -571,6 +572,13 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         // side is sum_j c_j sign(d_j) -- the coefficient with the sign bit of d_j xor-ed in (one v_bitop3 per unit), no
         // second pass and no stash.  sign(0) = 0 is kept exact: a group of rows with an exact zero in a live unit (a
         // wave-uniform test on compare masks) takes the select form instead.
+        //
+        // RotatE (score = -sum |z|, z = s o r - o): what the gradients of s, theta and o need from corruption j is the UNIT VECTOR
+        // z_j / |z_j| per unit, known when the row streams by.  sum_j c_j z_j/|z_j| is accumulated per side and turned into the
+        // row gradients once per positive (they are linear in it: d/ds = conj(r) o Z_obj, d/do = -Z_subj,
+        // d/dtheta = Im(conj(A) Z_obj) + Im(conj(o) Z_subj) with A = s o r) -- one sqrt and one rcp per unit and row instead of
+        // grad_unit's two evaluations, and no second read of the rows.  Object-side z_j = A - e_j and subject-side
+        // z_j = e_j o r - o are the reference's own operations (RotatE.py:96-104).
         float qa[CH][VEC][NC], qb[CH][VEC][NC];
         unsigned long long live_m[CH][VEC];   // TransE: lanes whose unit u of quad c is a unit of the model (not row padding)
         // this positive's block of the sign codes ([eta][nq] dwords; eta * nq < 2^23, so row offsets are 32-bit)
@@ -585,6 +593,10 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 if constexpr (MODEL == AMDKGE_TRANSE) {
                     ds[0] = 0.f; dd[0] = s[c][u][0] + p[c][u][0];   // the reference's first rounding of (s + p) - e, TransE.py:51-53
                     live_m[c][u] = __ballot(qok[c] && qoff[c] + u < a.k_live);
+                } else if constexpr (MODEL == AMDKGE_ROTATE) {
+                    ds[0] = 0.f; ds[1] = 0.f;   // A = s o r (p holds cos, sin)
+                    dd[0] = s[c][u][0] * p[c][u][0] - s[c][u][1] * p[c][u][1];
+                    dd[1] = s[c][u][0] * p[c][u][1] + s[c][u][1] * p[c][u][0];
                 } else {
                     grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], 1.f, ds, dp, dd);
                 }
@@ -658,6 +670,21 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                                 // (wave-uniform row pointer + the lane's quad index: no per-lane address arithmetic)
                                 uint32_t* crow = code_base + (uint32_t)(jv[f] * a.nq);
                                 crow[qoff[c] >> 2] = t01 | t23;
+                            }
+                        } else if constexpr (MODEL == AMDKGE_ROTATE) {
+#pragma unroll
+                            for (int u = 0; u < VEC; ++u) {
+                                float zr, zi;
+                                if (d == 0) {
+                                    zr = qa[c][u][0] - e[f][c][u][0]; zi = qa[c][u][1] - e[f][c][u][1];
+                                } else {
+                                    zr = e[f][c][u][0] * p[c][u][0] - e[f][c][u][1] * p[c][u][1] - o[c][u][0];
+                                    zi = e[f][c][u][0] * p[c][u][1] + e[f][c][u][1] * p[c][u][0] - o[c][u][1];
+                                }
+                                const float m = KGE_SQRT(zr * zr + zi * zi);
+                                t += m;
+                                const float inv = KGE_DIV(1.f, m + pad1[c][u]);   // m == 0 in a unit of the model: NaN, like the reference
+                                e[f][c][u][0] = zr * inv; e[f][c][u][1] = zi * inv;   // the unit vector, kept in place of the row
                             }
                         } else {
 #pragma unroll
@@ -962,6 +989,16 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                     const bool lv = qoff[c] + u < a.k_live;
                     const float Go = lv ? eo[0] : 0.f, Gs = lv ? es[0] : 0.f;
                     gs[c][u][0] += Go; gp[c][u][0] += Go + Gs; go[c][u][0] -= Gs;
+                    continue;
+                }
+                if constexpr (MODEL == AMDKGE_ROTATE) {
+                    // eo = Z_obj, es = Z_subj (sums of g'_j z_j / |z_j|, g' includes the score sign); p = (cos, sin)
+                    const float cs = p[c][u][0], sn = p[c][u][1];
+                    const float Ar = s[c][u][0] * cs - s[c][u][1] * sn, Ai = s[c][u][0] * sn + s[c][u][1] * cs;
+                    gs[c][u][0] += eo[0] * cs + eo[1] * sn;          // conj(r) o Z_obj
+                    gs[c][u][1] += eo[1] * cs - eo[0] * sn;
+                    go[c][u][0] -= es[0]; go[c][u][1] -= es[1];
+                    gp[c][u][0] += (eo[1] * Ar - eo[0] * Ai) + (es[1] * o[c][u][0] - es[0] * o[c][u][1]);   // d/dphase
                     continue;
                 }
                 grad_unit<MODEL>(s[c][u], p[c][u], eo, 1.f, ds, dp, dd);   // corruptions (s, p, e_j)
