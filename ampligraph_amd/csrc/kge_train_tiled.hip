@@ -78,6 +78,7 @@ struct TileArgs {
     int ns;                   // staged rows per positive (4; 5 in deterministic mode)
     int det;                  // deterministic mode: the tile's entries are sorted into a canonical order before they are added
     int sort_cap;             // det: entries the LDS sort buffer holds (power of two)
+    int own_cache;            // RotatE, queued form: the tile's own live rows are copied into LDS behind the accumulators (see make_plan)
     int lazy;                 // touched-rows optimizer mode (amdkge_opt.lazy): rows without an entry keep their bits
     const uint8_t* hot_map;   // AMDKGE_TILED_HOT_ROWS (see HOT_MAX in kge_train_kernel.h); NULL = off
     float* hot_buf;
@@ -170,15 +171,26 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         qok[c] = q < a.nq;
         qoff[c] = (qok[c] ? q : 0) * 4;
     }
+    // RotatE with many entries per row: every corruption entry needs the tile's own live row e (g (e - S) / |e - S|); read
+    // from the table that is one L2 round trip and 4K bytes per entry (half of the pass's traffic at the C2 shape), so the
+    // owner keeps a copy of its rows in LDS behind the accumulators (written by the wave that owns the row, like the zeroes)
+    float* own = acc + (size_t)a.tile_rows * a.K;
+    const size_t acc_floats = (size_t)a.tile_rows * a.K * (a.own_cache ? 2 : 1);
     for (int r = grp; r < (KGE_DBG(a, 2048) ? 0 : nrow); r += G)
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int h = 0; h < NC; ++h)
-                if (qok[c]) *reinterpret_cast<float4*>(acc + (size_t)r * a.K + qoff[c] + h * a.k) = make_float4(0, 0, 0, 0);
+                if (qok[c]) {
+                    *reinterpret_cast<float4*>(acc + (size_t)r * a.K + qoff[c] + h * a.k) = make_float4(0, 0, 0, 0);
+                    if constexpr (MODEL == AMDKGE_ROTATE) {
+                        if (a.own_cache && row_ok(r))
+                            *reinterpret_cast<float4*>(own + (size_t)r * a.K + qoff[c] + h * a.k) = KGE_LD4(a.x + row_of(r) * a.K + qoff[c] + h * a.k);
+                    }
+                }
     // touched-rows mode: one flag byte per (row, wave of the owning group) behind the accumulators.  Every wave of a group
     // sees the same entries, so each keeps its own copy: written and read by the same wave, no synchronisation needed.
-    uint8_t* tflag = reinterpret_cast<uint8_t*>(acc + (size_t)a.tile_rows * a.K);
+    uint8_t* tflag = reinterpret_cast<uint8_t*>(acc + acc_floats);
     if (a.lazy)
         for (int r = grp + G * lane; r < nrow; r += G * 64)
             tflag[r * gw + wg] = (a.touched && row_ok(r) && a.touched[row_of(r)]) ? 1 : 0;
@@ -187,7 +199,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     // corruption entries, the relation row (RotatE: its cos / sin from the per-step table) and the tile's own live row.
     // Kept apart from the arithmetic so that the loads of UNROLL entries are in flight together.
     constexpr int NX = TRILINEAR ? 1 : NC;   // trilinear models need no relation / own-row operands
-    auto load_ops = [&](uint32_t pos, uint32_t meta, int pp, float4 (&v)[CH][NC], float4 (&pv)[CH][NX], float4 (&ev)[CH][NX]) KGE_TILE_INLINE {
+    auto load_ops = [&](uint32_t pos, uint32_t meta, int pp, float4 (&v)[CH][NC], float4 (&pv)[CH][NX], float4 (&ev)[CH][NX], auto own_c) KGE_TILE_INLINE {
+        constexpr bool OWN = decltype(own_c)::value;   // RotatE: the own row comes from the LDS copy (add_entry reads it)
         const int role = meta & 3;   // 0: corruption, object replaced; 1: corruption, subject replaced; 2: own s row; 3: own o row
         const int which = (role == 0) ? 2 : (role == 1) ? 3 : (role == 2) ? 0 : 1;
         const float* src = a.stage_rows + ((int64_t)pos * a.ns + which) * a.K;
@@ -197,11 +210,15 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             for (int h = 0; h < NC; ++h) v[c][h] = *reinterpret_cast<const float4*>(src + qoff[c] + h * a.k);
         if constexpr (!TRILINEAR) {
             if (role < 2) {
-                const float* re = a.x + row_of((int)entry_local(meta)) * a.K;
+                if constexpr (OWN) {
+                    // (read from LDS by add_entry itself: nothing of the own row is held across the batch)
+                } else {
+                    const float* re = a.x + row_of((int)entry_local(meta)) * a.K;
 #pragma unroll
-                for (int c = 0; c < CH; ++c)
+                    for (int c = 0; c < CH; ++c)
 #pragma unroll
-                    for (int h = 0; h < NC; ++h) ev[c][h] = KGE_LD4(re + qoff[c] + h * a.k);
+                        for (int h = 0; h < NC; ++h) ev[c][h] = KGE_LD4(re + qoff[c] + h * a.k);
+                }
                 if constexpr (MODEL != AMDKGE_ROTATE) {   // (RotatE: the staged side row already carries the rotation)
                     const float* rp = a.rel + (int64_t)pp * a.K;
 #pragma unroll
@@ -212,7 +229,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             }
         }
     };
-    auto add_entry = [&](uint32_t meta, float g, const float4 (&v)[CH][NC], const float4 (&pv)[CH][NX], const float4 (&ev)[CH][NX]) KGE_TILE_INLINE {
+    auto add_entry = [&](uint32_t meta, float g, const float4 (&v)[CH][NC], const float4 (&pv)[CH][NX], const float4 (&ev)[CH][NX], auto own_c) KGE_TILE_INLINE {
+        constexpr bool OWN = decltype(own_c)::value;
         const int role = meta & 3;
         const int lr = (int)entry_local(meta);
         float* arow = acc + (size_t)lr * a.K;
@@ -226,11 +244,18 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         } else if constexpr (MODEL == AMDKGE_ROTATE) {
             // both sides: g (e - S) / |e - S| with S the staged side row (A = s o r, or B = o o conj(r)) and e the tile's own
             // row -- for object-side entries the very operations of grad_unit's dd
+            float4 eo[CH][NC];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int h = 0; h < NC; ++h)
+                    if constexpr (OWN) eo[c][h] = *reinterpret_cast<const float4*>(own + (size_t)lr * a.K + qoff[c] + h * a.k);
+                    else eo[c][h] = ev[c][h < NX ? h : 0];
 #pragma unroll
             for (int c = 0; c < CH; ++c)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float dr = (&ev[c][0].x)[u] - (&v[c][0].x)[u], di = (&ev[c][1].x)[u] - (&v[c][1].x)[u];
+                    const float dr = (&eo[c][0].x)[u] - (&v[c][0].x)[u], di = (&eo[c][1].x)[u] - (&v[c][1].x)[u];
                     const float m = KGE_SQRT(dr * dr + di * di) + ((qoff[c] + u >= a.k_live) ? 1.f : 0.f);   // (padding units: 0 / 1)
                     const float gm = KGE_DIV(g, m);
                     (&out[c][0].x)[u] = gm * dr;
@@ -288,13 +313,13 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                     const uint32_t pos = __builtin_amdgcn_readlane(mine.pos, tt);
                     meta[u] = __builtin_amdgcn_readlane(mine.meta, tt);
                     g[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.g), tt));
-                    load_ops(pos, meta[u], __builtin_amdgcn_readlane(mine_pp, tt), v[u], pv[u], ev[u]);
+                    load_ops(pos, meta[u], __builtin_amdgcn_readlane(mine_pp, tt), v[u], pv[u], ev[u], std::false_type{});
                     m = u + 1;
                 }
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                if (u < m) add_entry(meta[u], g[u], v[u], pv[u], ev[u]);
+                if (u < m) add_entry(meta[u], g[u], v[u], pv[u], ev[u], std::false_type{});
         }
     };
 
@@ -375,28 +400,36 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     // k <= 256, C1 -- ran at a fraction of the fabric bandwidth: the pass took the same ~66 us whatever the row width).
     // Now the wave first COLLECTS its entries into a private LDS queue (chunk loads software-pipelined, no row traffic),
     // then drains the queue UNROLL entries at a time with all operand loads of a batch in flight.
-    uint4* queue = reinterpret_cast<uint4*>(smem + (((size_t)a.tile_rows * a.K * 4 + (a.lazy ? (size_t)a.tile_rows * gw : 0) + 15) & ~(size_t)15)) +
+    uint4* queue = reinterpret_cast<uint4*>(smem + ((acc_floats * 4 + (a.lazy ? (size_t)a.tile_rows * gw : 0) + 15) & ~(size_t)15)) +
                    (size_t)wv * TILE_QCAP;
     int qn = 0;
-    auto drain = [&](const uint4* q) KGE_TILE_INLINE {
-        for (int i0 = 0; i0 < qn; i0 += UNROLL) {
-            uint32_t meta[UNROLL];
-            float g[UNROLL];
-            float4 v[UNROLL][CH][NC], pv[UNROLL][CH][NX], ev[UNROLL][CH][NX];
+    auto drain_n = [&](auto n_c, auto own_c, const uint4* q) KGE_TILE_INLINE {
+        constexpr int UN = decltype(n_c)::value;
+        for (int i0 = 0; i0 < qn; i0 += UN) {
+            uint32_t meta[UN];
+            float g[UN];
+            float4 v[UN][CH][NC], pv[UN][CH][NX], ev[UN][CH][NX];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 if (i0 + u < qn) {
                     const uint4 e = q[i0 + u];   // same address in every lane: one LDS broadcast read, then scalars
                     meta[u] = __builtin_amdgcn_readfirstlane(e.y);
                     g[u] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.z));
-                    load_ops(__builtin_amdgcn_readfirstlane(e.x), meta[u], (int)__builtin_amdgcn_readfirstlane(e.w), v[u], pv[u], ev[u]);
+                    load_ops(__builtin_amdgcn_readfirstlane(e.x), meta[u], (int)__builtin_amdgcn_readfirstlane(e.w), v[u], pv[u], ev[u], own_c);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-                if (i0 + u < qn) add_entry(meta[u], g[u], v[u], pv[u], ev[u]);
+            for (int u = 0; u < UN; ++u)
+                if (i0 + u < qn) add_entry(meta[u], g[u], v[u], pv[u], ev[u], own_c);
         }
         qn = 0;
+    };
+    auto drain = [&](const uint4* q) KGE_TILE_INLINE {
+        if constexpr (MODEL == AMDKGE_ROTATE) {
+            // (with the own rows in LDS an entry holds one operand row; twice the entries in flight measured no different)
+            if (a.own_cache) { drain_n(std::integral_constant<int, UNROLL>{}, std::true_type{}, q); return; }
+        }
+        drain_n(std::integral_constant<int, UNROLL>{}, std::false_type{}, q);
     };
     if constexpr (MODEL != AMDKGE_TRANSE) {
         // (this form is kept as it was measured: restating it as the single loop below cost the RotatE instantiation 17 % of
@@ -504,8 +537,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                     const uint4 e = queue[i0 + u];
                     const uint32_t pos = __builtin_amdgcn_readfirstlane(e.x), m16 = __builtin_amdgcn_readfirstlane(e.y) & 0xFFFFu;
                     float4 v1[CH][NC], pv1[CH][NX], ev1[CH][NX];
-                    load_ops(pos, m16, a.triples[3 * (int64_t)pos + 1], v1, pv1, ev1);
-                    add_entry(m16, __uint_as_float(__builtin_amdgcn_readfirstlane(e.z)), v1, pv1, ev1);
+                    load_ops(pos, m16, a.triples[3 * (int64_t)pos + 1], v1, pv1, ev1, std::false_type{});
+                    add_entry(m16, __uint_as_float(__builtin_amdgcn_readfirstlane(e.z)), v1, pv1, ev1, std::false_type{});
                 }
             }
         }
@@ -687,6 +720,7 @@ struct TiledPlan {
     int tile_rows, n_tiles, cap, ovf_cap, rb;
     int ns, sort_cap;   // deterministic mode: 5 staged rows per positive, LDS sort buffer entries (0 otherwise)
     size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, off_hot_map, off_hot_buf, off_codes, total;
+    bool own_cache;     // RotatE, queued form, >= 4 corruption entries per table row and step: own rows cached in LDS
     bool codes;         // TransE with one wave per positive: the forward kernel hands the signs of d_j to the tile pass (ENTRY_EXACT)
 };
 
@@ -703,11 +737,14 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     // (+ slack for overflow entries) fits the buffer next to them
     const int model_t = m->scoring_type == AMDKGE_HOLE ? AMDKGE_COMPLEX : m->scoring_type;
     const size_t queue_bytes = tile_queued(model_t, tile_ch_of(ks / 4), K) ? TILE_QUEUE_BYTES : 0;
+    // (few entries per row -- one GPU's C5 shard sees 0.7 -- would only halve the tiles)
+    p.own_cache = !det && m->scoring_type == AMDKGE_ROTATE && queue_bytes != 0 && B * (int64_t)eta >= 4 * m->n_ents;
+    const size_t row_bytes = (size_t)K * 4 * (p.own_cache ? 2 : 1);
     for (size_t budget = det ? 96 * 1024 : 150 * 1024 - queue_bytes;; budget = budget * 3 / 4) {
         // Whole ownership blocks per tile (block-interleaved ownership, see tile_backward_kernel).  The block size is the largest
         // power of two <= TILE_RB that still lets the tiles fill the 256 CUs evenly: a tile's rows come in multiples of the
         // block, and at C2 (14 505 rows, ~57 per tile) blocks of 8 would leave 11 % of the CUs without a tile.
-        const int fit = (int)(budget / ((size_t)K * 4));
+        const int fit = (int)(budget / row_bytes);
         if (fit < 1) return false;
         double best_eff = -1.0;
         for (int rb = (int)TILE_RB; rb >= 1; rb >>= 1) {
@@ -811,7 +848,7 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     // T: entity tiles (the owner applies the optimizer)
     te.gw = f.nq <= 128 ? 1 : (f.nq <= 256 ? 4 : 8);
     const size_t shmem_t = te.det ? (((size_t)te.tile_rows * te.K * 4 + (size_t)te.tile_rows * te.gw + 15) & ~(size_t)15) + (size_t)te.sort_cap * 16
-                                  : (((size_t)te.tile_rows * te.K * 4 + (te.lazy ? (size_t)te.tile_rows * te.gw : 0) + 15) & ~(size_t)15) +
+                                  : (((size_t)te.tile_rows * te.K * 4 * (te.own_cache ? 2 : 1) + (te.lazy ? (size_t)te.tile_rows * te.gw : 0) + 15) & ~(size_t)15) +
                                         (tile_queued(MODEL, tile_ch_of(f.nq), te.K) ? TILE_QUEUE_BYTES : 0);
     // entries in flight per wave: bounded by the 128 VGPRs a 1024-thread workgroup leaves per lane (TransE holds three operand
     // rows per entry, RotatE two complex ones)
@@ -898,7 +935,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
     te.rel_cs = rel_cs; te.lazy = lazy ? 1 : 0; te.touched = touched; te.ns = p.ns; te.det = det ? 1 : 0; te.sort_cap = p.sort_cap;
-    te.sign_codes = f.sign_codes; te.eta = eta;
+    te.sign_codes = f.sign_codes; te.eta = eta; te.own_cache = p.own_cache ? 1 : 0;
     te.n_rels = m->n_rels; te.loss_parts = f.loss_parts; te.loss_sum = d_loss_sum; te.hot_map = f.hot_map; te.hot_buf = f.hot_buf;
 #ifdef KGE_ABLATE
     te.dbg = f.dbg;
