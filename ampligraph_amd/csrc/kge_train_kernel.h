@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     // (TransE: one quad per lane only -- with two, the single pass measured 145 us against the stash form's 81 at k = 352:
     // register pressure leaves it 2 waves per SIMD)
     constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX ||
-                                                 ((MODEL == AMDKGE_TRANSE || MODEL == AMDKGE_ROTATE) && CH == 1));
+                                                 (MODEL == AMDKGE_TRANSE && CH == 1) || MODEL == AMDKGE_ROTATE);
     // TransE outside the single-pass geometry (two quads per lane, rows shared by four waves, atomic path): signs stashed by the
     // scoring pass
     constexpr bool SIGNSTASH = (MODEL == AMDKGE_TRANSE) && !ONEPASS && (STAGE || VEC == 4);   // (the scalar-load geometries keep the two-pass form)
