@@ -376,7 +376,7 @@ __host__ __device__ inline size_t sign_stash_bytes(int model, int eta, int CH) {
 __host__ __device__ inline size_t slot_lds_bytes(int eta, int W) {
     // neg[eta+1], repl[eta+1], keep[eta+1], then part[W][eta+1] (W>1) or perm[eta+1] (W==1), dfac[eta+1] (FocusE),
     // rounded to 8 bytes
-    const size_t b = (size_t)(eta + 1) * (3 + (W > 1 ? W : 1) + 1) * 4;
+    const size_t b = (size_t)(eta + 1) * (3 + (W > 1 ? W : 1) + 1) * 4 + (W > 1 ? 64 * 4 : 0);   // (+ the single-pass cross-wave sums)
     return (b + 7) & ~(size_t)7;
 }
 
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #endif
     // (single-pass RotatE keeps the rows as unit vectors next to two complex accumulators per side: with 3 rows in flight it
     // fits 3 waves per SIMD -- measured 85.8 us against 95.1 with 6 and 92.4 with 2)
-    constexpr int PF = (CH * NC * VEC <= 8) ? (MODEL == AMDKGE_ROTATE && STAGE && W == 1 ? 3 : KGE_PF) : 2;
+    constexpr int PF = (CH * NC * VEC <= 8) ? (MODEL == AMDKGE_ROTATE && STAGE ? 3 : KGE_PF) : 2;
     auto load_row = [&](const float* re, float (&e)[CH][VEC][NC]) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
@@ -556,8 +556,11 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
     // (TransE: one quad per lane only -- with two, the single pass measured 145 us against the stash form's 81 at k = 352:
     // register pressure leaves it 2 waves per SIMD)
-    constexpr bool ONEPASS = STAGE && W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX ||
-                                                 (MODEL == AMDKGE_TRANSE && CH == 1) || MODEL == AMDKGE_ROTATE);
+    // RotatE also when the four waves of a workgroup share the positive (k > 512: the C5 row width): per group of rows the
+    // waves' partial sums meet in LDS, every wave then evaluates the same coefficients -- one barrier per group, and the rows
+    // (8 KB each at k = 1000, eta = 64 of them per positive) are read once instead of twice
+    constexpr bool ONEPASS = STAGE && ((W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX || (MODEL == AMDKGE_TRANSE && CH == 1))) ||
+                                       MODEL == AMDKGE_ROTATE);
     // TransE outside the single-pass geometry (two quads per lane, rows shared by four waves, atomic path): signs stashed by the
     // scoring pass
     constexpr bool SIGNSTASH = (MODEL == AMDKGE_TRANSE) && !ONEPASS && (STAGE || VEC == 4);   // (the scalar-load geometries keep the two-pass form)
@@ -611,7 +614,21 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
             }
             part += qok[c] ? acc : 0.f;
         }
-        float P1 = sgn_scale * wave_sum(part);
+        // cross-wave sums (W > 1): [2][W][PF] partials of the row groups, double-buffered by group parity, then [W] for the positive
+        float* sh_red = sh_dfac + e1;
+        int grp_no = 0;
+        float P1;
+        if constexpr (W == 1) {
+            P1 = sgn_scale * wave_sum(part);
+        } else {
+            const float w0 = wave_sum(part);
+            if (lane == 0) sh_red[2 * W * PF + wv] = w0;
+            __syncthreads();
+            float t0 = 0.f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) t0 += sh_red[2 * W * PF + w];
+            P1 = sgn_scale * t0;
+        }
         if (focus_nl) focus_apply(focus_nl, P1, focus_wp, P1, dPfac);
         if (lane == 0) sh_neg[eta] = P1;
         // corruptions ordered by side (object-replaced first): each of the two row loops below then has a
@@ -697,9 +714,24 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                         }
                         acc += qok[c] ? t : 0.f;
                     }
-                    const float n = sgn_scale * wave_sum(acc);
-                    nv = (lane == f) ? n : nv;
+                    if constexpr (W == 1) {
+                        const float n = sgn_scale * wave_sum(acc);
+                        nv = (lane == f) ? n : nv;
+                    } else {
+                        const float w1 = wave_sum(acc);
+                        if (lane == 0) sh_red[((grp_no & 1) * W + wv) * PF + f] = w1;
+                    }
                     jl = (lane == f) ? jv[f] : jl;
+                }
+                if constexpr (W > 1) {
+                    __syncthreads();   // (the other buffer is free again: every wave passed the previous group's barrier after reading it)
+                    if (lane < PF) {
+                        float t1 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) t1 += sh_red[((grp_no & 1) * W + w) * PF + lane];
+                        nv = sgn_scale * t1;
+                    }
+                    ++grp_no;
                 }
                 const bool lane_valid = lane < min(PF, p_end - p0);
                 float dfl = 1.f;
@@ -839,7 +871,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
             }
         }
     }
-    if constexpr (W > 1) {
+    if constexpr (W > 1 && !ONEPASS) {
         __syncthreads();
         for (int j = ts; j < e1; j += TS) {
             float t2 = 0.f;
@@ -874,8 +906,8 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     float per = 0.f, dP = 0.f;
     if constexpr (ONEPASS) {
         // pairwise / absolute_margin have no transcendental and keep the generic evaluation
-        if (a.loss.kind == AMDKGE_LOSS_PAIRWISE || a.loss.kind == AMDKGE_LOSS_ABSOLUTE_MARGIN) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP);
-        else onepass_finish(a.loss, P, sh_neg, eta, lane, ops, per, dP);
+        if (a.loss.kind == AMDKGE_LOSS_PAIRWISE || a.loss.kind == AMDKGE_LOSS_ABSOLUTE_MARGIN) { if (W == 1 || wv == 0) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP); }
+        else if (W == 1 || wv == 0) onepass_finish(a.loss, P, sh_neg, eta, lane, ops, per, dP);   // (rewrites sh_neg in place: one wave)
     } else if (W == 1 || wv == 0) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP);
     if constexpr (W > 1) {
         if (wv == 0 && lane == 0) sh_part[0] = dP;
