@@ -556,11 +556,11 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     // ---- pass 1: scores (positive as j == -1) -------------------------------------------------
     // (TransE: one quad per lane only -- with two, the single pass measured 145 us against the stash form's 81 at k = 352:
     // register pressure leaves it 2 waves per SIMD)
-    // RotatE also when the four waves of a workgroup share the positive (k > 512: the C5 row width): per group of rows the
+    // All but TransE also when the four waves of a workgroup share the positive (k > 512: the C5 row width): per group of rows the
     // waves' partial sums meet in LDS, every wave then evaluates the same coefficients -- one barrier per group, and the rows
     // (8 KB each at k = 1000, eta = 64 of them per positive) are read once instead of twice
-    constexpr bool ONEPASS = STAGE && ((W == 1 && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX || (MODEL == AMDKGE_TRANSE && CH == 1))) ||
-                                       MODEL == AMDKGE_ROTATE);
+    constexpr bool ONEPASS = STAGE && (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX || MODEL == AMDKGE_ROTATE ||
+                                       (MODEL == AMDKGE_TRANSE && W == 1 && CH == 1));
     // TransE outside the single-pass geometry (two quads per lane, rows shared by four waves, atomic path): signs stashed by the
     // scoring pass
     constexpr bool SIGNSTASH = (MODEL == AMDKGE_TRANSE) && !ONEPASS && (STAGE || VEC == 4);   // (the scalar-load geometries keep the two-pass form)
