@@ -12,13 +12,15 @@
 //      128-byte-strided counter; full buckets spill to one shared overflow list), and stores per positive
 //      four K-float rows with plain 16-byte coalesced stores: the complete gradient rows of its own s and o,
 //      and two "side" rows A, B (trilinear models: A = d score/d o (s,p), B = d score/d s (p,o), which do not
-//      depend on the replaced row; TransE / RotatE: copies of the s and o rows as read by the forward pass).
+//      depend on the replaced row; TransE: copies of the s and o rows as read by the forward pass, plus one packed
+//      byte per unit and corruption with the sign of s + p - o; RotatE: A = s o r, B = o o conj(r)).
 //      The relation-row gradient (237 hot rows at C2) keeps the atomic row-add into the dense relation
 //      gradient buffer, which the ordinary sweep (kge_opt.hip) consumes.
 //   T  tile_backward_kernel (this file): one workgroup OWNS a tile of entity rows and keeps their gradient
-//      accumulators in LDS (<= 150 KB).  It walks its bucket (+ the overflow list), adds g * A|B (trilinear)
-//      or grad_unit(side row, live relation row, own live row) (TransE, RotatE) with LDS atomics
-//      (ds_add_f32), and finally applies the optimizer + regulariser to its rows straight from LDS: the
+//      accumulators in LDS (<= 150 KB).  It walks its bucket (+ the overflow list), adds g * A|B (trilinear),
+//      -/+ g with the stored sign bits (TransE; grad_unit on three rows where a unit is (near) zero) or
+//      g (e - S) / |e - S| on the side row S and its own live row e (RotatE) -- every wave into the rows it
+//      owns, plain LDS read-modify-writes --, and finally applies the optimizer + regulariser to its rows straight from LDS: the
 //      entity gradient never exists in HBM and the entity table needs no separate optimizer sweep.
 //      The side rows are staged copies because other tiles update their rows in place while this one
 //      is still reading.
