@@ -585,7 +585,8 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         // grad_unit's two evaluations, and no second read of the rows.  Object-side z_j = A - e_j and subject-side
         // z_j = e_j o r - o are the reference's own operations (RotatE.py:96-104).
         float qa[CH][VEC][NC], qb[CH][VEC][NC];
-        unsigned long long live_m[CH][VEC];   // TransE: lanes whose unit u of quad c is a unit of the model (not row padding)
+        float zmark[CH][VEC];   // TransE: what an exact zero of d compares equal to -- 0 in a unit of the model, NaN (never equal) in row
+                                // padding and idle lanes.  (Per-unit lane masks did the same from 8 SGPRs and spilled them.)
         // this positive's block of the sign codes ([eta][nq] dwords; eta * nq < 2^23, so row offsets are 32-bit)
         uint32_t* const code_base = a.sign_codes + (int64_t)__builtin_amdgcn_readfirstlane((int)i) * eta * a.nq;
         float part = 0.f;
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 float ds[NC], dp[NC], dd[NC];
                 if constexpr (MODEL == AMDKGE_TRANSE) {
                     ds[0] = 0.f; dd[0] = s[c][u][0] + p[c][u][0];   // the reference's first rounding of (s + p) - e, TransE.py:51-53
-                    live_m[c][u] = __ballot(qok[c] && qoff[c] + u < a.k_live);
+                    zmark[c][u] = (qok[c] && qoff[c] + u < a.k_live) ? 0.f : __builtin_nanf("");
                 } else if constexpr (MODEL == AMDKGE_ROTATE) {
                     ds[0] = 0.f; ds[1] = 0.f;   // A = s o r (p holds cos, sin)
                     dd[0] = s[c][u][0] * p[c][u][0] - s[c][u][1] * p[c][u][1];
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                                 const float dj = (d == 0) ? (qa[c][u][0] - e[f][c][u][0]) : ((e[f][c][u][0] + p[c][u][0]) - o[c][u][0]);
                                 e[f][c][u][0] = dj;
                                 t += fabsf(dj);
-                                zero_m |= __ballot(dj == 0.f) & live_m[c][u];
+                                zero_m |= __ballot(dj == zmark[c][u]);
                             }
                             if (a.sign_codes && active && p0 + f < p_end && qok[c]) {
                                 // top bytes (sign + 7 exponent bits) of the four d values of this lane, one dword: 3 v_perm_b32
