@@ -154,6 +154,15 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     // as slow as its busiest tile (zipf graph); dealing the blocks round the tiles spreads every popularity class.  Blocks
     // rather than single rows keep the optimizer's streams (x, m, v of a tile) in runs of TILE_RB rows: with single rows a
     // large table (C4: 123 k rows) lost 12 % to page locality.  Rows beyond the table in a tile's last block are skipped.
+    // The forward kernel's per-block loss partials (complete: it finished before this launch started) are folded into the
+    // caller's accumulator by the first LOSS_PARTS tiles, one slot each, while they start up.  A fold by the LAST tile -- a
+    // returning exchange, a butterfly and an add behind everyone else's work -- sat on the critical path of every step.
+    if (tid == 0)
+        for (int sl = tile; sl < LOSS_PARTS; sl += a.n_tiles) {
+            const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(a.loss_parts + (size_t)sl * LOSS_PART_STRIDE), 0ull);
+            const double v = __longlong_as_double((long long)old);
+            if (v != 0.0) atomicAdd(a.loss_sum, v);
+        }
     const uint32_t NT = (uint32_t)a.n_tiles;
     const int nrow = a.tile_rows;
     const uint32_t RB = (uint32_t)a.rb;
@@ -662,10 +671,9 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         }
     }
     __syncthreads();
-    if (s_last && wv == 0) {   // the last tile to finish folds the loss partials (one wave, one partial per lane)
-        fold_loss_parts(a.loss_parts, a.loss_sum, lane);      // (the forward kernel finished before this launch started)
-        fold_loss_parts(a.loss_parts, a.reg_loss, lane, 1);   // every tile's waves added theirs before taking the ticket
-    }
+    // the regulariser partials (added by every tile's waves before the ticket) are folded by the last tile to finish; the data
+    // loss was folded when the kernel started (below the fill counts)
+    if (s_last && wv == 0 && a.apply_update && a.reg_loss && a.opt.lam != 0.f) fold_loss_parts(a.loss_parts, a.reg_loss, lane, 1);
 }
 
 // Deterministic mode: the relation-row gradient.  One workgroup per relation walks the batch in order, collects the
