@@ -220,3 +220,28 @@ def test_get_invalid_keys_docstring_example():
 
     with pytest.raises(Exception):
         ix.get_invalid_keys(X, data_type="nope")
+
+
+def test_indexer_hash_path_equals_sort_path(monkeypatch):
+    """Large text inputs are numbered / looked up through pandas' hash tables, small ones (and pandas-less installs) through
+    numpy's sort + binary search: same first-seen ids (data_indexer.py:373-399), same dropped rows (:485-549)."""
+    import ampligraph_amd.datasets.indexer as I
+
+    if I._pd is None:
+        pytest.skip("pandas not importable")
+    rng = np.random.default_rng(3)
+    n, N, R = 20000, 900, 11
+    X = np.stack([np.char.add("e", rng.integers(0, N, n).astype(str)), np.char.add("r", rng.integers(0, R, n).astype(str)),
+                  np.char.add("e", rng.integers(0, N, n).astype(str))], 1)
+    a = I.DataIndexer(X)
+    Q = X[:9000].copy()
+    Q[::13, 2] = "unseen"
+    Q[5::17, 1] = "unseen-rel"
+    ia, ma = a.get_indexes(Q), a.valid_row_mask(Q)
+    monkeypatch.setattr(I, "_pd", None)
+    b = I.DataIndexer(X)
+    assert np.array_equal(a._ent_raw, b._ent_raw) and np.array_equal(a._rel_raw, b._rel_raw)
+    assert np.array_equal(a.get_indexes(X), b.get_indexes(X))
+    assert np.array_equal(ia, b.get_indexes(Q)) and np.array_equal(ma, b.valid_row_mask(Q))
+    # the reference's rule on its own docstring-sized example: ids in order of first appearance, subject before object
+    assert list(a.get_indexes(X[:1])[0]) == [0, 0, 1 if X[0, 0] != X[0, 2] else 0]
