@@ -314,6 +314,7 @@ def main():
                     break
         tiled = loop.use_tiled and eng.tiled_supported(B, args.eta)
         kernel_names = (["train_fwdbwd_kernel<..., STAGE=true>", "tile_backward_kernel"] if tiled else ["train_fwdbwd_kernel"])
+        opt_bytes = 7.0 * 4.0 * eng.K * (N + R) if (world == 1 and not opt.lazy) else None
         opt_txt = ("dense (non-lazy) Keras-legacy Adam every step" if not opt.lazy else
                    "touched-rows (lazy) Adam: a documented deviation from the reference's dense optimizer")
         if sharded:
@@ -341,6 +342,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": " + ".join(kernel_names), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_pos * B,
+                         # SURVEY.md 8(d) reports the optimizer separately: 7*4K bytes per updated row (x, m, v read + written, g
+                         # read).  Known on the host only for the dense mode on one GPU, where the pair sweeps every row
+                         "optimizer_bytes_per_launch": opt_bytes,
+                         "frac_incl_optimizer": ((bytes_per_pos * B + opt_bytes) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                 if opt_bytes is not None and tiled else None),
                          "note": "launch = one train step's kernel pair (HIP events on the launch stream around both); "
                                  "single GPU: the pair also applies the optimizer (7*4K*(N+R) B/step dense), which is NOT counted "
                                  "in the algorithmic bytes; traffic = L2<->fabric bytes (PMC, Infinity-Cache hits included)"},
