@@ -588,7 +588,8 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         float zmark[CH][VEC];   // TransE: what an exact zero of d compares equal to -- 0 in a unit of the model, NaN (never equal) in row
                                 // padding and idle lanes.  (Per-unit lane masks did the same from 8 SGPRs and spilled them.)
         // this positive's block of the sign codes ([eta][nq] dwords; eta * nq < 2^23, so row offsets are 32-bit)
-        uint32_t* const code_base = a.sign_codes + (int64_t)__builtin_amdgcn_readfirstlane((int)i) * eta * a.nq;
+        uint32_t* const code_base = (MODEL == AMDKGE_TRANSE && a.sign_codes != nullptr)
+                                        ? a.sign_codes + (int64_t)__builtin_amdgcn_readfirstlane((int)i) * eta * a.nq : nullptr;
         float part = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
