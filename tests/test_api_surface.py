@@ -115,6 +115,22 @@ def test_model_surface_without_gpu():
         m.predict_proba(np.zeros((1, 3)))
     with pytest.raises(NotImplementedError):
         m.fit(np.array([["a", "b", "c"]]), partitioning_k=3)
+    with pytest.raises(RuntimeError):     # fit before compile (:713)
+        ScoringBasedEmbeddingModel(eta=1, k=2).fit(np.array([["a", "b", "c"]]))
+    with pytest.raises(NotImplementedError):   # a Python callable cannot be fused into the HIP kernel: refused, not run on the host
+        m.compile(optimizer="adam", loss=lambda pos, neg: pos)
+    with pytest.raises(ValueError):       # optimizers.py:289
+        m.compile(optimizer="not-an-optimizer", loss="nll")
+    m.compile(optimizer="adam", loss="self_adversarial")
+    with pytest.raises(AssertionError):   # :1605-1615
+        m.evaluate(np.array([["a", "b", "c"]]), corrupt_side="x")
+    twin = ScoringBasedEmbeddingModel.from_config(m.get_config())
+    assert twin.get_config() == m.get_config() and twin.scoring_type == "RotatE"
+    import torch
+
+    if not torch.cuda.is_available():     # no GPU, no training: loudly, never a host fallback
+        with pytest.raises(RuntimeError, match="ROCm GPU"):
+            m.fit(np.array([["a", "b", "c"], ["c", "b", "a"]]), batch_size=2, epochs=1)
 
 
 def test_product_has_no_oracle_or_cpu_fallback():
