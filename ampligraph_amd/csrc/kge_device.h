@@ -147,6 +147,36 @@ __device__ __forceinline__ void prep_rel(const ModelConst& mc, float (&p)[ModelT
     }
 }
 
+// RotatE's DECLARED relation form (evaluate / predict / the owner-computes train step's per-step phase table): the phase
+// theta / (embedding_range / pi) rounded to fp32 (RotatE.py:96), then cos and sin CORRECTLY ROUNDED to fp32 -- evaluated in
+// fp64 (ocml, <= 2 ulp of fp64) and rounded once, which differs from the correctly rounded fp32 value only when the fp64
+// result lies within ~2^-52 relative of an fp32 rounding boundary (probability ~2^-27 per value).  A CPU restatement does the
+// same with libm's fp64 cos / sin (oracle/rank_ordered.py), which is what makes RotatE's ranks bit-comparable; cosf / sinf
+// (prep_rel above, 1-2 ulp, implementation-defined bits) stay in the atomic-path train kernel that evaluates them per positive.
+template <int MODEL>
+__device__ __forceinline__ void prep_rel_exact(const ModelConst& mc, float (&p)[ModelTraits<MODEL>::NC]) {
+    if constexpr (MODEL == AMDKGE_ROTATE) {
+        const double phi = (double)(p[0] / mc.phase_div);
+        double sn, cs;
+        sincos(phi, &sn, &cs);
+        p[0] = (float)cs;
+        p[1] = (float)sn;
+    }
+}
+
+// Correctly rounded fp32 square root in 6 issue slots + one quarter-rate instruction.  g = v_rsq_f32(x) (1 ulp), y = x g,
+// r = x - y^2 EXACTLY (one fma: y is within a few ulp of sqrt(x), so the residual is representable), y' = y + r (g/2).
+// Verified EXHAUSTIVELY on gfx950 against sqrtf for every fp32 x >= 2^-102 (scripts/experiments/sqrt_exact.hip,
+// profiles/r03_sqrt_exact.log: 0 mismatches in [2^-100, FLT_MAX]); below that the residual underflows, and v_rsq_f32 flushes
+// denormal inputs, so x < 2^-100 (g > 2^50), 0 (g = inf), inf (g = 0) and NaN take the libm path.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    const float g = __builtin_amdgcn_rsqf(x);
+    if (!(g > 0.f && g <= 0x1p50f)) return sqrtf(x);
+    const float y = x * g, h = 0.5f * g;
+    const float r = fmaf(-y, y, x);
+    return fmaf(r, h, y);
+}
+
 #ifdef KGE_FAST_ROTATE
 #define KGE_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #define KGE_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))

@@ -83,6 +83,10 @@ __host__ __device__ inline int mode_of(int model, int side) {
     return MODE_DOT;
 }
 
+// RotatE: 0 (default) = exact mode (correctly rounded modulus, rank_rot_kernel / sqrt_rn), 1 = the 1-ulp hardware v_sqrt_f32
+// in the generic tile kernel (amdkge_set_rank_rotate_fast).  The tile and the filter kernel of one mode share their chain.
+static int g_rotate_fast = 0;
+
 inline RankGeom geom_of(const amdkge_model* m, int side) {
     RankGeom g{};
     // stored layout (include/amdkge.h): the zero padding units add exact zeros to every accumulation chain (fmaf(0, 0, acc),
@@ -91,7 +95,10 @@ inline RankGeom geom_of(const amdkge_model* m, int side) {
     g.K = row_floats(m);
     const int mode = mode_of(m->scoring_type, side);
     if (mode == MODE_DOT || mode == MODE_L1 || mode == MODE_L1_SUB) { g.U = g.K; g.eplane = 0; g.qplane = 0; g.QW = g.K; }
-    else { g.U = ks; g.eplane = ks; g.qplane = ks; g.QW = (mode == MODE_ROT_S ? 4 : 2) * ks; }
+    else {
+        // exact mode walks the LIVE units only: a padding unit's modulus is sqrt(0), outside the fast sequence's domain
+        g.U = g_rotate_fast ? ks : m->k; g.eplane = ks; g.qplane = ks; g.QW = (mode == MODE_ROT_S ? 4 : 2) * ks;
+    }
     g.sgn = (side == AMDKGE_SIDE_S) ? 1.f : -1.f;
     return g;
 }
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void rank_prep_kernel(const float* __restrict_
         float s[NC], p[NC], o[NC];
 #pragma unroll
         for (int h = 0; h < NC; ++h) { s[h] = rs[c + h * k]; p[h] = rp[c + h * k]; o[h] = ro[c + h * k]; }
-        prep_rel<MODEL>(mc, p);
+        prep_rel_exact<MODEL>(mc, p);   // RotatE: correctly rounded cos / sin (kge_device.h)
         part += score_unit<MODEL>(s, p, o);
         if constexpr (MODEL == AMDKGE_TRANSE) {
             q[c] = (side == AMDKGE_SIDE_S) ? (p[0] - o[0]) : (s[0] + p[0]);           // TransE.py:77-83,107-113
@@ -306,6 +313,182 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
     }
     if constexpr (STORE) return;
     // reduce over the 16 lanes (te) that share the same queries, one atomic pair per query per block
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        int g = cgt[x], e = ceq[x];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); e += __shfl_xor(e, o, 64); }
+        const int64_t qi = q0 + tq * 4 + x;
+        if (te == 0 && qi < a.n) {
+            if (g) atomicAdd(&a.counts[2 * qi + 0], g);
+            if (e) atomicAdd(&a.counts[2 * qi + 1], e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RotatE, exact mode (the default): the tile kernel with the per-unit modulus CORRECTLY ROUNDED, so that the whole chain
+//     acc = fl(acc + sqrt_rn(fl(fl(re * re) + fl(im * im))))          (RotatE.py:151-160,209-214, unit order)
+// is a function of the inputs alone and a CPU restatement (oracle/csrc/rank_ordered.c) reproduces the ranks bit for bit.
+// Same tiling as rank_count_kernel (64 queries x 64 entities, 16 units per LDS stage, 4 x 4 micro tile per thread); the
+// arithmetic is written on PAIRS of entities so that it issues as packed fp32 (v_pk_add / v_pk_mul / v_pk_fma_f32: two lanes
+// of work per slot) and the modulus is sqrt_rn's fast sequence without its branch: v_rsq_f32 + 4 packed operations per pair.
+// Its domain (x >= 2^-100: exhaustively verified, see sqrt_rn in kge_device.h) is checked per entity tile and costs half a
+// slot per unit: every thread keeps the maximum of its v_rsq results (x < 2^-100, zero or denormal <=> g > 2^50) and looks at
+// its 16 accumulators (x = inf or NaN poisons them); if anything in the WORKGROUP is outside, the tile is redone with libm's
+// sqrtf.  Padding units of the stored layout are not walked at all (U = the model's k: their x is an exact 0, which is
+// outside the fast domain); live units with re = im = 0 exactly (a corruption that coincides with the rotated subject in
+// both components) take the slow path and are the only realistic trigger.
+// ------------------------------------------------------------------------------------------------
+template <bool SLOW, bool SUBJ>
+__device__ __forceinline__ void rot_micro(const float (&qv)[SUBJ ? 4 : 2][4], const float (&ev)[2][4], f32x2 (&acc)[4][2], float& gmax) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const f32x2 e0 = {ev[0][2 * y], ev[0][2 * y + 1]}, e1 = {ev[1][2 * y], ev[1][2 * y + 1]};
+            f32x2 re, im;
+            if constexpr (!SUBJ) {   // q = s o r                                    RotatE.py:209-214
+                const f32x2 q0 = {qv[0][x], qv[0][x]}, q1 = {qv[1][x], qv[1][x]};
+                re = q0 - e0;
+                im = q1 - e1;
+            } else {                 // q = (cos, sin, o_re, o_im)                   RotatE.py:151-160
+                const f32x2 c = {qv[0][x], qv[0][x]}, sn = {qv[1][x], qv[1][x]}, orr = {qv[2][x], qv[2][x]}, oi = {qv[3][x], qv[3][x]};
+                re = e0 * c - e1 * sn - orr;
+                im = e0 * sn + e1 * c - oi;
+            }
+            const f32x2 xx = re * re + im * im;
+            f32x2 m;
+            if constexpr (SLOW) {
+                m.x = sqrtf(xx.x);
+                m.y = sqrtf(xx.y);
+            } else {
+                f32x2 g;
+                g.x = __builtin_amdgcn_rsqf(xx.x);
+                g.y = __builtin_amdgcn_rsqf(xx.y);
+                gmax = fmaxf(fmaxf(gmax, g.x), g.y);
+                const f32x2 yv = xx * g, h = g * 0.5f;
+                const f32x2 r = __builtin_elementwise_fma(-yv, yv, xx);
+                m = __builtin_elementwise_fma(r, h, yv);
+            }
+            acc[x][y] = acc[x][y] + m;
+        }
+}
+
+template <bool SUBJ, bool STORE>
+__global__ __launch_bounds__(256) void rank_rot_kernel(CountArgs a) {
+    constexpr int NQF = SUBJ ? 4 : 2, NEF = 2;
+    __shared__ __attribute__((aligned(16))) float Qs[NQF][KT][LDP];
+    __shared__ __attribute__((aligned(16))) float Es[NEF][KT][LDP];
+
+    const int tid = threadIdx.x;
+    const int tq = tid >> 4, te = tid & 15;
+    const int64_t q0 = (int64_t)blockIdx.x * QT;
+    const int64_t e_begin = a.ent_lo + (int64_t)blockIdx.y * a.ent_per_block;
+    const int64_t e_end = min(a.ent_hi, e_begin + a.ent_per_block);
+    const int U = a.g.U;   // live units; the planes of Q and of a table row are a.g.qplane / a.g.eplane (stored width) apart
+
+    int qp[4] = {0, 0, 0, 0};
+    if constexpr (!STORE) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int64_t qi = q0 + tq * 4 + x;
+            qp[x] = a.qpos[qi < a.n ? qi : a.n - 1];
+        }
+    }
+    int cgt[4] = {0, 0, 0, 0}, ceq[4] = {0, 0, 0, 0};
+
+    const int lrow = tid >> 2, lgrp = tid & 3;   // loader: row 0..63, 4-unit group 0..3
+    const int64_t lq = q0 + lrow;
+    const float* qrow = a.Q + (lq < a.n ? lq : a.n - 1) * (int64_t)a.g.QW;
+
+    for (int64_t et = e_begin; et < e_end; et += ET) {
+        const int64_t le = et + lrow;
+        const int64_t le_c = le < e_end ? le : e_end - 1;
+        const int64_t erow_id = a.ent_ids ? (int64_t)a.ent_ids[le_c] : le_c;
+        const float* erow = a.ent + erow_id * a.g.K;
+        f32x2 acc[4][2];
+        float gmax = 0.f;
+
+        auto run_tile = [&](auto slow_c) __attribute__((always_inline)) {
+            constexpr bool SLOW = decltype(slow_c)::value;
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = f32x2{0.f, 0.f};
+            for (int k0 = 0; k0 < U; k0 += KT) {
+                // ---- global -> LDS, transposed to [plane][unit][row]; a 4-unit group that starts inside the row is loaded
+                //      whole (the stored row is a whole number of float4s; what lies beyond U is never multiplied) ----
+                const int ku = k0 + lgrp * 4;
+                const bool in = ku < U;
+#pragma unroll
+                for (int f = 0; f < NQF; ++f) {
+                    const float4 t = in ? *reinterpret_cast<const float4*>(qrow + f * a.g.qplane + ku) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    Qs[f][lgrp * 4 + 0][lrow] = t.x; Qs[f][lgrp * 4 + 1][lrow] = t.y; Qs[f][lgrp * 4 + 2][lrow] = t.z; Qs[f][lgrp * 4 + 3][lrow] = t.w;
+                }
+#pragma unroll
+                for (int f = 0; f < NEF; ++f) {
+                    const float4 t = in ? *reinterpret_cast<const float4*>(erow + f * a.g.eplane + ku) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    Es[f][lgrp * 4 + 0][lrow] = t.x; Es[f][lgrp * 4 + 1][lrow] = t.y; Es[f][lgrp * 4 + 2][lrow] = t.z; Es[f][lgrp * 4 + 3][lrow] = t.w;
+                }
+                __syncthreads();
+                auto unit = [&](int kk) __attribute__((always_inline)) {
+                    float qv[NQF][4], ev[NEF][4];
+#pragma unroll
+                    for (int f = 0; f < NQF; ++f) {
+                        const float4 t = *reinterpret_cast<const float4*>(&Qs[f][kk][tq * 4]);
+                        qv[f][0] = t.x; qv[f][1] = t.y; qv[f][2] = t.z; qv[f][3] = t.w;
+                    }
+#pragma unroll
+                    for (int f = 0; f < NEF; ++f) {
+                        const float4 t = *reinterpret_cast<const float4*>(&Es[f][kk][te * 4]);
+                        ev[f][0] = t.x; ev[f][1] = t.y; ev[f][2] = t.z; ev[f][3] = t.w;
+                    }
+                    rot_micro<SLOW, SUBJ>(qv, ev, acc, gmax);
+                };
+                if (U - k0 >= KT) {
+#pragma unroll
+                    for (int kk = 0; kk < KT; ++kk) unit(kk);
+                } else {
+                    for (int kk = 0; kk < U - k0; ++kk) unit(kk);   // the row's last, partial stage: live units only
+                }
+                __syncthreads();
+            }
+        };
+        run_tile(std::false_type{});
+        bool bad = !(gmax <= 0x1p50f);
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) bad |= !(fabsf(acc[x][y].x) < INFINITY) || !(fabsf(acc[x][y].y) < INFINITY);
+        if (__syncthreads_or(bad ? 1 : 0)) run_tile(std::true_type{});
+
+        if constexpr (STORE) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int64_t qi = q0 + tq * 4 + x;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    const int64_t ej = et + te * 4 + y;
+                    const float sc = (y & 1) ? acc[x][y >> 1].y : acc[x][y >> 1].x;
+                    if (qi < a.n && ej < e_end) a.scores[qi * a.ld + (ej - a.ent_lo)] = a.sgn_scale * sc;
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const bool valid = (et + te * 4 + y) < e_end;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float sc = (y & 1) ? acc[x][y >> 1].y : acc[x][y >> 1].x;
+                const int q = quantise(a.sgn_scale * sc);
+                cgt[x] += (valid && qp[x] < q) ? 1 : 0;
+                ceq[x] += (valid && qp[x] == q) ? 1 : 0;
+            }
+        }
+    }
+    if constexpr (STORE) return;
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
         int g = cgt[x], e = ceq[x];
@@ -744,7 +927,17 @@ struct FilterArgs {
     float sgn_scale;
 };
 
-template <int MODE, bool V4>
+// One unit of RotatE's exact-mode chain for ONE (query, entity) pair: the operations of rot_micro, scalar (sqrt_rn == the
+// packed sequence inside its domain, libm's sqrtf outside: bitwise the tile kernel's value either way).
+template <int MODE>
+__device__ __forceinline__ float rot_exact_op(float acc, const float (&q)[ModeTraits<MODE>::NQF], const float (&e)[2]) {
+    float re, im;
+    if constexpr (MODE == MODE_ROT_O) { re = q[0] - e[0]; im = q[1] - e[1]; }
+    else { re = e[0] * q[0] - e[1] * q[1] - q[2]; im = e[0] * q[1] + e[1] * q[0] - q[3]; }
+    return acc + sqrt_rn(re * re + im * im);
+}
+
+template <int MODE, bool V4, bool EXACT_ROT = false>
 __global__ __launch_bounds__(256) void rank_filter_kernel(FilterArgs a) {
     constexpr int NQF = ModeTraits<MODE>::NQF, NEF = ModeTraits<MODE>::NEF;
     const int lane = threadIdx.x & 63;
@@ -768,7 +961,31 @@ __global__ __launch_bounds__(256) void rank_filter_kernel(FilterArgs a) {
         }
         const float* erow = a.ent + (ok ? id : 0) * a.g.K;
         float acc = 0.f;
-        if (V4) {
+        if constexpr (EXACT_ROT) {   // live units only (a.g.U = k), float4 loads inside the stored (padded) row
+            for (int u0 = 0; u0 < a.g.U; u0 += 4) {
+                float qv[NQF][4], ev[NEF][4];
+#pragma unroll
+                for (int p = 0; p < NQF; ++p) {
+                    const float4 t = *reinterpret_cast<const float4*>(qrow + p * a.g.qplane + u0);
+                    qv[p][0] = t.x; qv[p][1] = t.y; qv[p][2] = t.z; qv[p][3] = t.w;
+                }
+#pragma unroll
+                for (int p = 0; p < NEF; ++p) {
+                    const float4 t = *reinterpret_cast<const float4*>(erow + p * a.g.eplane + u0);
+                    ev[p][0] = t.x; ev[p][1] = t.y; ev[p][2] = t.z; ev[p][3] = t.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u0 + u >= a.g.U) break;
+                    float qq[NQF], ee[NEF];
+#pragma unroll
+                    for (int p = 0; p < NQF; ++p) qq[p] = qv[p][u];
+#pragma unroll
+                    for (int p = 0; p < NEF; ++p) ee[p] = ev[p][u];
+                    acc = rot_exact_op<MODE>(acc, qq, ee);
+                }
+            }
+        } else if (V4) {
             for (int u0 = 0; u0 < a.g.U; u0 += 4) {
                 float qv[NQF][4], ev[NEF][4];
 #pragma unroll
@@ -865,6 +1082,11 @@ extern "C" int amdkge_set_rank_kernel(int which) {
     return AMDKGE_OK;
 }
 
+extern "C" int amdkge_set_rank_rotate_fast(int fast) {
+    g_rotate_fast = fast ? 1 : 0;
+    return AMDKGE_OK;
+}
+
 extern "C" int64_t amdkge_rank_workspace_bytes(const amdkge_model* m, int64_t n) {
     if (validate_model(m) != AMDKGE_OK || n < 0) return -1;
     const int64_t qw = (m->scoring_type == AMDKGE_ROTATE) ? 4ll * stored_k(m) : row_floats(m);
@@ -889,8 +1111,9 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
     CountArgs a{};
     a.ent = d_ent; a.Q = w.Q; a.qpos = w.qpos; a.ent_ids = d_ent_ids; a.counts = d_counts; a.n = n;
     a.ent_lo = ent_lo; a.ent_hi = ent_hi; a.g = g; a.sgn_scale = mc.score_sign * mc.score_scale;
-    const bool v4 = (g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
     const int mode = mode_of(m->scoring_type, side);
+    const bool rot_exact = (mode == MODE_ROT_O || mode == MODE_ROT_S) && !g_rotate_fast;
+    const bool v4 = (rot_exact || g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
     const int force = g_rank_kernel;   // amdkge_set_rank_kernel (tests): 1 forces the VALU tile kernel, 2 the first MFMA kernel
     const bool mfma = (mode == MODE_DOT) && force != 1;
     const int qt = mfma ? MQ : QT, et_ = mfma ? ME : ET;
@@ -942,6 +1165,12 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
         else if (v4) hipLaunchKernelGGL((rank_count_mfma_kernel<true>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         else hipLaunchKernelGGL((rank_count_mfma_kernel<false>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         return check_launch("rank_counts_mfma");
+    }
+    if (rot_exact) {
+        if (!v4) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: RotatE's exact mode needs the padded stored layout (k_pad = amdkge_padded_k(k)); dense rows with k % 4 != 0 only have the fast mode (amdkge_set_rank_rotate_fast)");
+        if (mode == MODE_ROT_S) hipLaunchKernelGGL((rank_rot_kernel<true, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((rank_rot_kernel<false, false>), grid, dim3(256), 0, st, a);
+        return check_launch("rank_counts_rot");
     }
 #define KGE_CNT(MODE) do { if (v4) hipLaunchKernelGGL((rank_count_kernel<MODE, true>), grid, dim3(256), 0, st, a); \
                            else hipLaunchKernelGGL((rank_count_kernel<MODE, false>), grid, dim3(256), 0, st, a); } while (0)
@@ -1004,8 +1233,15 @@ extern "C" int amdkge_rank_filter(const amdkge_model* m, const float* d_ent, con
     a.subset_pos = d_subset_pos; a.sub = d_sub; a.n = n; a.ent_lo = ent_lo; a.ent_hi = ent_hi; a.g = g;
     a.sgn_scale = mc.score_sign * mc.score_scale;
     const unsigned grid = (unsigned)((n + 3) / 4);
-    const bool v4 = (g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
     const int mode = mode_of(m->scoring_type, side);
+    const bool rot_exact = (mode == MODE_ROT_O || mode == MODE_ROT_S) && !g_rotate_fast;
+    const bool v4 = (rot_exact || g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
+    if (rot_exact) {
+        if (!v4) return set_error(AMDKGE_EUNSUPPORTED, "rank_filter: RotatE's exact mode needs the padded stored layout (k_pad = amdkge_padded_k(k))");
+        if (mode == MODE_ROT_S) hipLaunchKernelGGL((rank_filter_kernel<MODE_ROT_S, true, true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((rank_filter_kernel<MODE_ROT_O, true, true>), dim3(grid), dim3(256), 0, st, a);
+        return check_launch("rank_filter_rot");
+    }
 #define KGE_FLT(MODE) do { if (v4) hipLaunchKernelGGL((rank_filter_kernel<MODE, true>), dim3(grid), dim3(256), 0, st, a); \
                            else hipLaunchKernelGGL((rank_filter_kernel<MODE, false>), dim3(grid), dim3(256), 0, st, a); } while (0)
     switch (mode) {
@@ -1042,6 +1278,12 @@ static int launch_store(int mode, bool v4, CountArgs& a, int64_t n, int64_t m, h
     if (splits > 65535 || qtiles > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "scores: too many tiles for one launch; split the queries");
     a.ent_per_block = (int)(tiles_per * ET);
     const dim3 grid((unsigned)qtiles, (unsigned)splits);
+    if ((mode == MODE_ROT_O || mode == MODE_ROT_S) && !g_rotate_fast) {
+        if (!v4) return set_error(AMDKGE_EUNSUPPORTED, "scores: RotatE's exact mode needs the padded stored layout (k_pad = amdkge_padded_k(k))");
+        if (mode == MODE_ROT_S) hipLaunchKernelGGL((rank_rot_kernel<true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((rank_rot_kernel<false, true>), grid, dim3(256), 0, st, a);
+        return check_launch("corruption_scores_rot");
+    }
 #define KGE_STORE(MODE) do { if (v4) hipLaunchKernelGGL((rank_count_kernel<MODE, true, true>), grid, dim3(256), 0, st, a); \
                              else hipLaunchKernelGGL((rank_count_kernel<MODE, false, true>), grid, dim3(256), 0, st, a); } while (0)
     switch (mode) {
@@ -1072,8 +1314,10 @@ extern "C" int amdkge_corruption_scores(const amdkge_model* m, const float* d_en
     CountArgs a{};
     a.ent = d_ent; a.Q = w.Q; a.qpos = w.qpos; a.ent_ids = d_ent_ids; a.n = n; a.ent_lo = ent_lo; a.ent_hi = ent_hi; a.g = g;
     a.sgn_scale = mc.score_sign * mc.score_scale; a.scores = d_scores; a.ld = ld;
-    const bool v4 = (g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
-    return launch_store(mode_of(m->scoring_type, side), v4, a, n, ent_hi - ent_lo, st);
+    const int mode = mode_of(m->scoring_type, side);
+    const bool rot_exact = (mode == MODE_ROT_O || mode == MODE_ROT_S) && !g_rotate_fast;
+    const bool v4 = (rot_exact || g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
+    return launch_store(mode, v4, a, n, ent_hi - ent_lo, st);
 }
 
 extern "C" int amdkge_row_dots(const float* d_q, int64_t n, const float* d_table, int32_t row_floats, const int32_t* d_ent_ids,

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ en
         }
 #pragma unroll
         for (int u = 0; u < VEC; ++u) {
-            prep_rel<MODEL>(mc, p[u]);
+            prep_rel_exact<MODEL>(mc, p[u]);   // RotatE: the declared correctly rounded cos / sin (same values as evaluate)
             part += score_unit<MODEL>(s[u], p[u], o[u]);
         }
     }

@@ -29,6 +29,8 @@
 // (/root/reference/ampligraph/latent_features/models/ScoringBasedEmbeddingModel.py:370-429) including
 // optimizer.minimize (optimizers.py:136-168) and the LP regulariser (regularizers.py:35-37).
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 // RotatE's modulus and its reciprocal in the TRAINING kernels use the hardware v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the
 // correctly rounded libm sequences: the fused kernels are bound by exactly these on RotatE (measured 1.26x on the step);
@@ -93,7 +95,8 @@ struct TileArgs {
     const float* stage_rows;  // [B][4][K]
     const StageEntry* lists;  // [n_tiles][cap]
     const StageEntry* ovf;    // overflow entries
-    int* counters;            // [(n_tiles + 3) * 32]: bucket fills, overflow count, finished-tiles ticket, det-sort overflow flag
+    int* counters;            // [(n_tiles + 2) * 32]: bucket fills, overflow count, finished-tiles ticket
+    int* status_flag;         // det-sort overflow flag: at a workspace offset that does not depend on the plan (sticky until queried)
     double* loss_parts;       // the forward kernel's per-block loss partials, folded into loss_sum by the last tile
     double* loss_sum;
     double* reg_loss;
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
         __syncthreads();
         int total = s_total;
         if (total > a.sort_cap) {   // more entries than the sort buffer holds (a very hot tile): flagged, the host raises
-            if (tid == 0) atomicExch(a.counters + (size_t)(a.n_tiles + 2) * 32, 1);
+            if (tid == 0) atomicExch(a.status_flag, 1);
             total = a.sort_cap;
         }
         int n2 = 64;
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(256) void rel_backward_det_kernel(const int32_t* __
         if (tid + 256 * c < K) g_rel[(int64_t)r * K + tid + 256 * c] += acc[c];
 }
 
-// RotatE: cos / sin of every relation phase, once per step (same cosf / sinf as prep_rel, so the tile pass sees the
+// RotatE: cos / sin of every relation phase, once per step, in the declared correctly rounded form (prep_rel_exact, kge_device.h); the tile pass sees the
 // very values the forward kernel used)
 __global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict__ rel, int64_t n_rels, int k, int K, ModelConst mc,
                                                         float* __restrict__ cs) {
@@ -720,7 +723,7 @@ __global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict_
     const int64_t r = idx / k;
     const int c = (int)(idx - r * k);
     float p[2] = {rel[r * K + c], 0.f};
-    prep_rel<AMDKGE_ROTATE>(mc, p);
+    prep_rel_exact<AMDKGE_ROTATE>(mc, p);
     cs[r * K + c] = p[0];
     cs[r * K + k + c] = p[1];
 }
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(256) void rel_phase_kernel(const float* __restrict_
 struct TiledPlan {
     int tile_rows, n_tiles, cap, ovf_cap, rb;
     int ns, sort_cap;   // deterministic mode: 5 staged rows per positive, LDS sort buffer entries (0 otherwise)
-    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, off_hot_map, off_hot_buf, off_codes, total;
+    size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, off_flag, off_hot_map, off_hot_buf, off_codes, total;
     bool own_cache;     // RotatE, queued form, >= 4 corruption entries per table row and step: own rows cached in LDS
     bool codes;         // TransE with one wave per positive: the forward kernel hands the signs of d_j to the tile pass (ENTRY_EXACT)
 };
@@ -792,10 +795,13 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
     p.off_loss = o; o += up((size_t)LOSS_PARTS * LOSS_PART_STRIDE * 8);   // first: the same place in every plan (kept zero between steps)
+    p.off_flag = o; o += 256;                                             // sticky status flag (amdkge_train_tiled_status): also plan-independent
     p.off_hot_map = o; o += up((size_t)m->n_ents);                        // hot-row map and replicas: also independent of B / eta / mode,
     p.off_hot_buf = o; o += up((size_t)HOT_MAX * HOT_REPL * K * 4);       // written by amdkge_train_tiled_set_hot_rows
     p.off_touch = o; o += up((size_t)m->n_ents);                          // byte per entity row (lazy optimizer + POS_ATOMIC), kept zero between steps
-    p.off_cnt = o; o += up((size_t)(p.n_tiles + 3) * 32 * 4);   // bucket fills, overflow count, finished-tiles ticket, det-sort overflow flag
+    // Everything from here on moves with the plan (n_tiles and cap depend on B through own_cache, the bucket capacity and the
+    // deterministic mode's LDS split): see plan_guard() for what keeps the counters of one plan safe from the lists of another.
+    p.off_cnt = o; o += up((size_t)(p.n_tiles + 2) * 32 * 4);   // bucket fills, overflow count, finished-tiles ticket
     p.off_lists = o; o += up((size_t)p.n_tiles * p.cap * sizeof(StageEntry));
     p.off_ovf = o; o += up((size_t)p.ovf_cap * sizeof(StageEntry));
     p.off_rows = o; o += up((size_t)B * p.ns * K * 4);
@@ -805,6 +811,28 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     p.off_codes = o; o += up(p.codes ? code_bytes : 0);
     p.total = o + 256;
     return true;
+}
+
+// One workspace serves steps of different batch sizes (fit() ends every epoch with a short batch), and the position of the
+// bucket lists depends on the plan: the lists and staged rows of one plan may lie where another plan keeps its counters.  A
+// plan's counters are zero when its step ends, so they only have to be re-zeroed when a step with a DIFFERENT geometry has
+// used the buffer in between.  The library remembers, per workspace address, the geometry of the last step enqueued on it and
+// clears the counter region on the step's stream when it changes (first sight of an address counts as a change; the
+// caller's zero-fill contract covers a buffer that is freed and re-allocated at the same address).
+static int plan_guard(const void* d_work, const TiledPlan& p, char* w, hipStream_t st) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, uint64_t> last;
+    const uint64_t sig = ((uint64_t)(uint32_t)p.n_tiles << 32) ^ ((uint64_t)p.off_cnt * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(uint32_t)p.cap;
+    bool changed;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = last.find(d_work);
+        changed = it == last.end() || it->second != sig;
+        if (changed) last[d_work] = sig;
+    }
+    if (changed)
+        if (hipError_t e = hipMemsetAsync(w + p.off_cnt, 0, (size_t)(p.n_tiles + 2) * 32 * 4, st)) return set_error_hip(e, "hipMemsetAsync(tile counters)");
+    return AMDKGE_OK;
 }
 
 template <int MODEL, int CH, int UNROLL>
@@ -915,6 +943,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     const int ks = stored_k(m), K = row_floats(m);
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    if (int rc = plan_guard(d_work, p, w, st)) return rc;
     int* counters = (int*)(w + p.off_cnt);
     StageEntry* lists = (StageEntry*)(w + p.off_lists);
     StageEntry* ovf = (StageEntry*)(w + p.off_ovf);
@@ -950,7 +979,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
 #ifdef KGE_ABLATE
     te.dbg = f.dbg;
 #endif
-    te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters;
+    te.triples = d_triples; te.stage_rows = stage_rows; te.lists = lists; te.ovf = ovf; te.counters = counters; te.status_flag = (int*)(w + p.off_flag);
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = ks; te.K = K; te.k_live = m->k; te.nq = ks / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.rb = p.rb; te.mc = f.mc;
     fill_opt_args(te.opt, opt);
@@ -998,7 +1027,7 @@ extern "C" int amdkge_train_tiled_status(const amdkge_model* m, int64_t B, int32
     TiledPlan p;
     if (!make_plan(m, B, eta, p, (flags & AMDKGE_TILED_DETERMINISTIC) != 0)) return set_error(AMDKGE_EUNSUPPORTED, "train_tiled_status: shape not supported");
     char* w = (char*)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
-    int* flag = (int*)(w + p.off_cnt) + (size_t)(p.n_tiles + 2) * 32;
+    int* flag = (int*)(w + p.off_flag);   // the same place whatever B / flags the flagged step ran with
     hipStream_t st = (hipStream_t)stream;
     if (hipError_t e = hipMemcpyAsync(status, flag, sizeof(int), hipMemcpyDeviceToHost, st)) return set_error_hip(e, "hipMemcpyAsync(status)");
     if (hipError_t e = hipStreamSynchronize(st)) return set_error_hip(e, "hipStreamSynchronize");

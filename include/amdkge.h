@@ -250,6 +250,15 @@ int64_t amdkge_rank_workspace_bytes(const amdkge_model* m, int64_t n);
  * kernel for DistMult / ComplEx / HolE, VALU tile kernel for TransE / RotatE), 1 = always the VALU tile kernel, 2 = the
  * first (un-pipelined) MFMA kernel.  All three produce the same bits; the parity tests compare them. */
 int amdkge_set_rank_kernel(int which);
+/* RotatE's per-unit modulus in the rank / filter / corruption-score kernels (process-wide, set before the calls it should apply to).
+ *   0 (default) = EXACT: cos / sin of the phase correctly rounded to fp32 (fp64 evaluation, one rounding) and the modulus a
+ *       correctly rounded fp32 square root, so the chain  acc = fl(acc + sqrt(fl(fl(re re) + fl(im im))))  over the live units in
+ *       table order is a function of the tables alone: filtered ranks are bit-identical to the CPU restatement of that chain
+ *       (oracle/csrc/rank_ordered.c).  Needs whole-float4 stored halves (k_pad = amdkge_padded_k(k), what the Python host
+ *       always uses); AMDKGE_EUNSUPPORTED otherwise.
+ *   1 = FAST: the hardware's 1-ulp v_sqrt_f32 (about 1.3x faster; ranks may differ from the exact mode only where a
+ *       quantised comparison at the int32(score * 1000) boundary is decided by the last bit of a modulus). */
+int amdkge_set_rank_rotate_fast(int fast);
 int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d_rel,
                        const int32_t* d_triples, int64_t n, int32_t side,
                        const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,

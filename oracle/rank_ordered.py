@@ -15,8 +15,11 @@ kernels differ).  This module fixes ONE order -- the one the HIP rank kernels de
   * the 1-vs-all corruption scores as one accumulator per (query, entity) walked in table order with a fused
     multiply-add (contraction models) or add-of-absolute-value (TransE) per unit: oracle/csrc/rank_ordered.c.
 
-RotatE is restated too, but its kernels use the hardware cos/sin/sqrt (1 ulp), so only the contraction models and
-TransE are bit-comparable; RotatE stays on the fragile-bounded comparison.
+  * RotatE (round 3): the phase theta / (embedding_range / pi) rounded to fp32 (RotatE.py:96), its cos and sin CORRECTLY
+    ROUNDED to fp32 (evaluated in fp64, rounded once -- libm here, ocml on the GPU: both well inside the 2^-29 relative
+    margin in which one more rounding could differ), the per-unit modulus a correctly rounded fp32 sqrtf of
+    fl(fl(re re) + fl(im im)), accumulated over the LIVE units in table order.  That is the kernels' exact mode (the
+    default; kge_rank.hip rank_rot_kernel, kge_device.h sqrt_rn / prep_rel_exact), so RotatE is bit-comparable too.
 """
 import ctypes as C
 import os
@@ -103,10 +106,10 @@ def prep(model, side, s, p, o, max_rel_size=None):
             Q = np.concatenate([(m(sr, pr) - m(si, pi)).astype(F32), (m(si, pr) + m(sr, pi)).astype(F32)], 1)
         scale = F32(2.0 / k) if model == "HolE" else F32(1.0)             # HolE.py:45
         return O.quantise(scale * pos), np.ascontiguousarray(Q), MODE_DOT, K, 0, scale
-    # RotatE (RotatE.py:96-104,151-160,209-214) -- not bit-comparable with the kernels (hardware cos / sin / sqrt)
+    # RotatE (RotatE.py:96-104,151-160,209-214): declared form = fp32 phase, correctly rounded cos / sin, correctly rounded sqrt
     div = O.rotate_phase_divisor(k, max_rel_size)
     phi = (pr / div).astype(F32)
-    c, sn = np.cos(phi).astype(F32), np.sin(phi).astype(F32)
+    c, sn = np.cos(phi.astype(np.float64)).astype(F32), np.sin(phi.astype(np.float64)).astype(F32)
     re = ((m(sr, c) - m(si, sn)).astype(F32) - orr).astype(F32)
     im = ((m(sr, sn) + m(si, c)).astype(F32) - oi).astype(F32)
     pos = _slot_sum(np.sqrt((m(re, re) + m(im, im)).astype(F32)).astype(F32))

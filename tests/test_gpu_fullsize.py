@@ -317,7 +317,9 @@ def test_table_beyond_2_31_elements(gpu_lib, model, k):
 @pytest.mark.parametrize("model,k,dataset,n_test", [("ComplEx", 200, "synth-fb15k237", None),     # C2: all 20 438 test triples
                                                       ("DistMult", 400, "synth-wn18rr", None),      # C3: all 2 924 test triples
                                                       ("HolE", 350, "synth-fb15k237", 3000),        # padded halves (350 -> 352)
-                                                      ("TransE", 50, "synth-fb15k237", 3000)])      # C1 shape, L1 chain
+                                                      ("TransE", 50, "synth-fb15k237", 3000),       # C1 shape, L1 chain
+                                                      ("RotatE", 200, "synth-fb15k237", None),      # all 20 438 triples, exact-mode modulus (round 3)
+                                                      ("RotatE", 50, "synth-fb15k237", 3000)])      # padded halves (50 -> 52): live units only
 def test_fullsize_filtered_ranks_bit_identical(gpu_lib, model, k, dataset, n_test):
     """"Identical filtered ranks" (BASELINE.json north_star) at full size on REAL-VALUED tables: the HIP path against the
     oracle's declared-order fp32 mode (oracle/rank_ordered.py: same rounding points, same accumulation order as
@@ -382,3 +384,75 @@ def test_fullsize_filtered_ranks_bit_identical(gpu_lib, model, k, dataset, n_tes
         assert np.array_equal(got, ranks(ora, strat, "s,o")), strat
     mrr_g, mrr_o = float(np.mean(1.0 / ranks(gpu, "worst", "s,o"))), float(np.mean(1.0 / ranks(ora, "worst", "s,o")))
     assert mrr_g == mrr_o
+
+
+def test_fullsize_rotate_c5_width_ranks_bit_identical(gpu_lib):
+    """RotatE at configs[4]'s row width (k = 1000: 8 000-byte rows, 1 000 relations) against 200 000 entities, 1 024 test triples,
+    both sides, filtered: counts, filter subtractions and ranks of the HIP path's exact mode == the declared-order oracle, bit
+    for bit; then the fast (1-ulp v_sqrt_f32) mode on the same inputs: equal or off by a handful of fragile comparisons."""
+    from oracle import rank_ordered as RO
+
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.datasets.filters import FilterIndex
+    from ampligraph_amd.engine import KgeEngine
+
+    N, R, k, n = 200_000, 1000, 1000, 1024
+    rng = np.random.default_rng(23)
+    ent = (rng.standard_normal((N, 2 * k), dtype=np.float32) * np.float32(0.05))
+    rel = (rng.standard_normal((R, 2 * k), dtype=np.float32) * np.float32(0.002))
+    train = np.stack([rng.integers(0, N, 300_000), rng.integers(0, R, 300_000), rng.integers(0, N, 300_000)], 1).astype(np.int32)
+    test = train[:n].copy()
+    test[n // 2:, 0] = rng.integers(0, N, n - n // 2)   # half of the test triples are in the filter set with their own (p, o) group
+    eng = KgeEngine("RotatE", k, N, R, max_rel_size=R)
+    eng.set_tables(ent, rel)
+    fi = FilterIndex([train, test], N, R)
+    Xd = torch.as_tensor(test).cuda()
+    exact = {}
+    for side, nm, rng_fn, ids in ((_ffi.SIDE_S, "s", fi.subject_ranges, fi.s_ids), (_ffi.SIDE_O, "o", fi.object_ranges, fi.o_ids)):
+        lo, hi = rng_fn(test)
+        flt = (torch.as_tensor(lo).cuda(), torch.as_tensor(hi).cuda(), torch.as_tensor(ids).cuda())
+        ranks, counts, sub = eng.rank_side(Xd, side, "worst", flt)
+        oc, ctx = RO.side_counts("RotatE", nm, ent, rel, test, R)
+        osub = RO.filter_sub(ctx, [ids[a:b] for a, b in zip(lo, hi)])
+        assert np.array_equal(counts.cpu().numpy(), oc), (nm, int((counts.cpu().numpy() != oc).sum()))
+        assert np.array_equal(sub.cpu().numpy(), osub), nm
+        assert np.array_equal(ranks.cpu().numpy(), oc.sum(1) - osub + 1), nm
+        assert len(np.unique(oc[:, 0])) > n // 4   # a real ranking problem
+        exact[nm] = (counts.cpu().numpy(), flt)
+    try:
+        _ffi.check(gpu_lib.amdkge_set_rank_rotate_fast(1))
+        for side, nm in ((_ffi.SIDE_S, "s"), (_ffi.SIDE_O, "o")):
+            c_fast = eng.rank_side(Xd, side, "worst", exact[nm][1])[1].cpu().numpy()
+            d = np.abs(c_fast.astype(np.int64) - exact[nm][0])
+            assert d.max() <= 3 and (d.sum(1) > 0).mean() < 0.2, (nm, int(d.max()), float((d.sum(1) > 0).mean()))
+    finally:
+        gpu_lib.amdkge_set_rank_rotate_fast(0)
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_fullsize_rotate_alternating_batch_sizes_share_one_workspace(gpu_lib, deterministic):
+    """fit() ends every epoch with a short batch.  For RotatE k = 200 on 14 505 entities the plan of the owner-computes pair
+    differs between B = 10 000 (own rows cached in LDS: twice the tiles) and the epoch's last 2 115 positives, so the bucket
+    lists of one plan lie where the other keeps its counters: every step of an alternating sequence on ONE engine
+    (one workspace) must still produce the gradients of the independent atomic-scatter kernel."""
+    model, k, eta, N, R = "RotatE", 200, 20, 14505, 237
+    eng = _engine(model, k, N, R)
+    ld = _loss("self_adversarial")
+    from ampligraph_amd import _ffi
+
+    opt = _ffi.Opt(_ffi.OPTIMIZERS["adam"], 2, 1e-3, 0.9, 0.999, 1e-7, 0.0, 1)
+    eng.prepare_training("adam")
+    for step, B in enumerate([10000, 2115, 10000, 2115, 300, 10000]):
+        X = _triples(B, N, R, seed=10 + step)
+        eng.g_flat.zero_()
+        eng.loss_acc.zero_()
+        eng.train_fwdbwd(X, eta, ld, 5, step)
+        l1, ge1, gr1 = float(eng.loss_acc[0]), eng.g_ent.clone(), eng.g_rel.clone()
+        eng.g_flat.zero_()
+        eng.loss_acc.zero_()
+        eng.train_step_tiled(X, eta, ld, opt, 5, step, grad_only=True, deterministic=deterministic)
+        torch.cuda.synchronize()
+        assert abs(l1 - float(eng.loss_acc[0])) <= 2e-5 * abs(l1), (step, B)
+        assert _rotate_rows_close(eng.g_ent, ge1, 2e-4) and _rows_close(eng.g_rel, gr1, 2e-4), (step, B)
+        if deterministic:
+            assert eng.tiled_status() == 0
