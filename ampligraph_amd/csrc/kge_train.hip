@@ -12,6 +12,8 @@
 // accumulated in registers per distinct row (s, p, o: one atomic row-add each per positive; every
 // replacement row: one atomic row-add) with hardware fp32 atomics into the dense gradient buffers.
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 // RotatE's modulus and its reciprocal in the TRAINING kernels use the hardware v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the
 // correctly rounded libm sequences: the fused kernels are bound by exactly these on RotatE (measured 1.26x on the step);
@@ -44,16 +46,23 @@ __global__ void loss_fold_kernel(double* parts, double* loss_sum) {
     fold_loss_parts(parts, loss_sum, threadIdx.x);   // one wave
 }
 
-// per-device scratch of the atomic path (it has no workspace argument): LOSS_PARTS partial sums, zero between calls
-static double* loss_parts_of_current_device() {
-    static double* parts[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!parts[dev]) {
-        if (hipMalloc((void**)&parts[dev], (size_t)LOSS_PARTS * LOSS_PART_STRIDE * sizeof(double)) != hipSuccess) { parts[dev] = nullptr; return nullptr; }
-        if (hipMemset(parts[dev], 0, (size_t)LOSS_PARTS * LOSS_PART_STRIDE * sizeof(double)) != hipSuccess) return nullptr;
-    }
-    return parts[dev];
+// Scratch of the atomic path (it has no workspace argument): LOSS_PARTS partial sums, zero between calls.  One buffer per LOSS
+// ACCUMULATOR (keyed by d_loss_sum): two engines or sessions that train on different streams of one GPU have their own
+// accumulators, hence their own partials -- a buffer shared per device let their kernels and fold launches mix sums
+// (ADVICE r2).  Calls that share an accumulator are ordered by their caller anyway.  Thread-safe; the few hundred bytes per
+// accumulator live until the process ends.
+static double* loss_parts_for(const void* d_loss_sum) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, double*> parts;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = parts.find(d_loss_sum);
+    if (it != parts.end()) return it->second;
+    double* p = nullptr;
+    const size_t bytes = (size_t)LOSS_PARTS * LOSS_PART_STRIDE * sizeof(double);
+    if (hipMalloc((void**)&p, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    parts.emplace(d_loss_sum, p);
+    return p;
 }
 
 template <int MODEL, int VEC, int W>
@@ -157,7 +166,7 @@ extern "C" int amdkge_train_fwdbwd(const amdkge_model* m, const amdkge_loss* los
     { const char* e = getenv("AMDKGE_DEBUG"); a.dbg = e ? atoi(e) : 0; }
 #endif
     hipStream_t st = (hipStream_t)stream;
-    a.loss_parts = loss_parts_of_current_device();
+    a.loss_parts = loss_parts_for(d_loss_sum);
     if (!a.loss_parts) return set_error(AMDKGE_ENOMEM, "train: cannot allocate the loss scratch");
     int rc;
     switch (m->scoring_type) {

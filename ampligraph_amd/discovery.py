@@ -74,8 +74,7 @@ def query_topn(model, top_n=10, head=None, relation=None, tail=None, ents_to_con
         cand_ids = np.asarray(ix.get_indexes(np.asarray(ents_to_consider), "e"), dtype=np.int64)
     n_cand = model._n_ents if cand_ids is None else len(cand_ids)
     n = min(int(top_n), n_cand)
-    if n > 1024:
-        raise ValueError("query_topn: top_n is limited to 1024 on the device path")
+    # (top_n > 1024: engine.topk_rows sorts the whole score row on the device instead of the streaming selection)
     if sp is None:
         ids_dev = None if cand_ids is None else torch.as_tensor(cand_ids.astype(np.int32)).to(dev)
         pos, val = eng.corruption_topk(torch.as_tensor(q).to(dev), side, n, ent_ids=ids_dev)
@@ -92,7 +91,7 @@ def query_topn(model, top_n=10, head=None, relation=None, tail=None, ents_to_con
         else:
             loc = sp.local_subset(torch.as_tensor(cand_ids).to(dev))[0]
             n_loc = int(loc.shape[0])
-        k_loc = min(n, 1024)
+        k_loc = n
         gid = torch.full((1, k_loc), -1, dtype=torch.int32, device=dev)
         gval = torch.full((1, k_loc), float("-inf"), dtype=torch.float32, device=dev)
         if n_loc > 0:

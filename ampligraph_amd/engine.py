@@ -285,6 +285,12 @@ class KgeEngine:
                                           _ptr(xl), _ptr(nl), _ptr(send_ids), _ptr(counts), _ptr(work), _stream()))
         return xl, nl, send_ids, counts
 
+    def zero_route_overflow(self):
+        """Clear the sticky overflow flag of shard_route (counts[world]); stream-ordered."""
+        counts = self._bufs.get("route_counts")
+        if counts is not None:
+            self.zero_(counts[-1:])
+
     def gather_rows(self, table, idx, name="gathered"):
         """rows table[idx] (idx < 0: zero rows) into a reusable [n, Ks] buffer (amdkge_gather_rows)."""
         n = int(idx.shape[0])
@@ -369,6 +375,23 @@ class KgeEngine:
         """(idx int32 [n,k], val fp32 [n,k]) of the k best entries per row of vals [n,m] (amdkge_topk_rows); with `payload`
         (int32, same shape and row stride as vals) idx holds the payload entries of the selected columns."""
         n, m = int(vals.shape[0]), int(vals.shape[1])
+        if int(k) > 1024:
+            # beyond the streaming selection's k: a full stable sort of the (scaled) row on the device, which is what the
+            # reference does for every top_n (argsort over all candidates, discovery.py:1150-1160); same order rule as the
+            # kernel (best first, equal values by increasing column), missing entries (m < k) as index -1 / -inf
+            v = vals.to(torch.float32)
+            if col_scale is not None:
+                v = v * col_scale[None, :m]
+            if col_bias is not None:
+                v = v + col_bias[None, :m]
+            sv, si = torch.sort(v, dim=1, descending=bool(largest), stable=True)
+            kk = min(int(k), m)
+            idx = torch.full((n, int(k)), -1, dtype=torch.int32, device=self.device)
+            val = torch.full((n, int(k)), float("-inf") if largest else float("inf"), dtype=torch.float32, device=self.device)
+            sel = si[:, :kk]
+            idx[:, :kk] = (sel if payload is None else torch.gather(payload[:, :m].to(torch.int64), 1, sel)).to(torch.int32)
+            val[:, :kk] = sv[:, :kk]
+            return idx, val
         idx = torch.empty(n, int(k), dtype=torch.int32, device=self.device)
         val = torch.empty(n, int(k), dtype=torch.float32, device=self.device)
         check(self.lib.amdkge_topk_rows(_ptr(vals), n, m, int(vals.stride(0)), _ptr(col_scale), _ptr(col_bias), _ptr(payload), int(k), 1 if largest else 0,

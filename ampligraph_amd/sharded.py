@@ -145,24 +145,28 @@ class ShardedStepLoop:
             optimizer.bind(engine)   # get_weights() / set_weights() of the wrapper read and write the engine's state tensors
 
     @staticmethod
-    def peer_capacity(batch_per_rank, eta, negatives, world=1, n_ents=None):
-        """Request slots per peer.  Worst case = every id of the rank's share is remote, distinct and owned by ONE peer;
-        with more than two ranks the lists are sized at AMDKGE_SHARD_CAP_FACTOR (default 2) times the even split instead
-        (ids spread over the owners; an overflow is detected on the device and reported, never silent)."""
+    def peer_capacity(batch_per_rank, eta, negatives, world=1, n_ents=None, cap_factor=None):
+        """Request slots per peer.  Default = the WORST case for every world size: every id of the rank's share remote, distinct
+        and owned by ONE peer (bounded by the rows a peer owns).  That case is ordinary, not pathological: ids are numbered
+        first-seen and batches are sequential slices of the training set (graph_data_loader.py:472-523), so the early batches
+        of an epoch hold almost only low ids, all owned by rank 0.  cap_factor (or AMDKGE_SHARD_CAP_FACTOR) sizes the
+        lists at that multiple of the even split instead -- for id streams that are uniform by construction (bench.py's
+        synthetic graphs), where it saves wire bytes; an overflow is then detected on the device and raised at the epoch's end."""
         import os
 
         worst = int(batch_per_rank) * (2 + (int(eta) if negatives == "global" else 0))
         if n_ents is not None:
             worst = min(worst, -(-int(n_ents) // int(world)))
-        if world <= 2:
+        if cap_factor is None and "AMDKGE_SHARD_CAP_FACTOR" in os.environ:
+            cap_factor = float(os.environ["AMDKGE_SHARD_CAP_FACTOR"])
+        if world <= 2 or cap_factor is None:
             return max(1, worst)
-        factor = float(os.environ.get("AMDKGE_SHARD_CAP_FACTOR", "2.0"))
-        return max(1, min(worst, int(factor * worst / world) + 64))
+        return max(1, min(worst, int(float(cap_factor) * worst / world) + 64))
 
     @staticmethod
-    def rows_needed(batch_per_rank, eta, negatives, world=1, n_ents=None):
+    def rows_needed(batch_per_rank, eta, negatives, world=1, n_ents=None, cap_factor=None):
         """Scratch rows one step needs behind the shard: `world` peer lists of peer_capacity rows."""
-        return int(world) * ShardedStepLoop.peer_capacity(batch_per_rank, eta, negatives, world, n_ents)
+        return int(world) * ShardedStepLoop.peer_capacity(batch_per_rank, eta, negatives, world, n_ents, cap_factor)
 
     def step(self, global_batch, rng_step, focus=None):
         """focus: None or (w fp32 device tensor [Bg], beta, non-linearity name) -- FocusE, as trainer.StepLoop.step."""
@@ -208,7 +212,10 @@ class ShardedStepLoop:
             kw = dict(row_offset=lo, b_global=bg, neg_override=nl)
             if nl is None:   # shard-local negatives: replacement rows are local rows [0, n_local)
                 kw.update(sample_base=0, sample_range=sp.n_local)
-            if (self.use_tiled or self.deterministic) and eng.tiled_supported(b, self.eta):
+            tiled = (self.use_tiled or self.deterministic) and eng.tiled_supported(b, self.eta)
+            if self.deterministic and not tiled:   # as trainer.StepLoop: never a silent fall-back to the atomic path
+                raise ValueError("deterministic mode needs the owner-computes train path (k <= 2048)")
+            if tiled:
                 if self.deterministic:
                     kw["deterministic"] = True
                 eng.train_step_tiled(xl, self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step, grad_only=True, **kw)
@@ -237,11 +244,14 @@ class ShardedStepLoop:
     def reset_loss(self):
         self.engine.loss_acc.zero_()
         self.n_steps = 0
+        if self._route_counts is not None:
+            self.engine.zero_route_overflow()   # the sticky device flag: a new epoch starts clean
 
     def mean_batch_loss(self):
         """Data loss and the entity-shard regulariser parts are summed over ranks; the relation-table
         regulariser part is identical on every rank and counted once."""
         if self._route_counts is not None and int(self._route_counts[self.world].item()) != 0:
+            self.engine.zero_route_overflow()   # sticky since the step that overflowed; reported once
             raise RuntimeError(f"row-sharded step: a peer's request list overflowed its {self.cap_peer} slots (skewed ids?); "
                                "results of this epoch are invalid -- raise AMDKGE_SHARD_CAP_FACTOR or the scratch capacity")
         acc = self.engine.loss_acc.clone()

@@ -10,8 +10,12 @@ then the per-tile LDS accumulation kernel that also applies Adam to both tables)
 in its gradient-only form + the data-parallel merge over RCCL/xGMI (reduce-scatter by all_to_all, sharded
 optimizer sweep, all_to_all of the updated parameter slices; AMDKGE_DP_MERGE=allreduce for one all-reduce).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run
-(one rank per GPU).  Rank 0 prints ONE JSON line.  Extra objects: `roofline` (the train-step kernel pair,
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N>1 the driver launches it under torch.distributed.run (one
+rank per GPU); started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the script launches its own N ranks
+the same way and fails loudly when the node has fewer than N GPUs (AMDKGE_BENCH_BACKEND=gloo: development, N ranks on the GPUs
+there are).  Rank 0 prints ONE JSON line.  The timed region contains nothing but the K calls of the step (no event records):
+it is repeated --reps times (each bracketed by barrier + synchronize, max over ranks) and `ms_per_step` / `value` are the
+MEDIAN repetition; the per-phase HIP events are recorded in a separate, untimed pass of the same steps.  Extra objects: `roofline` (the train-step kernel pair,
 HBM-bound, algorithmic bytes 2*(3+eta)*4K per positive; duration = HIP events on the launch
 stream around the pair, i.e. the sum of the two kernels' durations + one launch gap), `cpu_baseline`
 (oracle/ref_cpu.py, the op-for-op torch-CPU port, on a bounded sample) and `eval` (filtered
@@ -71,6 +75,8 @@ def parse():
     ap.add_argument("--skew-mode", default="auto", choices=["auto", "none", "atomic", "hot"],
                     help="development: how the positives' own rows of hot entities are handled (auto = configure_for_data decides; none = all "
                          "staged; atomic = AMDKGE_TILED_POS_ATOMIC; hot = replica rows for the hot entities only)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region; the median is reported (min / max beside it)")
+    ap.add_argument("--phase-steps", type=int, default=32, help="steps of the separate, untimed pass that records the per-phase HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -159,16 +165,42 @@ def eval_bench(eng, data, rank):
             "mrr_untrained_tables": float(np.mean(1.0 / r)), "note": "tables as left by the timed training steps"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (what the
+    driver's own command line does) and pass their output through.  One rank per GPU: a node with fewer than N GPUs is an
+    error, not a silent one-GPU run (AMDKGE_BENCH_BACKEND=gloo lifts that for development: ranks share the GPUs there are)."""
+    import socket
+    import subprocess
+
+    backend = os.environ.get("AMDKGE_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {have} GPU(s); one rank per GPU is required "
+                         "(AMDKGE_BENCH_BACKEND=gloo runs several ranks per GPU for development)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # AMDKGE_BENCH_BACKEND=gloo (development): several ranks on ONE GPU, collectives through the host -- exercises the
     # multi-rank code path of this script on a single-GPU box; the driver's runs use nccl (= RCCL over xGMI)
     backend = os.environ.get("AMDKGE_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: no GPU for LOCAL_RANK={local_rank} ({torch.cuda.device_count()} visible); one rank per GPU")
     dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dist = None
@@ -219,7 +251,9 @@ def main():
 
         negs = args.parallelism.split("-")[1]
         spec = ShardSpec(N, world, rank)
-        cap = ShardedStepLoop.rows_needed(args.batch, args.eta, negs, world, N)
+        # the synthetic graphs are uniform over the ids BY CONSTRUCTION: request lists at twice the even split (the product's
+        # default is the worst case, right for first-seen ids in sequential batches; --popularity zipf keeps it)
+        cap = ShardedStepLoop.rows_needed(args.batch, args.eta, negs, world, N, cap_factor=2.0 if args.popularity == "uniform" else None)
         eng = KgeEngine(args.model, args.k, spec.n_local + cap, R, max_rel_size=R)
         fill_rows(eng, spec.lo, spec.hi)
         eng.pack(rel0, out=eng.rel)
@@ -256,47 +290,72 @@ def main():
         def batch_of(step):   # triples [step * Bg, (step + 1) * Bg) of the 500 M-triple stream, generated in place (one launch)
             return eng.synth_triples(0, step * Bg, Bg, N, R, out=stream_buf)
 
-    phases = list(loop.PHASES)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(phases) + 1)] for _ in range(args.steps)]
-    cur = {"i": None}
-
-    def hook(i):   # HIP events on the stream the kernels are launched on (torch's current stream), at the phase boundaries
-        if cur["i"] is not None:
-            ev[cur["i"]][i].record()
-
     # N > 1, replicated tables: which gradient-merge schedule is fastest depends on the fabric -- measure the candidates
     # on this node first (ordinary training steps, before the warmup; AMDKGE_DP_MERGE pins one instead)
     tuned = 0
     if world > 1 and not sharded and "AMDKGE_DP_MERGE" not in os.environ and not opt.lazy:
         tuned = loop.tune_merge(batch_of, 0)
-    loop.kernel_hook = hook
+    loop.kernel_hook = None
     loop.reset_loss()
-    for s in range(tuned, tuned + args.warmup):
-        loop.step(batch_of(s), s)
-    torch.cuda.synchronize()
+    nxt = tuned
+    for _ in range(args.warmup):
+        loop.step(batch_of(nxt), nxt)
+        nxt += 1
+    # ---- timed: `reps` repetitions of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides; nothing but
+    #      the step calls inside (no event records, no host reads); max over ranks per repetition, median repetition reported
+    rep_s = []
+    for _ in range(max(1, args.reps)):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _s in range(args.steps):
+            loop.step(batch_of(nxt), nxt)
+            nxt += 1
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        rep_s.append(time.perf_counter() - t0)
+    rank_ms = [float(np.median(rep_s)) / max(1, args.steps) * 1e3]   # this rank's median, before the max over ranks
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        cur["i"] = s
-        loop.step(batch_of(tuned + args.warmup + s), tuned + args.warmup + s)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    cur["i"] = None
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor(rep_s, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        rep_s = [float(x) for x in t.tolist()]
+        rk = torch.zeros(world, dtype=torch.float64, device="cuda")
+        rk[rank] = rank_ms[0]
+        dist.all_reduce(rk)
+        rank_ms = [float(x) for x in rk.tolist()]
+    dt = float(np.median(rep_s))
     loss_mean = loop.mean_batch_loss()
 
-    phase_ms = {nm: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i, nm in enumerate(phases)} if args.steps else {}
+    # ---- untimed: the per-phase split, HIP events on the stream the kernels are launched on (torch's current stream) at
+    #      the phase boundaries of the same step (single GPU: the kernel pair IS the step -- one phase)
+    phases = list(loop.PHASES) if (world > 1 or sharded) else ["kernels"]
+    n_ph = max(1, min(args.phase_steps, args.steps)) if args.steps else 0
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(loop.PHASES) + 1)] for _ in range(n_ph)]
+    cur = {"i": None}
+
+    def hook(i):
+        if cur["i"] is not None:
+            ev[cur["i"]][i].record()
+
+    loop.kernel_hook = hook
+    for i in range(n_ph):
+        cur["i"] = i
+        loop.step(batch_of(nxt), nxt)
+        nxt += 1
+    cur["i"] = None
+    loop.kernel_hook = None
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    phase_ms = {nm: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i, nm in enumerate(phases)} if n_ph else {}
     kern_ms = phase_ms.get("kernels", float("nan"))
     if rank == 0:
         triples = float(world) * B * (1 + args.eta) * args.steps
+        backend_world = dist.get_world_size() if world > 1 else 1
         bytes_per_pos = 2.0 * (3 + args.eta) * 4.0 * eng.K   # each distinct row read once + its gradient written once
         achieved = bytes_per_pos * B / (kern_ms * 1e-3) / 1e9
         # PMC traffic cannot be collected inside this process (rocprofv3 wraps the command): the figure below is REPLAYED from
@@ -329,9 +388,13 @@ def main():
         out = {
             "metric": ("training triples/sec (incl. negatives), ComplEx k=200 eta=20 FB15K-237-shaped" if headline
                        else f"training triples/sec (incl. negatives), {args.model} k={args.k} eta={args.eta} {args.dataset}"),
-            "value": triples / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": triples / dt, "unit": "triples/s", "n_gpus": backend_world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # the timed K-step region is repeated; value / ms_per_step are the median repetition (max over ranks each)
+            "repetitions": len(rep_s), "ms_per_step_min": min(rep_s) / args.steps * 1e3, "ms_per_step_max": max(rep_s) / args.steps * 1e3,
+            "ranks": {"backend": backend if world > 1 else None, "world": backend_world, "gpus_visible": torch.cuda.device_count(),
+                      "ms_per_step_rank_min": min(rank_ms), "ms_per_step_rank_max": max(rank_ms)},
             "config": {"workload": f"{args.dataset} ({args.popularity}, seed 0) {args.model} k={args.k} eta={args.eta} "
                                    f"{args.loss} adam lr=1e-3, {B} positives/GPU/step, tables resident in HBM, {opt_txt}",
                        "preset": args.preset, "optimizer_mode": args.optimizer_mode, "deterministic": bool(loop.deterministic),
@@ -347,6 +410,8 @@ def main():
                          "optimizer_bytes_per_launch": opt_bytes,
                          "frac_incl_optimizer": ((bytes_per_pos * B + opt_bytes) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                  if opt_bytes is not None and tiled else None),
+                         "kernel_ms_source": f"HIP events on the launch stream around the pair, mean of {n_ph} steps recorded right after "
+                                             "the timed repetitions (same workload, same process; the timed region itself holds no event records)",
                          "note": "launch = one train step's kernel pair (HIP events on the launch stream around both); "
                                  "single GPU: the pair also applies the optimizer (7*4K*(N+R) B/step dense), which is NOT counted "
                                  "in the algorithmic bytes; traffic = L2<->fabric bytes (PMC, Infinity-Cache hits included)"},

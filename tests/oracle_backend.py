@@ -79,6 +79,10 @@ class OracleEngine:
             self._route_counts[W] |= counts[W]
         return xl, nl, send_ids, self._route_counts
 
+    def zero_route_overflow(self):
+        if hasattr(self, "_route_counts"):
+            self._route_counts[-1] = 0
+
     def gather_rows(self, table, idx, name="gathered"):
         i = idx.to(torch.int64)
         out = table[i.clamp(min=0)].clone()

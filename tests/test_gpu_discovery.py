@@ -10,7 +10,8 @@ from test_gpu_kernels import dev, make_engine, rand_triples
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,m,k", [(3, 10, 4), (5, 14505, 10), (2, 100000, 1024), (4, 7, 7), (1, 3, 5), (6, 5000, 100)])
+@pytest.mark.parametrize("n,m,k", [(3, 10, 4), (5, 14505, 10), (2, 100000, 1024), (4, 7, 7), (1, 3, 5), (6, 5000, 100),
+                                   (2, 5000, 3000), (2, 1500, 2000)])   # k > 1024: the full-sort path (any top_n, like the reference)
 @pytest.mark.parametrize("largest", [True, False])
 def test_topk_rows_against_numpy(gpu_lib, n, m, k, largest):
     eng, _, _ = make_engine("DistMult", 4, 8, 3)
@@ -139,6 +140,27 @@ def _check_discovery(m, X):
 def test_discovery_surface_single_gpu(gpu_lib):
     m, X = _fit_model()
     _check_discovery(m, X)
+
+
+def test_query_topn_beyond_1024(gpu_lib):
+    """top_n larger than the streaming selection's 1024: the reference accepts any top_n (argsort over all candidates,
+    discovery.py:985-1168); ours must too, with the same order as brute force over predict()."""
+    from ampligraph_amd.discovery import query_topn
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel
+
+    rng = np.random.default_rng(5)
+    N, R = 3000, 3
+    X = np.stack([rng.permutation(N), rng.integers(0, R, N), rng.permutation(N)], 1)
+    X = np.char.add(np.array(["e", "r", "e"]), X.astype(str))
+    m = ScoringBasedEmbeddingModel(eta=2, k=8, scoring_type="DistMult", seed=1)
+    m.compile(optimizer="adam", loss="nll")
+    m.fit(X, batch_size=1000, epochs=1, verbose=False)
+    ents = np.unique(np.concatenate([X[:, 0], X[:, 2]]))
+    Y, S = query_topn(m, top_n=2500, head="e7", relation="r1")
+    sc = m.predict(np.stack([np.full(len(ents), "e7"), np.full(len(ents), "r1"), ents], 1))
+    assert Y.shape == (2500, 3) and len(set(Y[:, 2])) == 2500
+    assert np.allclose(S, np.sort(sc)[::-1][:2500], rtol=1e-5, atol=1e-6) and (np.diff(S) <= 0).all()
+    assert np.allclose(m.predict(Y), S, rtol=1e-5, atol=1e-6)
 
 
 def test_discovery_surface_row_sharded(gpu_lib):

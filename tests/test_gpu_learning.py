@@ -21,10 +21,12 @@ EPOCHS, BATCH, ETA, K, LR = 40, 1024, 5, 16, 2e-2
 # kernels.  The bars below are the measured drift with headroom, and the early epochs are held tight.
 CASES = [("ComplEx", "multiclass_nll", 1e-4, 1e-4, 2e-3, 0.15), ("DistMult", "self_adversarial", 1e-4, 1e-4, 2e-3, 0.05),
          ("TransE", "nll", 2e-3, 5e-5, 1.5e-2, 0.15), ("TransE", "pairwise", 2e-2, 2e-3, 1.5e-2, 0.15),
-         # round 3: the two remaining models.  HolE = ComplEx's score scaled by 2/k; RotatE's training kernels take the modulus
-         # and its reciprocal from v_sqrt_f32 / v_rcp_f32 (1 ulp) -- smooth away from |z| = 0, held to the same bars
-         ("HolE", "self_adversarial", 1e-4, 1e-4, 2e-3, 0.05), ("RotatE", "self_adversarial", 1e-4, 1e-4, 2e-3, 0.05),
-         ("RotatE", "nll", 1e-4, 1e-4, 2e-3, 0.05)]
+         # round 3: the two remaining models.  HolE = ComplEx's score scaled by 2/k: same bars (measured 1e-5 / 4e-4 MRR).  RotatE's
+         # gradient z / |z| is ill-conditioned where a unit's modulus is ~0 (no epsilon, RotatE.py:102-104), so fp32 trajectories
+         # part slowly: measured on MI355X vs the fp64-accumulating oracle 2.4e-5 .. 1.3e-4 in the loss after 160 Adam steps,
+         # 8e-4 .. 1.6e-3 in MRR (inside the north_star's +-0.002); first 5 epochs within 5e-7.  Loss bar = measured x 4.
+         ("HolE", "self_adversarial", 1e-4, 1e-4, 2e-3, 0.05), ("RotatE", "self_adversarial", 5e-4, 1e-5, 2e-3, 0.05),
+         ("RotatE", "nll", 5e-4, 1e-5, 2e-3, 0.05)]
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
