@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AMDKGE_LIB") or os.path.join(_HERE, "lib", "libamdkge.so")   # AMDKGE_LIB: development builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums of include/amdkge.h
 SCORING_TYPES = {"TransE": 0, "DistMult": 1, "ComplEx": 2, "HolE": 3, "RotatE": 4}
@@ -51,7 +51,10 @@ class Loss(C.Structure):
 class Opt(C.Structure):
     _fields_ = [("kind", C.c_int32), ("reg_p", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("epsilon", C.c_float), ("reg_lambda", C.c_float), ("iteration", C.c_int64),
-                ("lazy", C.c_int32), ("row_floats", C.c_int32)]
+                ("lazy", C.c_int32), ("row_floats", C.c_int32),
+                # ABI 3: second LP term of the swept table; the relation table's terms where one call sweeps both
+                ("reg2_p", C.c_int32), ("reg2_lambda", C.c_float), ("rel_reg_p", C.c_int32), ("rel_reg2_p", C.c_int32),
+                ("rel_reg2_lambda", C.c_float)]
 
 
 class SessionConfig(C.Structure):

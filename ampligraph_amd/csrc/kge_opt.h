@@ -14,6 +14,10 @@ struct OptArgs {
     double* reg_loss;
     float lr, lr_t, beta1, beta2, omb1, omb2, eps, lam;
     int kind, reg_p;
+    // second LP term of the same table (Keras l1_l2): gradient weight lam2, value weight relative to the first term
+    // (the sweeps accumulate sum |x|^p + ratio2 * |x|^p2 and scale by lam once at the end); lam2 == 0: none
+    float lam2, ratio2;
+    int reg_p2;
     int lazy, row_floats;   // touched-rows mode (include/amdkge.h, amdkge_opt.lazy)
 };
 
@@ -31,6 +35,10 @@ __device__ __forceinline__ void opt_elem(const OptArgs& a, float& x, float g, fl
         reg_acc += ipowf(ax, a.reg_p);
         const float sg = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
         g += a.lam * (float)a.reg_p * ipowf(ax, a.reg_p - 1) * sg;
+        if (a.lam2 != 0.f) {
+            reg_acc += a.ratio2 * ipowf(ax, a.reg_p2);
+            g += a.lam2 * (float)a.reg_p2 * ipowf(ax, a.reg_p2 - 1) * sg;
+        }
     }
     if constexpr (KIND == AMDKGE_OPT_ADAM) {
         s0 = s0 * a.beta1 + g * a.omb1;
@@ -160,12 +168,20 @@ __device__ __forceinline__ float opt_sweep_rows(const OptArgs& a, int64_t first_
     return reg_acc;
 }
 
+// regulariser terms of one table -> OptArgs.  The kernels key everything on lam != 0, so a lone second term becomes the first.
+inline void set_reg_terms(OptArgs& a, int p1, float lam1, int p2, float lam2) {
+    if (lam1 == 0.f && lam2 != 0.f) { p1 = p2; lam1 = lam2; lam2 = 0.f; }
+    a.lam = lam1; a.reg_p = p1; a.lam2 = lam2; a.reg_p2 = p2;
+    a.ratio2 = (lam2 != 0.f) ? (float)((double)lam2 / (double)lam1) : 0.f;
+}
+
 // host-side: fill the derived fields of OptArgs from the ABI descriptor
 inline void fill_opt_args(OptArgs& a, const amdkge_opt* opt) {
     a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->epsilon;
     a.omb1 = (float)(1.0 - (double)opt->beta1);   // python: 1 - beta_1, cast to fp32 like the TF constant
     a.omb2 = (float)(1.0 - (double)opt->beta2);
-    a.lam = opt->reg_lambda; a.kind = opt->kind; a.reg_p = opt->reg_p;
+    a.kind = opt->kind;
+    set_reg_terms(a, opt->reg_p, opt->reg_lambda, opt->reg2_p, opt->reg2_lambda);
     a.lazy = opt->lazy ? 1 : 0; a.row_floats = opt->row_floats;
     const double t = (double)opt->iteration;
     if (opt->kind == AMDKGE_OPT_ADAMAX) a.lr_t = (float)((double)opt->lr / (1.0 - pow((double)opt->beta1, t)));
@@ -177,6 +193,9 @@ inline int validate_opt(const amdkge_opt* opt) {
     if (opt->kind < AMDKGE_OPT_SGD || opt->kind > AMDKGE_OPT_ADAMAX) return set_error(AMDKGE_EINVAL, "unknown optimizer kind");
     if (opt->iteration < 1) return set_error(AMDKGE_EINVAL, "optimizer iteration is 1-based");
     if (opt->reg_lambda != 0.f && opt->reg_p < 1) return set_error(AMDKGE_EINVAL, "regulariser p must be >= 1");
+    if (opt->reg2_lambda != 0.f && opt->reg2_p < 1) return set_error(AMDKGE_EINVAL, "regulariser p (second term) must be >= 1");
+    if (opt->rel_reg2_lambda != 0.f && opt->rel_reg2_p < 1) return set_error(AMDKGE_EINVAL, "relation regulariser p (second term) must be >= 1");
+    if (opt->rel_reg_p < 0) return set_error(AMDKGE_EINVAL, "rel_reg_p must be 0 (= reg_p) or >= 1");
     if (opt->lazy && (opt->row_floats < 4 || opt->row_floats % 4 != 0))
         return set_error(AMDKGE_EINVAL, "lazy optimizer mode needs row_floats = amdkge_row_floats(model) of a padded layout (multiple of 4)");
     return AMDKGE_OK;

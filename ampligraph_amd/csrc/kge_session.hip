@@ -238,6 +238,8 @@ extern "C" int amdkge_session_train_step(amdkge_session* s, const int32_t* tripl
         KGE_RC(amdkge_opt_step(&opt, s->tab[0], s->g_ent, s->tab[2], s->tab[3], m->n_ents * (int64_t)s->Ks, s->acc + 1, s->st));
         amdkge_opt orel = opt;
         orel.reg_lambda = s->cfg.rel_reg_lambda;
+        if (opt.rel_reg_p > 0) orel.reg_p = opt.rel_reg_p;
+        orel.reg2_p = opt.rel_reg2_p; orel.reg2_lambda = opt.rel_reg2_lambda;
         KGE_RC(amdkge_opt_step(&orel, s->tab[1], s->g_rel, s->tab[4], s->tab[5], m->n_rels * (int64_t)s->Ks, s->acc + 1, s->st));
     }
     double h[2] = {0.0, 0.0};

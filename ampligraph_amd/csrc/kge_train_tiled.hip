@@ -993,7 +993,8 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     if (rel_here) {
         te.rel_opt = te.opt;
         te.rel_opt.x = d_rel; te.rel_opt.g = d_grad_rel; te.rel_opt.s0 = d_rel_slot0; te.rel_opt.s1 = d_rel_slot1;
-        te.rel_opt.n = (int64_t)m->n_rels * K; te.rel_opt.reg_loss = d_reg_loss; te.rel_opt.lam = rel_reg_lambda;
+        te.rel_opt.n = (int64_t)m->n_rels * K; te.rel_opt.reg_loss = d_reg_loss;
+        set_reg_terms(te.rel_opt, opt->rel_reg_p > 0 ? opt->rel_reg_p : opt->reg_p, rel_reg_lambda, opt->rel_reg2_p, opt->rel_reg2_lambda);
         if (fuse_rel) {
             const int64_t n4 = (te.rel_opt.n + 3) / 4;
             te.rel_blocks = (int)((n4 + TILE_THREADS - 1) / TILE_THREADS < 64 ? (n4 + TILE_THREADS - 1) / TILE_THREADS : 64);
@@ -1016,6 +1017,8 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     if (rc != AMDKGE_OK || !rel_here || fuse_rel) return rc;
     amdkge_opt ro = *opt;
     ro.reg_lambda = rel_reg_lambda;
+    if (opt->rel_reg_p > 0) ro.reg_p = opt->rel_reg_p;
+    ro.reg2_p = opt->rel_reg2_p; ro.reg2_lambda = opt->rel_reg2_lambda;
     ro.row_floats = K;
     return amdkge_opt_step(&ro, d_rel, d_grad_rel, d_rel_slot0, d_rel_slot1, (int64_t)m->n_rels * K, d_reg_loss, stream);
 }

@@ -21,6 +21,29 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def reg_fields(reg, default_p):
+    """Regulariser argument of the engine's step / sweep calls -> (p1, lambda1, p2, lambda2) for the amdkge_opt descriptor.
+    `reg`: None / a number (lambda of ONE LP term whose p the descriptor already carries: the form the kernel tests and
+    older callers use) or an object with `.terms` = [(p, lambda), ...] (latent_features.regularizers.LPRegularizer: one
+    term, or two for Keras' l1_l2)."""
+    if reg is None:
+        return int(default_p), 0.0, int(default_p), 0.0
+    if isinstance(reg, (int, float)):
+        return int(default_p), float(reg), int(default_p), 0.0
+    t = list(reg.terms)[:2]
+    while len(t) < 2:
+        t.append((int(default_p), 0.0))
+    return int(t[0][0]), float(t[0][1]), int(t[1][0]), float(t[1][1])
+
+
+def _same_reg(a, b, default_p):
+    return reg_fields(a, default_p) == reg_fields(b, default_p)
+
+
+def _set_reg(opt_desc, reg, default_p):
+    opt_desc.reg_p, opt_desc.reg_lambda, opt_desc.reg2_p, opt_desc.reg2_lambda = reg_fields(reg, default_p)
+
+
 class KgeEngine:
     def __init__(self, scoring_type, k, n_ents, n_rels, max_rel_size=None, device=None, pad=True):
         """pad=True (the product's setting): tables are STORED with each half padded to a multiple of 4 units
@@ -186,12 +209,17 @@ class KgeEngine:
             sample_range = self.n_ents
         s0, s1 = self._slots_of("e")
         r0, r1 = self._slots_of("r")
-        opt_desc.reg_lambda = float(reg_e)
+        p0 = int(opt_desc.reg_p)   # the descriptor's own p: what a bare lambda refers to
+        _set_reg(opt_desc, reg_e, p0)
+        rp1, rl1, rp2, rl2 = reg_fields(reg_r, p0)
+        if rl1 == 0.0 and rl2 != 0.0:
+            rp1, rl1, rl2 = rp2, rl2, 0.0
+        opt_desc.rel_reg_p, opt_desc.rel_reg2_p, opt_desc.rel_reg2_lambda = rp1, rp2, rl2
         opt_desc.row_floats = self.Ks
         try:
             check(self.lib.amdkge_train_step_tiled(
                 C.byref(self.model), C.byref(loss), C.byref(opt_desc), _ptr(self.ent), _ptr(self.rel), _ptr(s0), _ptr(s1),
-                _ptr(r0), _ptr(r1), float(reg_r), _ptr(triples), B, int(eta), int(sample_base), int(sample_range),
+                _ptr(r0), _ptr(r1), float(rl1), _ptr(triples), B, int(eta), int(sample_base), int(sample_range),
                 int(seed), int(step), int(row_offset), int(b_global), _ptr(neg_override),
                 _ptr(self.g_ent), _ptr(self.g_rel), 0 if grad_only else 1, flags,
                 C.c_void_p(self.loss_acc.data_ptr()), C.c_void_p(self.loss_acc.data_ptr() + 8),
@@ -199,6 +227,8 @@ class KgeEngine:
         except Exception:
             self._twork = None   # bookkeeping may be dirty after a failed launch: start from a fresh zeroed buffer
             raise
+        finally:
+            opt_desc.reg_p = p0
 
     def set_hot_rows(self, ids):
         """Declare up to 64 hot entity rows (AMDKGE_TILED_HOT_ROWS: skewed graphs); None / empty switches the feature off."""
@@ -225,23 +255,26 @@ class KgeEngine:
         rows); reg_slots = loss_acc slots receiving the entity / relation regulariser values."""
         n_e = self.ent.numel() if rows_e is None else int(rows_e) * self.Ks
         opt_desc.row_floats = self.Ks
-        if rows_e is None and float(reg_e) == float(reg_r) and reg_slots[0] == reg_slots[1] and not opt_desc.lazy:
+        p0 = int(opt_desc.reg_p)
+        if rows_e is None and _same_reg(reg_e, reg_r, p0) and reg_slots[0] == reg_slots[1] and not opt_desc.lazy:
             # both tables in ONE launch: they live in one flat allocation (the padding between / behind them holds zero
             # parameters and zero gradients, which every rule maps to zero) -- one launch less on launch-bound shapes (C1)
-            opt_desc.reg_lambda = float(reg_e)
+            _set_reg(opt_desc, reg_e, p0)
             names = _ffi.OPT_SLOTS[self.opt_kind]
             sl = [self.slot_flat[n] for n in names] + [None, None]
             n_all = self._off + self._nr
             check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(self.p_flat), _ptr(self.g_flat), _ptr(sl[0]), _ptr(sl[1]), n_all,
                                            C.c_void_p(self.loss_acc.data_ptr() + 8 * int(reg_slots[0])), _stream()))
+            opt_desc.reg_p = p0
             return
         for x, g, table, lam, n_el, slot in ((self.ent, self.g_ent, "e", reg_e, n_e, reg_slots[0]),
                                              (self.rel, self.g_rel, "r", reg_r, self.rel.numel(), reg_slots[1])):
             reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(slot))
-            opt_desc.reg_lambda = float(lam)
+            _set_reg(opt_desc, lam, p0)
             s0, s1 = self._slots_of(table)
             check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(x), _ptr(g), _ptr(s0), _ptr(s1),
                                            n_el, reg_ptr, _stream()))
+        opt_desc.reg_p = p0
 
     def opt_step_flat(self, opt_desc, lo, hi, reg_e=0.0, reg_r=0.0, reg_slot=1):
         """Dense sweep over elements [lo, hi) of the flat parameter vector (sharded-optimizer data parallelism: a rank
@@ -258,11 +291,13 @@ class KgeEngine:
         names = _ffi.OPT_SLOTS[self.opt_kind]
         if opt_desc.lazy:
             raise ValueError("the touched-rows optimizer mode sweeps whole rows: use the all-reduce gradient merge")
+        p0 = int(opt_desc.reg_p)
         for a, b, lam in segs:
-            opt_desc.reg_lambda = float(lam)
+            _set_reg(opt_desc, lam, p0)
             sl = [self.slot_flat[n][a:b] for n in names] + [None, None]
             check(self.lib.amdkge_opt_step(C.byref(opt_desc), _ptr(self.p_flat[a:b]), _ptr(self.g_flat[a:b]), _ptr(sl[0]),
                                            _ptr(sl[1]), b - a, reg_ptr, _stream()))
+        opt_desc.reg_p = p0
 
     # ------------------------------------------------------------------ multi-GPU data path (kge_shard.hip)
     def shard_route(self, spec, triples, negs, cap):
@@ -319,11 +354,13 @@ class KgeEngine:
             segs.append((a, b, reg_r))
         reg_ptr = C.c_void_p(self.loss_acc.data_ptr() + 8 * int(reg_slot))
         names = _ffi.OPT_SLOTS[self.opt_kind]
+        p0 = int(opt_desc.reg_p)
         for a, b, lam in segs:
-            opt_desc.reg_lambda = float(lam)
+            _set_reg(opt_desc, lam, p0)
             sl = [self.slot_flat[n][a:b] for n in names] + [None, None]
             check(self.lib.amdkge_opt_step_merged(C.byref(opt_desc), _ptr(self.p_flat[a:b]), _ptr(parts[a - lo:]), int(n_parts),
                                                   int(part_stride), _ptr(sl[0]), _ptr(sl[1]), b - a, reg_ptr, _stream()))
+        opt_desc.reg_p = p0
 
     def synth_triples(self, seed, first_row, n, n_ents, n_rels, out=None):
         """int32 [n,3] triples number first_row .. of the counter-based synthetic stream (amdkge_synth_triples)."""
@@ -384,6 +421,7 @@ class KgeEngine:
                 v = v * col_scale[None, :m]
             if col_bias is not None:
                 v = v + col_bias[None, :m]
+            v = torch.nan_to_num(v, nan=float("-inf") if largest else float("inf"), posinf=float("inf"), neginf=float("-inf"))   # NaN ranks last, as in the kernel
             sv, si = torch.sort(v, dim=1, descending=bool(largest), stable=True)
             kk = min(int(k), m)
             idx = torch.full((n, int(k)), -1, dtype=torch.int32, device=self.device)

@@ -145,10 +145,10 @@ class ScoringBasedEmbeddingModel:
                 "RotatE requires the relation embeddings to be initialised with GlorotUniform"
         reg = entity_relation_regularizer
         regs = list(reg) if isinstance(reg, (list, tuple)) else [reg, reg]
+        if len(regs) != 2:   # EmbeddingLookupLayer.py:147-150
+            raise AssertionError("Incorrect length for regularizer. Expected 2, got {}".format(len(regs)))
+        # independent per table, either may be None, each a sum of at most two LP terms (EmbeddingLookupLayer.py:131-155)
         self._regularizers = [regularizers.get(r) for r in regs]
-        if (self._regularizers[0] is None) != (self._regularizers[1] is None) or (
-                self._regularizers[0] is not None and self._regularizers[0].p != self._regularizers[1].p):
-            raise NotImplementedError("entity and relation regularisers must share p (different lambdas are fine)")
         self.is_compiled = True
 
     def _assert_compile_was_called(self):
@@ -255,8 +255,7 @@ class ScoringBasedEmbeddingModel:
                                    self._dist(), negatives=self._sharded_negatives)
         else:
             loop = StepLoop(self._engine, self.eta, self.loss, self.optimizer, reg, self.seed, self._dist())
-        if reg is not None and self._regularizers[1].lam != reg.lam:
-            loop.lam_rel = self._regularizers[1].lam   # [entity_reg, relation_reg] pair with different lambdas
+        loop.reg_rel = self._regularizers[1]   # the relation table's own regulariser (or None)
         if getattr(self, "_deterministic", False):
             loop.deterministic = True   # AMDKGE_TILED_DETERMINISTIC: bitwise reproducible tables (include/amdkge.h)
         return loop
@@ -738,7 +737,7 @@ class ScoringBasedEmbeddingModel:
                 "iterations": self.optimizer.iterations if self.is_compiled else 0,
                 "loss": {"name": self.loss.name, "params": self.loss._loss_parameters} if self.is_compiled else None,
                 "calibration": self.calibration_parameters if self.is_calibrated else None,
-                "regularizer": ([None if r is None else {"p": r.p, "lambda": r.lam} for r in self._regularizers]
+                "regularizer": ([None if r is None else {"p": r.p, "lambda": r.lam, "p2": r.p2, "lambda2": r.lam2} for r in self._regularizers]
                                 if self.is_compiled else None)}
         with open(filepath + ".json.tmp", "w") as f:
             json.dump(meta, f)

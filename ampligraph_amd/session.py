@@ -37,10 +37,15 @@ class Session:
         cfg.loss = loss.to_ffi()
         if focus_nonlinearity is not None:
             cfg.loss.focus_nonlinearity = _ffi.FOCUS_NONLINEARITY[focus_nonlinearity]
-        cfg.opt = optimizer.to_ffi(1, regularizer.p if regularizer is not None else 2)
-        cfg.opt.reg_lambda = regularizer.lam if regularizer is not None else 0.0
+        from .engine import reg_fields
+
+        cfg.opt = optimizer.to_ffi(1, 2)
+        cfg.opt.reg_p, cfg.opt.reg_lambda, cfg.opt.reg2_p, cfg.opt.reg2_lambda = reg_fields(regularizer, 2)
         rr = rel_regularizer if rel_regularizer is not None else regularizer
-        cfg.rel_reg_lambda = rr.lam if rr is not None else 0.0
+        rp1, rl1, rp2, rl2 = reg_fields(rr, 2)
+        if rl1 == 0.0 and rl2 != 0.0:
+            rp1, rl1, rl2 = rp2, rl2, 0.0
+        cfg.rel_reg_lambda, cfg.opt.rel_reg_p, cfg.opt.rel_reg2_p, cfg.opt.rel_reg2_lambda = rl1, rp1, rp2, rl2
         cfg.eta, cfg.seed, cfg.device, cfg.flags = int(eta), int(seed), int(device), (1 if pos_atomic else 0) | (2 if deterministic else 0)
         self._h = C.c_void_p()
         check(self.lib.amdkge_session_create(C.byref(cfg), C.byref(self._h)))

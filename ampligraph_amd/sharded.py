@@ -125,7 +125,7 @@ class ShardedStepLoop:
         self.loss_ffi = loss.to_ffi()
         self.optimizer = optimizer
         self.reg = regularizer
-        self.lam_rel = None   # relation-table lambda when it differs from the entity table's (same p)
+        self.reg_rel = "same"   # relation table: "same" as the entity table's, None, or its own regulariser (trainer.StepLoop)
         self.seed = int(seed)
         self.negatives = negatives
         self.world, self.rank = spec.world, spec.rank
@@ -205,8 +205,8 @@ class ShardedStepLoop:
             hook(1)
         # ---- 2. fused train step on the local index space (gradient only) --------------------------------
         self.optimizer.iterations += 1
-        lam = self.reg.lam if self.reg is not None else 0.0
-        opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2)
+        lam = self.reg
+        opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, 2)
         g_scratch = eng.g_ent[sp.n_local:sp.n_local + W * cap]
         if b > 0:
             kw = dict(row_offset=lo, b_global=bg, neg_override=nl)
@@ -236,7 +236,7 @@ class ShardedStepLoop:
         if hook is not None:
             hook(3)
         # ---- 4. every rank sweeps its rows and the replicated relation table -------------------------------
-        eng.opt_step(opt_ffi, lam, lam if self.lam_rel is None else self.lam_rel, rows_e=sp.n_local, reg_slots=(1, 2))
+        eng.opt_step(opt_ffi, lam, lam if isinstance(self.reg_rel, str) else self.reg_rel, rows_e=sp.n_local, reg_slots=(1, 2))
         if hook is not None:
             hook(4)
         self.n_steps += 1

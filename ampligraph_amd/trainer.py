@@ -88,8 +88,10 @@ class StepLoop:
         self.eta = int(eta)
         self.loss_ffi = loss.to_ffi()
         self.optimizer = optimizer
+        # regulariser of the entity table; the relation table takes `reg_rel` -- "same" (the default: one regulariser for both,
+        # EmbeddingLookupLayer.py:153-155), None, or its own object (an [entity, relation] pair, :147-152)
         self.reg = regularizer
-        self.lam_rel = None   # relation-table lambda when it differs from the entity table's (same p)
+        self.reg_rel = "same"
         self.seed = int(seed)
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
@@ -156,9 +158,9 @@ class StepLoop:
             self.loss_ffi.focus_nonlinearity = 0
             self.loss_ffi.d_focus_w = None
         self.optimizer.iterations += 1
-        lam = self.reg.lam if self.reg is not None else 0.0
-        lam_r = lam if self.lam_rel is None else self.lam_rel
-        opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, self.reg.p if self.reg is not None else 2)
+        lam = self.reg    # LPRegularizer objects (or None): the engine turns them into the descriptor's (p, lambda) terms
+        lam_r = self.reg if isinstance(self.reg_rel, str) else self.reg_rel
+        opt_ffi = self.optimizer.to_ffi(self.optimizer.iterations, 2)
         # owner-computes path (kge_train_tiled.hip) whenever the shape allows it: no global atomics, no dense
         # entity gradient; data-parallel runs take its gradient-only form and keep the dense sweep
         tiled = (self.use_tiled or self.deterministic) and hi > lo and eng.tiled_supported(hi - lo, self.eta)

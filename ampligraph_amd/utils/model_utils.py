@@ -56,7 +56,8 @@ def restore_model(model_name_path=None):
         prm = dict(meta["loss"].get("params") or {})
         from ..latent_features import regularizers
 
-        regs = [None if r is None else regularizers.get("LP", r) for r in (meta.get("regularizer") or [None, None])]
+        regs = [None if r is None else regularizers.LPRegularizer(r.get("p", 2), r.get("lambda", 1e-5), r.get("p2"), r.get("lambda2", 0.0))
+                for r in (meta.get("regularizer") or [None, None])]
         model.compile(optimizer=optimizers.get(name, oc), loss=loss_functions.get(meta["loss"]["name"], prm),
                       entity_relation_regularizer=regs)
     model.load_weights(base)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AMDKGE_ABI_VERSION 2
+#define AMDKGE_ABI_VERSION 3
 
 /* error classes */
 #define AMDKGE_OK 0
@@ -107,6 +107,17 @@ typedef struct amdkge_opt {
      * amdkge_opt_step to find row boundaries, ignored when lazy == 0. */
     int32_t lazy;
     int32_t row_floats;
+    /* ABI 3: the regulariser forms the reference accepts beyond one shared LP term (EmbeddingLookupLayer.py:131-155 takes a
+     * [entity, relation] pair of independent Keras regularisers; tf.keras 'l1_l2' is l1*sum|x| + l2*sum x^2).
+     *   reg2_p / reg2_lambda : a SECOND LP term of the swept table, added to the first (0 = none);
+     *   rel_reg_p, rel_reg2_p / rel_reg2_lambda : the relation table's terms where one call sweeps both tables
+     *       (amdkge_train_step_tiled with relation slots; its rel_reg_lambda argument is the first term's weight);
+     *       rel_reg_p == 0 means "the entity table's p" (what ABI 2 callers got). */
+    int32_t reg2_p;
+    float reg2_lambda;
+    int32_t rel_reg_p;
+    int32_t rel_reg2_p;
+    float rel_reg2_lambda;
 } amdkge_opt;
 
 /* ---- library / device helpers (so that a host without torch can drive the engine) ---- */

@@ -493,13 +493,26 @@ def dense_gradients(model, ent, rel, pos, negs, eta, loss_name, loss_params=None
         np.add.at(Ge, tri[:, 2], g * go)
     total = float(total)
     if reg is not None:
-        pw = reg.get("p", 2)
-        for tab, G, lam in ((ent, Ge, reg.get("lam_e", 0.0)), (rel, Gr, reg.get("lam_r", 0.0))):
-            if lam:
+        for tab, G, terms in zip((ent, rel), (Ge, Gr), reg_terms(reg)):
+            for pw, lam in terms:
                 x = tab.astype(np.float64)
                 total += lam * float((np.abs(x) ** pw).sum())
                 G += lam * pw * np.abs(x) ** (pw - 1) * np.sign(x)
     return F32(total), Ge, Gr, (sp, sn, per)
+
+
+def reg_terms(reg):
+    """Regulariser description -> ([(p, lambda), ...] of the entity table, [...] of the relation table).
+
+    reg = dict(p=..., lam_e=..., lam_r=...): one LP term with a shared p (regularizers.py:14-37); optional keys
+    terms_e / terms_r = [(p, lambda), ...] replace a table's term list: the reference hands [entity, relation] pairs of
+    independent Keras regularisers to the lookup layer (EmbeddingLookupLayer.py:131-155), and tf.keras 'l1_l2' is two terms."""
+    if reg is None:
+        return [], []
+    pw = reg.get("p", 2)
+    te = reg.get("terms_e", [(pw, reg.get("lam_e", 0.0))])
+    tr = reg.get("terms_r", [(pw, reg.get("lam_r", 0.0))])
+    return [(int(p_), float(l_)) for p_, l_ in te if l_], [(int(p_), float(l_)) for p_, l_ in tr if l_]
 
 
 def apply_optimizer(state, Ge, Gr, beta1=None, beta2=None, eps=None):
@@ -584,10 +597,11 @@ def apply_optimizer_lazy(state, Ge, Gr, reg=None):
     masks = [np.any(Ge != 0, axis=1), np.any(Gr != 0, axis=1)]
     reg_loss = 0.0
     if reg is not None:
-        for x, G, mask, lam in ((state.ent, Ge, masks[0], reg["lam_e"]), (state.rel, Gr, masks[1], reg["lam_r"])):
+        for x, G, mask, terms in zip((state.ent, state.rel), (Ge, Gr), masks, reg_terms(reg)):
             xx = x.astype(np.float64)[mask]
-            reg_loss += lam * float((np.abs(xx) ** reg["p"]).sum())
-            G[mask] += lam * reg["p"] * np.abs(xx) ** (reg["p"] - 1) * np.sign(xx)
+            for pw, lam in terms:
+                reg_loss += lam * float((np.abs(xx) ** pw).sum())
+                G[mask] += lam * pw * np.abs(xx) ** (pw - 1) * np.sign(xx)
     keep = [(state.ent.copy(), {k: v.copy() for k, v in state.slots.items() if k.endswith("_e")}),
             (state.rel.copy(), {k: v.copy() for k, v in state.slots.items() if k.endswith("_r")})]
     apply_optimizer(state, Ge, Gr)

@@ -10,6 +10,16 @@ LOSS_BY_ID = {0: "pairwise", 1: "nll", 2: "absolute_margin", 3: "self_adversaria
 OPT_BY_ID = {0: "sgd", 1: "adagrad", 2: "adam"}
 
 
+
+def _terms(reg, default_p):
+    """regulariser argument of the engine surface (a bare lambda, or an object with .terms) -> [(p, lambda), ...]"""
+    if reg is None:
+        return []
+    if isinstance(reg, (int, float)):
+        return [(int(default_p), float(reg))] if reg else []
+    return list(reg.terms)
+
+
 class OracleEngine:
     def __init__(self, model, k, ent, rel, tiled=False, flat=False):
         self.model, self.k = model, k
@@ -168,9 +178,10 @@ class OracleEngine:
         reg_before = self.loss_acc.clone()
         self._sweep(opt, reg_e, reg_r, (reg_slot, reg_slot), None)
         self.loss_acc.copy_(reg_before)
-        for lam, a, b in ((reg_e, max(lo, 0), min(hi, self._ne)), (reg_r, max(lo, self._off), min(hi, self._off + self._nr))):
-            if lam and b > a:
-                self.loss_acc[reg_slot] += lam * float((np.abs(keep_p[a:b].astype(np.float64)) ** opt.reg_p).sum())
+        for reg, a, b in ((reg_e, max(lo, 0), min(hi, self._ne)), (reg_r, max(lo, self._off), min(hi, self._off + self._nr))):
+            for pw, lam in _terms(reg, opt.reg_p):
+                if b > a:
+                    self.loss_acc[reg_slot] += lam * float((np.abs(keep_p[a:b].astype(np.float64)) ** pw).sum())
         mask = np.ones(self._p.shape, dtype=bool)
         mask[lo:hi] = False
         self._p[mask] = keep_p[mask]
@@ -230,13 +241,13 @@ class OracleEngine:
         self.state.iterations = opt.iteration - 1
         Ge, Gr = self.g_ent.numpy().astype(np.float64), self.g_rel.numpy().astype(np.float64)
         for x, G, lam, slot, rows in ((self.state.ent, Ge, lam_e, reg_slots[0], rows_e), (self.state.rel, Gr, lam_r, reg_slots[1], None)):
-            if lam:
+            for pw, lm in _terms(lam, opt.reg_p):
                 xx = x.astype(np.float64)
                 if rows is not None:
                     xx = xx.copy()
                     xx[rows:] = 0.0   # scratch rows carry no regulariser
-                self.loss_acc[slot] += lam * float((np.abs(xx) ** opt.reg_p).sum())
-                G += lam * opt.reg_p * np.abs(xx) ** (opt.reg_p - 1) * np.sign(xx)
+                self.loss_acc[slot] += lm * float((np.abs(xx) ** pw).sum())
+                G += lm * pw * np.abs(xx) ** (pw - 1) * np.sign(xx)
         kind = self.state.optimizer   # the descriptor's beta1 / beta2 carry other hyper-parameters for the non-Adam rules
         if kind in ("adam", "adamax", "adagrad", "sgd"):
             O.apply_optimizer(self.state, Ge, Gr, opt.beta1, opt.beta2, opt.epsilon)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/amdkge.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
-    assert lib.amdkge_abi_version() == 2
+    assert lib.amdkge_abi_version() == 3 == _ffi.ABI_VERSION
     assert lib.amdkge_internal_k(2, 200) == 400 and lib.amdkge_internal_k(0, 50) == 50
 
 
@@ -171,3 +171,33 @@ def test_compat_argument_mapping_and_session_without_gpu():
 
         with pytest.raises(_ffi.AmdKgeError):
             Session("ComplEx", 8, 10, 2, 3, loss_functions.get("nll"), optimizers.get("adam"))
+
+
+def test_regulariser_forms_the_reference_accepts():
+    """regularizers.get mirrors what the reference hands to tf.keras.regularizers.get (regularizers.py:59-73,
+    EmbeddingLookupLayer.py:131-155): LP / l3 with hyper-parameters, Keras' names l1, l2, l1_l2 and the L1L2 config dict; the
+    penalty of a table is the sum of at most two LP terms."""
+    import numpy as np
+
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, regularizers
+
+    x = np.array([[1.0, -2.0], [0.5, 0.0]])
+    assert regularizers.get(None) is None
+    assert regularizers.get("LP").terms == [(2, 1e-5)] and regularizers.get("l3", {"lambda": 0.1}).terms == [(3, 0.1)]
+    assert regularizers.get("l1").terms == [(1, 0.01)] and regularizers.get("L2").terms == [(2, 0.01)]
+    r = regularizers.get("l1_l2")
+    assert r.terms == [(1, 0.01), (2, 0.01)] and abs(r(x) - (0.01 * 3.5 + 0.01 * 5.25)) < 1e-12
+    r = regularizers.get({"class_name": "L1L2", "config": {"l1": 0.0, "l2": 0.5}})
+    assert r.terms == [(2, 0.5)]
+    assert regularizers.get({"class_name": "L1L2", "config": {"l1": 0.0, "l2": 0.0}}) is None
+    with pytest.raises(ValueError):
+        regularizers.get("nonsense")
+    m = ScoringBasedEmbeddingModel(eta=1, k=4, scoring_type="TransE")
+    m.compile(optimizer="adam", loss="nll", entity_relation_regularizer=[regularizers.get("LP", {"p": 3}), None])   # one-sided pair
+    assert m._regularizers[0].p == 3 and m._regularizers[1] is None
+    with pytest.raises(AssertionError):   # EmbeddingLookupLayer.py:147-150
+        m.compile(optimizer="adam", loss="nll", entity_relation_regularizer=["l1", "l2", "l1"])
+    from ampligraph_amd.engine import reg_fields
+
+    assert reg_fields(None, 2) == (2, 0.0, 2, 0.0) and reg_fields(0.5, 3) == (3, 0.5, 3, 0.0)
+    assert reg_fields(regularizers.get("l1_l2"), 2) == (1, 0.01, 2, 0.01)

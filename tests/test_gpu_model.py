@@ -83,6 +83,63 @@ def test_fit_with_lp_regularizer(gpu_lib):
     assert np.allclose(h.history["loss"], hist, rtol=2e-4)
 
 
+@pytest.mark.parametrize("model,path", [("ComplEx", "tiled"), ("TransE", "atomic"), ("RotatE", "tiled"), ("DistMult", "lazy")])
+@pytest.mark.parametrize("form", ["mixed_p", "entity_only", "relation_only", "l1_l2", "l1_l2_config_and_l3"])
+def test_fit_regulariser_forms_of_the_reference(gpu_lib, model, path, form):
+    """a17: the reference hands `entity_relation_regularizer` to tf.keras.regularizers.get per table
+    (EmbeddingLookupLayer.py:131-155): an [entity, relation] pair of INDEPENDENT regularisers -- different p, either one None --
+    and Keras' own names ('l1_l2' = l1 sum|x| + l2 sum x^2).  Loss histories against the oracle with the same per-table terms,
+    on the owner-computes pair (fused relation sweep for ComplEx, separate one for RotatE), the atomic path + dense sweep
+    (TransE k < 128) and the touched-rows mode."""
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers, regularizers
+
+    LP = lambda p, lam: regularizers.get("LP", {"p": p, "lambda": lam})   # noqa: E731
+    pair, terms = {
+        "mixed_p": ([LP(3, 2e-2), LP(2, 5e-3)], ([(3, 2e-2)], [(2, 5e-3)])),
+        "entity_only": ([LP(2, 1e-2), None], ([(2, 1e-2)], [])),
+        "relation_only": ([None, LP(1, 1e-3)], ([], [(1, 1e-3)])),
+        "l1_l2": ("l1_l2", ([(1, 0.01), (2, 0.01)], [(1, 0.01), (2, 0.01)])),
+        "l1_l2_config_and_l3": ([{"class_name": "L1L2", "config": {"l1": 2e-3, "l2": 3e-2}}, regularizers.get("l3", {"lambda": 1e-2})],
+                                ([(1, 2e-3), (2, 3e-2)], [(3, 1e-2)])),
+    }[form]
+    X = toy_graph(4)
+    k, eta, bs, epochs, lr = 8, 3, 256, 3, 1e-2
+    m = ScoringBasedEmbeddingModel(eta=eta, k=k, scoring_type=model, seed=2)
+    kw = {"optimizer_mode": "lazy"} if path == "lazy" else {}
+    m.compile(optimizer=optimizers.get("adam", {"learning_rate": lr}), loss="nll", entity_relation_regularizer=pair, **kw)
+    h = m.fit(X, batch_size=bs, epochs=epochs, verbose=False)
+    assert m._loop.use_tiled == (path != "atomic")
+    reg = {"terms_e": terms[0], "terms_r": terms[1]}
+    if path == "lazy":
+        st, Xi, hist = lazy_replay(model, X, k, eta, "nll", "adam", lr, bs, epochs, 2, reg)
+    else:
+        st, Xi, hist = oracle_replay(model, X, k, eta, "nll", "adam", lr, bs, epochs, seed=2, reg=reg)
+    assert np.allclose(h.history["loss"], hist, rtol=2e-4), (h.history["loss"], hist)
+    ent, rel = m._engine.get_tables()
+    for got, ref in ((ent, st.ent), (rel, st.rel)):
+        close = np.abs(got - ref) <= 1e-4 + 1e-3 * np.abs(ref)
+        assert close.mean() > 0.99, close.mean()
+
+
+def lazy_replay(model, X, k, eta, loss, opt, lr, batch_size, epochs, seed, reg):
+    from ampligraph_amd.latent_features.initializers import initialise
+
+    ents, rels = O.first_seen_index(X)
+    Xi = O.to_indexes(X, ents, rels)
+    N, R, K = len(ents), len(rels), O.internal_k(model, k)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    st = O.TrainState(initialise("glorot_uniform", (N, K), rng), initialise("glorot_uniform", (R, K), rng), opt, lr)
+    steps = -(-len(Xi) // batch_size)
+    hist = []
+    for ep in range(epochs):
+        tot = 0.0
+        for s_ in range(steps):
+            tot += float(O.train_step(st, model, Xi[s_ * batch_size:(s_ + 1) * batch_size], eta, loss, seed, ep * steps + s_,
+                                      max_rel_size=R, reg=reg, lazy=True))
+        hist.append(tot / steps)
+    return st, Xi, hist
+
+
 @pytest.mark.parametrize("model", ["ComplEx", "TransE", "RotatE"])
 def test_evaluate_matches_oracle(gpu_lib, model):
     from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel
