@@ -89,6 +89,9 @@ SIGNATURES = {
     "amdkge_unpack_rows": (C.c_int, [C.POINTER(Model), P, I64, P, P]),
     "amdkge_set_rank_kernel": (C.c_int, [C.c_int]),
     "amdkge_set_rank_rotate_fast": (C.c_int, [C.c_int]),
+    "amdkge_set_tile_direct": (C.c_int, [C.c_int]),
+    "amdkge_filter_build_workspace_bytes": (I64, [I64, I64, I64]),
+    "amdkge_filter_build": (C.c_int, [P, I64, I32, I64, I64, P, P, P, P, P, P]),
     "amdkge_score": (C.c_int, [C.POINTER(Model), P, P, P, I64, P, P]),
     "amdkge_platt_step": (C.c_int, [P, I64, P, I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, P, P]),
     "amdkge_sample_corruptions": (C.c_int, [P, I64, I32, I64, I64, U64, U64, I64, I64, P, P]),

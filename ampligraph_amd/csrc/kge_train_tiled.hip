@@ -108,6 +108,7 @@ struct TileArgs {
     int k_live;               // the model's k (RotatE: units behind it are zero padding, see grad_unit)
     int tile_rows, n_tiles, cap, ovf_cap;
     int rb;                   // rows per ownership block (block-interleaved tiles)
+    int direct;               // launched as tile_direct_kernel (kge_tile_direct.h)
     int gw;                   // waves that share one row (1: a wave covers the row; 4 / 8: long rows are split over a group of
                               // waves, each lane one quad), rows are owned by wave GROUPS: TILE_WAVES / gw owners per tile
     ModelConst mc;
@@ -679,6 +680,10 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     if (s_last && wv == 0 && a.apply_update && a.reg_loss && a.opt.lam != 0.f) fold_loss_parts(a.loss_parts, a.reg_loss, lane, 1);
 }
 
+}  // namespace kge
+#include "kge_tile_direct.h"
+namespace kge {
+
 // Deterministic mode: the relation-row gradient.  One workgroup per relation walks the batch in order, collects the
 // positives of its relation (compacted in batch order through a ballot prefix) and adds their staged fifth rows in that
 // order, every thread owning fixed columns of the row: the same additions in the same order on every run.
@@ -735,7 +740,10 @@ struct TiledPlan {
     size_t off_cnt, off_lists, off_ovf, off_rows, off_cs, off_touch, off_loss, off_flag, off_hot_map, off_hot_buf, off_codes, total;
     bool own_cache;     // RotatE, queued form, >= 4 corruption entries per table row and step: own rows cached in LDS
     bool codes;         // TransE with one wave per positive: the forward kernel hands the signs of d_j to the tile pass (ENTRY_EXACT)
+    bool direct;        // long rows (> 128 quads per half): the row-direct tile pass (kge_tile_direct.h)
 };
+
+static int g_tile_direct = 1;   // amdkge_set_tile_direct (A/B measurements, tests): 0 keeps long rows on tile_backward_kernel
 
 static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p, bool det = false) {
     const int ks = stored_k(m), K = row_floats(m);
@@ -792,6 +800,9 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
         if (p.tile_rows == 1) return false;   // one row per tile and its bucket still does not fit: not a shape for this mode
     }
     p.ovf_cap = (int)(entries > 0 ? entries : 1);
+    // row-direct pass: one wave group per tile, the bucket sorted in LDS, rows through registers -- long rows only, and only
+    // while a bucket (+ slack for overflow entries) is a small LDS list
+    p.direct = g_tile_direct && !det && ks / 4 > 128 && p.cap <= 3000 && p.tile_rows <= 2048;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
     p.off_loss = o; o += up((size_t)LOSS_PARTS * LOSS_PART_STRIDE * 8);   // first: the same place in every plan (kept zero between steps)
@@ -885,6 +896,12 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     }
     // T: entity tiles (the owner applies the optimizer)
     te.gw = f.nq <= 128 ? 1 : (f.nq <= 256 ? 4 : 8);
+    if (te.direct) {
+        const size_t sh = direct_lds_bytes(te.cap, te.tile_rows);
+        if (te.gw == 4) hipLaunchKernelGGL((tile_direct_kernel<MODEL, 4>), dim3(te.n_tiles + te.rel_blocks), dim3(256), sh, st, te);
+        else hipLaunchKernelGGL((tile_direct_kernel<MODEL, 8>), dim3(te.n_tiles + te.rel_blocks), dim3(512), sh, st, te);
+        return check_launch("tile_direct");
+    }
     const size_t shmem_t = te.det ? (((size_t)te.tile_rows * te.K * 4 + (size_t)te.tile_rows * te.gw + 15) & ~(size_t)15) + (size_t)te.sort_cap * 16
                                   : (((size_t)te.tile_rows * te.K * 4 * (te.own_cache ? 2 : 1) + (te.lazy ? (size_t)te.tile_rows * te.gw : 0) + 15) & ~(size_t)15) +
                                         (tile_queued(MODEL, tile_ch_of(f.nq), te.K) ? TILE_QUEUE_BYTES : 0);
@@ -899,6 +916,11 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
 }  // namespace kge
 
 using namespace kge;
+
+extern "C" int amdkge_set_tile_direct(int on) {
+    g_tile_direct = on ? 1 : 0;
+    return AMDKGE_OK;
+}
 
 extern "C" int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta) {
     if (validate_model(m) != AMDKGE_OK || B < 0 || B >= (1ll << 30) || eta < 1) return -1;
@@ -974,7 +996,7 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     TileArgs te{};
     te.x = d_ent; te.s0 = d_ent_slot0; te.s1 = d_ent_slot1; te.g_ent = d_grad_ent; te.apply_update = apply_update ? 1 : 0; te.pos_atomic = (flags & AMDKGE_TILED_POS_ATOMIC) ? 1 : 0; te.rel = d_rel;
     te.rel_cs = rel_cs; te.lazy = lazy ? 1 : 0; te.touched = touched; te.ns = p.ns; te.det = det ? 1 : 0; te.sort_cap = p.sort_cap;
-    te.sign_codes = f.sign_codes; te.eta = eta; te.own_cache = p.own_cache ? 1 : 0;
+    te.sign_codes = f.sign_codes; te.eta = eta; te.own_cache = p.own_cache ? 1 : 0; te.direct = p.direct ? 1 : 0;
     te.n_rels = m->n_rels; te.loss_parts = f.loss_parts; te.loss_sum = d_loss_sum; te.hot_map = f.hot_map; te.hot_buf = f.hot_buf;
 #ifdef KGE_ABLATE
     te.dbg = f.dbg;

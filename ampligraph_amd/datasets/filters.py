@@ -10,7 +10,14 @@ import numpy as np
 
 
 class FilterIndex:
-    def __init__(self, datasets, n_ents, n_rels):
+    def __init__(self, datasets, n_ents, n_rels, engine=None):
+        """engine=None: the index is built on the host (numpy sorts; the checker of the device build and what GPU-less callers
+        get).  With a KgeEngine the id triples are uploaded once and the index is built ON THE DEVICE by amdkge_filter_build
+        (kge_filter.hip: key generation, radix sort, scan, scatter) -- evaluate() then does no host sort at all; the host arrays
+        (po_keys, ...) are downloaded lazily only if somebody asks for them."""
+        if engine is not None:
+            self._init_device(datasets, n_ents, n_rels, engine)
+            return
         X = np.concatenate([np.asarray(d)[:, :3].astype(np.int64) for d in datasets], 0) if len(datasets) else \
             np.zeros((0, 3), dtype=np.int64)
         self.n_ents, self.n_rels = int(n_ents), int(n_rels)
@@ -29,6 +36,40 @@ class FilterIndex:
         self.sp_keys, self.sp_start = np.unique(k_o // N, return_index=True)
         self.sp_start = np.append(self.sp_start, k_o.size).astype(np.int64)
         self.o_ids = (k_o % N).astype(np.int32)
+
+    def _init_device(self, datasets, n_ents, n_rels, engine):
+        import torch
+
+        self.n_ents, self.n_rels = int(n_ents), int(n_rels)
+        N, R = self.n_ents, self.n_rels
+        if R * N * N >= 2 ** 63:
+            raise ValueError(f"FilterIndex: n_rels * n_ents^2 = {R * N * N} does not fit the packed int64 keys "
+                             "(n_ents up to ~96 M at 1 000 relations)")
+        dev = engine.device
+        parts = []
+        for d in datasets:
+            if isinstance(d, torch.Tensor):
+                parts.append(d[:, :3].to(device=dev, dtype=torch.int32))
+            else:
+                parts.append(torch.as_tensor(np.ascontiguousarray(np.asarray(d)[:, :3], dtype=np.int32)).to(dev))
+        X = torch.cat(parts, 0).contiguous() if parts else torch.zeros(0, 3, dtype=torch.int32, device=dev)
+        built = {sd: engine.filter_build(X, sd, N, R) for sd in ("s", "o")}
+        (pk, ps, si), (sk, ss, oi) = built["s"], built["o"]
+        one = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._dev = {"device": str(dev), "po_keys": pk, "po_start": ps, "s_ids": si if si.numel() else one,
+                     "sp_keys": sk, "sp_start": ss, "o_ids": oi if oi.numel() else one}
+        self._dev_sizes = {"s_ids": int(si.numel()), "o_ids": int(oi.numel())}
+
+    def __getattr__(self, name):
+        # host views of a device-built index, on demand (tests, bench's host-side range lookups)
+        if name in ("po_keys", "po_start", "sp_keys", "sp_start", "s_ids", "o_ids") and "_dev" in self.__dict__:
+            t = self.__dict__["_dev"][name]
+            if name in ("s_ids", "o_ids"):
+                t = t[:self.__dict__["_dev_sizes"][name]]
+            a = t.cpu().numpy()
+            self.__dict__[name] = a
+            return a
+        raise AttributeError(name)
 
     @staticmethod
     def _ranges(keys, start, q):

@@ -241,8 +241,11 @@ class KgeEngine:
             check(self.lib.amdkge_train_tiled_set_hot_rows(C.byref(self.model), _ptr(self._twork), None, 0, _stream()))
 
     def tiled_status(self):
-        """!= 0 if a DETERMINISTIC step fell back to unsorted accumulation in some tile since the last query (synchronises)."""
-        if self._twork is None or not hasattr(self, "_last_tiled") or not (self._last_tiled[2] & 2):
+        """Sticky status of the owner-computes steps since the last query (synchronises): 1 = a DETERMINISTIC step fell back to
+        unsorted accumulation in some tile; 2 = a tile of the row-direct pass (long rows) received more entries than its LDS
+        list holds.  Queried only where one of the two can be set."""
+        long_rows = self.ks > 512   # stored half width beyond 128 quads: kge_tile_direct.h
+        if self._twork is None or not hasattr(self, "_last_tiled") or not ((self._last_tiled[2] & 2) or long_rows):
             return 0
         st = C.c_int32(0)
         B, eta, flags = self._last_tiled
@@ -377,6 +380,24 @@ class KgeEngine:
             _ptr(triples), B, int(eta), int(sample_base), int(sample_range or self.n_ents), int(seed),
             int(step), int(row_offset), int(b_global), _ptr(out), _stream()))
         return out
+
+    def filter_build(self, triples, side, n_ents, n_rels):
+        """amdkge_filter_build: the CSR filter index of one side from the concatenated id triples (int32 [m,3] device tensor).
+        -> (keys int64 [n_groups], start int64 [n_groups + 1], ids int32 [n_unique]) device tensors.  One stream
+        synchronisation (the two counts come back to size the views); an index is built once per evaluate() and cached."""
+        m = int(triples.shape[0])
+        keys = torch.empty(max(m, 1), dtype=torch.int64, device=self.device)
+        start = torch.empty(m + 1, dtype=torch.int64, device=self.device)
+        ids = torch.empty(max(m, 1), dtype=torch.int32, device=self.device)
+        counts = torch.zeros(2, dtype=torch.int64, device=self.device)
+        need = int(self.lib.amdkge_filter_build_workspace_bytes(m, int(n_ents), int(n_rels)))
+        if need < 0:
+            raise ValueError("filter_build: bad sizes")
+        work = self._buf("filter_build_work", (need,), torch.uint8)
+        check(self.lib.amdkge_filter_build(_ptr(triples), m, 1 if side == "s" else 2, int(n_ents), int(n_rels), _ptr(keys), _ptr(start),
+                                           _ptr(ids), _ptr(counts), _ptr(work), _stream()))
+        ng, nu = (int(c) for c in counts.tolist())
+        return keys[:ng], start[:ng + 1], ids[:nu]
 
     def filter_ranges(self, keys, start, triples, side, n_ents, n_rels):
         """(lo, hi) int64 device tensors: each triple's range in a FilterIndex id array (amdkge_filter_ranges)."""

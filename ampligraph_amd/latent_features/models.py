@@ -420,9 +420,9 @@ class ScoringBasedEmbeddingModel:
     # ------------------------------------------------------------------------------------ filters
     def _filter_index(self, use_filter, Xi):
         """FilterIndex for evaluate(): the union of the given datasets (dict) or the evaluated data itself (True), all
-        indexed with the training id map (graph_data_loader.py:184-190,652-653).  Building it costs host time comparable
-        to tens of evaluations on the device (string -> id mapping + sort of the union), so the last one is cached by
-        content checksum: validation during fit() and repeated evaluate() calls reuse it."""
+        indexed with the training id map (graph_data_loader.py:184-190,652-653).  The id mapping is host work (labels), the
+        index itself (sort + CSR) is built on the device (amdkge_filter_build); the last one is cached by content checksum, so
+        validation during fit() and repeated evaluate() calls reuse it."""
         import zlib
 
         if isinstance(use_filter, dict):
@@ -437,12 +437,13 @@ class ScoringBasedEmbeddingModel:
             key = None if key is None else ("dict", tuple(key), self._n_ents, self._n_rels)
             if key is not None and getattr(self, "_filter_cache", (None, None))[0] == key:
                 return self._filter_cache[1]
-            fi = FilterIndex([self.data_indexer.get_indexes(a) for a in arrays], self._n_ents, self._n_rels)
+            # (id mapping on the host -- labels are host data --, then the index itself is built on the device: kge_filter.hip)
+            fi = FilterIndex([self.data_indexer.get_indexes(a) for a in arrays], self._n_ents, self._n_rels, engine=self._engine)
             if key is not None:
                 self._filter_cache = (key, fi)
             return fi
         if use_filter:
-            return FilterIndex([Xi], self._n_ents, self._n_rels)
+            return FilterIndex([Xi], self._n_ents, self._n_rels, engine=self._engine)
         return None
 
     # ------------------------------------------------------------------------------------ predict

@@ -135,15 +135,18 @@ def eval_bench(eng, data, rank):
 
     test = data["test"]
     n = test.shape[0]
-    t0 = time.perf_counter()
-    fi = FilterIndex([data["train"], data["valid"], test], data["n_ents"], data["n_rels"])
-    slo, shi = fi.subject_ranges(test)
-    olo, ohi = fi.object_ranges(test)
-    host_prep = time.perf_counter() - t0
     dev = eng.device
     Xd = torch.as_tensor(test).to(dev)
-    fs = (torch.as_tensor(slo).to(dev), torch.as_tensor(shi).to(dev), torch.as_tensor(fi.s_ids).to(dev))
-    fo = (torch.as_tensor(olo).to(dev), torch.as_tensor(ohi).to(dev), torch.as_tensor(fi.o_ids).to(dev))
+    FilterIndex([test[:8]], data["n_ents"], data["n_rels"], engine=eng)   # (first-use costs of the library path, untimed)
+    torch.cuda.synchronize()
+    # the filter index (train + valid + test: 310 k triples at C2): upload of the id triples, device build (amdkge_filter_build:
+    # keys, radix sort, scan, scatter) and the per-triple range lookup (amdkge_filter_ranges) -- what evaluate() does
+    t0 = time.perf_counter()
+    fi = FilterIndex([data["train"], data["valid"], test], data["n_ents"], data["n_rels"], engine=eng)
+    fs = fi.device_filter(eng, Xd, "s")
+    fo = fi.device_filter(eng, Xd, "o")
+    torch.cuda.synchronize()
+    index_ms = (time.perf_counter() - t0) * 1e3
     ranks = torch.empty(n, 2, dtype=torch.int32, device=dev)
 
     def run():
@@ -161,7 +164,8 @@ def eval_bench(eng, data, rank):
     r = ranks.cpu().numpy()
     flops = 2.0 * data["n_ents"] * eng.K * n * 2
     return {"ranks_per_s": 2 * n / dt, "ms": dt * 1e3, "n_test": int(n), "sides": 2, "filtered": True,
-            "host_filter_index_ms": host_prep * 1e3, "achieved_tflops_fp32": flops / dt / 1e12,
+            "filter_index_ms": index_ms, "filter_index": "built on the device (upload + amdkge_filter_build + amdkge_filter_ranges, both sides)",
+            "achieved_tflops_fp32": flops / dt / 1e12,
             "mrr_untrained_tables": float(np.mean(1.0 / r)), "note": "tables as left by the timed training steps"}
 
 

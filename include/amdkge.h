@@ -226,6 +226,12 @@ int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_s
  * as touched in the lazy optimizer mode.  Results are identical up to fp32 summation order. */
 #define AMDKGE_TILED_HOT_ROWS 4
 int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta);
+/* Long rows (stored half width > 512 units, i.e. rows beyond 2 KB: the C5 row width) take the ROW-DIRECT form of the tile pass by
+ * default (kge_tile_direct.h: one wave group per tile, its bucket sorted in LDS, every row folded in registers and updated in
+ * one go -- x read once, several tiles resident per CU).  0 keeps them on the LDS-accumulator kernel (A/B measurements, tests);
+ * process-wide, both forms compute the same step up to fp32 summation order.  amdkge_train_tiled_status reports 2 when a tile's
+ * entries outgrew the direct form's LDS list (a pathologically hot tile: that step's sums are incomplete). */
+int amdkge_set_tile_direct(int on);
 /* status != 0 after a DETERMINISTIC step: some tile fell back to unsorted accumulation since the last query (flag is cleared).
  * Synchronises the stream. */
 /* Declares the hot rows of a workspace (d_hot_ids: device int32 [n_hot], n_hot <= 64; n_hot = 0 clears them).  The map and the
@@ -280,6 +286,19 @@ int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d
  * hi=off[i+1]).  Ids are table row ids; they are kept if ent_lo <= id < ent_hi (partition rule
  * :280-288) and, when d_subset_pos != NULL (int32 [n_ents], -1 = not in entities_subset,
  * :266-275), if d_subset_pos[id] >= 0.  d_sub[n] int32 += #{f : q(pos) <= q(corr_f)}. */
+/* The filter index itself, built on the device (kge_filter.hip): the CSR that amdkge_filter_ranges searches, from the
+ * concatenated, id-mapped filter datasets -- replaces the reference's per-batch pandas group-by + `sum(lists, [])`
+ * (datasets/graph_data_loader.py:287-350,382-439).  side S: groups keyed (p * n_ents + o) with the SET of subjects seen with
+ * them; side O: groups keyed (s * n_rels + p) with the SET of objects.
+ *   d_triples : int32 [m, 3] (duplicates allowed: the datasets may overlap)
+ *   d_keys    : int64 [m]      out: the sorted distinct group keys (first n_groups valid)
+ *   d_start   : int64 [m + 1]  out: CSR offsets into d_ids (first n_groups + 1 valid)
+ *   d_ids     : int32 [m]      out: the values, ascending within a group (first n_unique valid)
+ *   d_counts  : int64 [2]      out: n_groups, n_unique (read them back after synchronising the stream)
+ *   d_work    : amdkge_filter_build_workspace_bytes(m, n_ents, n_rels) bytes.  n_rels * n_ents^2 must be < 2^63. */
+int64_t amdkge_filter_build_workspace_bytes(int64_t m, int64_t n_ents, int64_t n_rels);
+int amdkge_filter_build(const int32_t* d_triples, int64_t m, int32_t side, int64_t n_ents, int64_t n_rels,
+                        int64_t* d_keys, int64_t* d_start, int32_t* d_ids, int64_t* d_counts, void* d_work, void* stream);
 int amdkge_rank_filter(const amdkge_model* m, const float* d_ent, const float* d_rel,
                        const int32_t* d_triples, int64_t n, int32_t side,
                        const int64_t* d_flt_lo, const int64_t* d_flt_hi, const int32_t* d_flt_ids,

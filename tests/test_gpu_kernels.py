@@ -689,6 +689,38 @@ def test_filter_ranges_kernel_equals_host_lookup(gpu_lib):
             assert np.array_equal(lo, l2.cpu().numpy()) and np.array_equal(hi, h2.cpu().numpy()), sd
 
 
+def test_filter_index_built_on_device_equals_host_build(gpu_lib):
+    """amdkge_filter_build (keys, radix sort, scan, scatter on the device) produces the very arrays of the host build
+    (datasets/filters.py: numpy unique / searchsorted, itself pinned by the reference's KAT and the oracle's sets): group keys,
+    CSR offsets and ids, for overlapping datasets (duplicates collapse), the reference's KAT, an empty index, one triple, and
+    ids near the top of a 50 M-entity range (keys beyond 2^53)."""
+    from ampligraph_amd.datasets.filters import FilterIndex
+
+    eng, _, _ = make_engine("DistMult", 8, 16, 3)
+    rng = np.random.default_rng(4)
+    cases = []
+    X = rand_triples(rng, 20000, 300, 7)
+    cases.append(([X, X[:5000], rand_triples(rng, 3000, 300, 7)], 300, 7))
+    cases.append(([np.array([[1, 1, 2], [1, 1, 3], [1, 1, 4], [5, 1, 3], [5, 1, 4], [6, 1, 3], [6, 1, 2], [6, 1, 4], [6, 1, 7]]),
+                   np.array([[3, 1, 2], [4, 1, 3], [5, 1, 4], [5, 1, 2], [1, 1, 5]]), np.array([[3, 1, 6], [2, 1, 2], [1, 1, 6]])], 8, 2))
+    cases.append(([], 8, 2))
+    cases.append(([np.array([[7, 1, 0]])], 8, 2))
+    N_big = 50_000_000
+    big = np.stack([rng.integers(N_big - 1000, N_big, 5000), rng.integers(0, 1000, 5000), rng.integers(N_big - 50, N_big, 5000)], 1)
+    cases.append(([big, big[:100]], N_big, 1000))
+    for datasets, N, R in cases:
+        host = FilterIndex(datasets, N, R)
+        devi = FilterIndex(datasets, N, R, engine=eng)
+        for nm in ("po_keys", "po_start", "s_ids", "sp_keys", "sp_start", "o_ids"):
+            a, b = getattr(host, nm), getattr(devi, nm)
+            assert a.shape == b.shape and np.array_equal(a, b), (nm, N, a[:5], b[:5])
+        T = np.concatenate([np.asarray(d) for d in datasets])[:500] if datasets else rand_triples(rng, 10, N, R)
+        for sd, fn in (("s", host.subject_ranges), ("o", host.object_ranges)):
+            lo, hi = fn(T)
+            l2, h2, ids = devi.device_filter(eng, dev(T.astype(np.int32)), sd)
+            assert np.array_equal(lo, l2.cpu().numpy()) and np.array_equal(hi, h2.cpu().numpy()), sd
+
+
 @pytest.mark.parametrize("model,k", [("ComplEx", 16), ("TransE", 50), ("RotatE", 9), ("DistMult", 600)])
 def test_tiled_hot_rows_parity(gpu_lib, model, k):
     """AMDKGE_TILED_HOT_ROWS: a few entities are the s / o of most positives; their own-row gradients go through replica rows

@@ -1,0 +1,98 @@
+"""The row-direct tile pass for long rows (kge_tile_direct.h; rows beyond 2 KB: the C5 row width) -- whole steps against the
+oracle and against the LDS-accumulator kernel it replaces there (amdkge_set_tile_direct(0)), in every mode the tile pass has:
+in place / gradient only, touched-rows optimizer, atomic positives, hot-row replicas, overflowing buckets, every update rule."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kge_oracle as O
+from test_gpu_kernels import assert_grads_close, dense, dev, loss_desc, make_engine, make_optimizer, rand_triples, run_tiled_grads
+
+pytestmark = pytest.mark.gpu
+
+WIDE = [("RotatE", 1000), ("ComplEx", 600), ("DistMult", 2048), ("TransE", 600), ("HolE", 516), ("RotatE", 1001), ("TransE", 2044)]
+
+
+@pytest.fixture
+def direct_switch(gpu_lib):
+    yield lambda on: gpu_lib.amdkge_set_tile_direct(1 if on else 0)
+    gpu_lib.amdkge_set_tile_direct(1)
+
+
+@pytest.mark.parametrize("model,k", WIDE)
+def test_direct_gradients_match_oracle_and_lds_kernel(gpu_lib, direct_switch, model, k):
+    N, R, B, eta = 150, 4, 300, 6
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.08)
+    rng = np.random.default_rng(2)
+    X = rand_triples(rng, B, N, R)
+    negs = O.generate_corruptions(X, N, eta, 3, 1)
+    total, Te, Tr, _ = O.dense_gradients(model, ent, rel, X, negs, eta, "self_adversarial", None, "sum", R)
+    out = {}
+    for on in (True, False):
+        direct_switch(on)
+        for pa in (False, True):
+            L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, "self_adversarial", "sum", 3, 1, pos_atomic=pa)
+            assert abs(L - float(total)) <= 2e-5 * max(1.0, abs(L)), (on, pa)
+            assert_grads_close(Ge, Te)
+            assert_grads_close(Gr, Tr)
+            out[(on, pa)] = Ge
+    assert np.allclose(out[(True, False)], out[(False, False)], rtol=1e-4, atol=1e-6 * np.abs(Te).max())
+
+
+@pytest.mark.parametrize("opt", ["adam", "adagrad", "sgd", "sgd+momentum", "rmsprop", "rmsprop+momentum", "adadelta", "adamax"])
+@pytest.mark.parametrize("model,k,reg", [("RotatE", 1000, (3, 1e-2)), ("ComplEx", 600, None), ("TransE", 600, (2, 1e-3))])
+def test_direct_step_in_place_parity(gpu_lib, opt, model, k, reg):
+    """Whole steps (tables + slots updated row by row from registers) == oracle train_step, 3 steps, dense and touched-rows mode."""
+    N, R, B, eta = 120, 4, 60, 3   # B * (eta + 2) = 300 entries on 120 rows: some rows stay untouched
+    for lazy in (False, True):
+        eng, ent, rel = make_engine(model, k, N, R, scale=0.08)
+        w, mk = make_optimizer(opt.split("+")[0], {"momentum": 0.7} if "+" in opt else {})
+        w.lazy = lazy
+        eng.prepare_training(w.name)
+        st = mk(ent, rel)
+        rng = np.random.default_rng(6)
+        oreg = None if reg is None else dict(p=reg[0], lam_e=reg[1], lam_r=reg[1])
+        lam = reg[1] if reg else 0.0
+        for t in range(1, 4):
+            X = rand_triples(rng, B, N, R)
+            before = eng.ent.clone()
+            eng.loss_acc.zero_()
+            eng.train_step_tiled(dev(X), eta, loss_desc("self_adversarial"), w.to_ffi(t, reg[0] if reg else 2), 77, t, reg_e=lam, reg_r=lam)
+            ref_loss = float(O.train_step(st, model, X, eta, "self_adversarial", 77, t, max_rel_size=R, reg=oreg, lazy=lazy))
+            torch.cuda.synchronize()
+            got_loss = float(eng.loss_acc[0].item()) + float(eng.loss_acc[1].item())
+            assert abs(got_loss - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss)), (lazy, t, got_loss, ref_loss)
+            e, r = eng.get_tables()
+            ce = np.abs(e - st.ent) <= 1e-5 + 1e-4 * np.abs(st.ent)
+            assert ce.mean() > 0.995 and np.abs(e - st.ent).max() < 2.5e-2, (opt, model, lazy, t, ce.mean())
+            if lazy:   # rows without an entry keep their bits
+                negs = O.generate_corruptions(X, N, eta, 77, t)
+                touched = np.zeros(N, dtype=bool)
+                touched[np.concatenate([X[:, 0], X[:, 2], negs[:, 0], negs[:, 2]])] = True
+                assert (~touched).sum() > 0
+                assert torch.equal(eng.ent[torch.as_tensor(~touched).cuda()], before[torch.as_tensor(~touched).cuda()])
+            for nme in st.slots:
+                ok = np.isclose(dense(eng, eng.slots[nme]), st.slots[nme], rtol=1e-3, atol=1e-6 + 2e-5 * np.abs(st.slots[nme]).max())
+                assert ok.mean() > (0.99 if w.name == "rmsprop_mom" and nme.startswith("mom") else 0.999), (nme, lazy, t, ok.mean())
+        assert eng.tiled_status() == 0
+
+
+@pytest.mark.parametrize("model,k", [("ComplEx", 600), ("RotatE", 1000)])
+def test_direct_overflowing_bucket_and_hot_rows(gpu_lib, model, k):
+    """Every positive shares one subject: its tile's bucket overflows into the shared list (filtered into the LDS list by the
+    owning tile); the same batch with that entity declared hot (replica rows) gives the same gradients."""
+    N, R, eta, B = 200, 3, 2, 1500
+    eng, ent, rel = make_engine(model, k, N, R, scale=0.08)
+    rng = np.random.default_rng(8)
+    X = rand_triples(rng, B, N, R)
+    X[:, 0] = 7
+    X[::5, 2] = 7
+    negs = O.generate_corruptions(X, N, eta, 5, 2)
+    total, Te, Tr, _ = O.dense_gradients(model, ent, rel, X, negs, eta, "nll", None, "sum", R)
+    for hot in (False, True):
+        eng.set_hot_rows(np.array([7], dtype=np.int32) if hot else None)
+        L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, "nll", "sum", 5, 2)
+        assert abs(L - float(total)) <= 2e-5 * max(1.0, abs(L))
+        assert_grads_close(Ge, Te, tol=1e-4)
+        assert_grads_close(Gr, Tr, tol=1e-4)
+        assert eng.tiled_status() == 0
