@@ -89,6 +89,8 @@ SIGNATURES = {
     "amdkge_unpack_rows": (C.c_int, [C.POINTER(Model), P, I64, P, P]),
     "amdkge_set_rank_kernel": (C.c_int, [C.c_int]),
     "amdkge_set_rank_rotate_fast": (C.c_int, [C.c_int]),
+    "amdkge_rank_screen_workspace_bytes": (I64, [C.POINTER(Model), I64, I64]),
+    "amdkge_rank_counts_screened": (C.c_int, [C.POINTER(Model), P, P, P, I64, I32, P, I64, I64, P, P, P, I64, P]),
     "amdkge_set_tile_direct": (C.c_int, [C.c_int]),
     "amdkge_filter_build_workspace_bytes": (I64, [I64, I64, I64]),
     "amdkge_filter_build": (C.c_int, [P, I64, I32, I64, I64, P, P, P, P, P, P]),

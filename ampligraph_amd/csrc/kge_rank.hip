@@ -174,6 +174,7 @@ struct CountArgs {
     int qtiles, splits;   // MFMA kernel: logical grid, decoded from a 1-D XCD-aware launch
     float* scores;        // STORE variant of the VALU tile kernel: [n][ld] un-quantised scores instead of counts
     int64_t ld;
+    const int* guard;     // pipelined MFMA kernel as the fall-back of the int8 screening pass: runs only if *guard != 0
 };
 
 template <int MODE, bool V4, bool STORE = false>
@@ -713,6 +714,7 @@ __global__ __launch_bounds__(256, 2) void rank_count_mfma_pipe_kernel(CountArgs 
     tile_t Es = reinterpret_cast<tile_t>(smem_rank + (size_t)2 * MK * MLD * sizeof(float));
     int* qps = reinterpret_cast<int*>(smem_rank + (size_t)4 * MK * MLD * sizeof(float));
 
+    if (a.guard && *a.guard == 0) return;   // (screened call that did not overflow its recheck list: nothing to do)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = (wv >> 1) * 64, we = (wv & 1) * 64;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -1038,6 +1040,10 @@ __global__ void rank_compose_kernel(const int32_t* counts, const int32_t* sub, i
     ranks[i * stride] = r + 1;                                      // ScoringBasedEmbeddingModel.py:1684
 }
 
+}  // namespace kge
+#include "kge_rank_screen.h"
+namespace kge {
+
 static inline char* align_up(char* p, size_t a) { return (char*)(((uintptr_t)p + a - 1) & ~(uintptr_t)(a - 1)); }
 
 struct Workspace {
@@ -1070,6 +1076,55 @@ static int run_prep(const amdkge_model* m, const float* d_ent, const float* d_re
     return check_launch("rank_prep");
 }
 
+static inline bool sgn_scale_positive(const ModelConst& mc) { return mc.score_sign * mc.score_scale > 0.f; }
+
+// the screening sequence of one rank_counts call (see kge_rank_screen.h); counts of decided + rechecked pairs are merged into
+// d_counts unless the recheck list overflowed (flag at counter[1]: the guarded exact kernel then produces them)
+static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* d_ent_ids, int64_t ent_lo, int64_t mcand, int64_t n,
+                      const RankGeom& g, const Workspace& w, const ModelConst& mc, int32_t* d_counts, void* d_screen, size_t screen_bytes,
+                      hipStream_t st) {
+    ScreenBufs b = carve_screen(d_screen, screen_bytes, n, mcand, g.U);
+    const float sgn_scale = mc.score_sign * mc.score_scale;
+    if (hipError_t e = hipMemsetAsync(b.counter, 0, 256 + scr_up((size_t)n * 8), st)) return set_error_hip(e, "hipMemsetAsync(screen counters)");
+    const double u = ldexp(1.0, -24), gam = (double)g.U * u / (1.0 - (double)g.U * u);
+    hipLaunchKernelGGL(rank_limbs_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.Q, (int64_t)g.QW, (const int32_t*)nullptr, (int64_t)0, n, g.U, b.S,
+                       (float)(gam * (1.0 + 1e-6)), b.qlimbs, b.qm);
+    if (int rc = check_launch("rank_limbs(Q)")) return rc;
+    hipLaunchKernelGGL(rank_limbs_kernel, dim3((unsigned)((mcand + 3) / 4)), dim3(256), 0, st, d_ent, (int64_t)g.K, d_ent_ids, ent_lo, mcand, g.U, b.S, 1.f,
+                       b.elimbs, b.em);
+    if (int rc = check_launch("rank_limbs(E)")) return rc;
+    hipLaunchKernelGGL(rank_thresholds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.qpos, n, sgn_scale, b.qt);
+    if (int rc = check_launch("rank_thresholds")) return rc;
+    ScreenArgs sa{};
+    sa.b = b; sa.n = n; sa.m = mcand; sa.U = g.U;
+    sa.drop = (float)((double)g.U * (8388608.0 + 16384.0 + 0.25) * (1.0 + 1e-6));
+    const int64_t qtiles = (n + SCR_Q - 1) / SCR_Q, etiles = (mcand + SCR_ET - 1) / SCR_ET;
+    // two workgroups per CU: ~8 rounds of blocks, each block a run of entity tiles (its query fragments stay in L1 / L2)
+    int64_t tiles_per = (qtiles * etiles + 16 * 256 - 1) / (16 * 256);
+    if (tiles_per < 1) tiles_per = 1;
+    if (tiles_per > 16384) tiles_per = 16384;   // (a lane's packed 16-bit counters see 2 candidates per tile)
+    if (tiles_per > etiles) tiles_per = etiles;
+    const int64_t splits = (etiles + tiles_per - 1) / tiles_per;
+    sa.ent_per_block = (int)(tiles_per * SCR_ET); sa.qtiles = (int)qtiles; sa.splits = (int)splits;
+    const int64_t nblk = 8 * ((qtiles + 7) / 8) * splits;
+    if (nblk > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES))
+            return set_error_hip(e, "hipFuncSetAttribute(rank_screen)");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(rank_screen_kernel, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
+    if (int rc = check_launch("rank_screen")) return rc;
+    RecheckArgs ra{};
+    ra.ent = d_ent; ra.Q = w.Q; ra.qpos = w.qpos; ra.ent_ids = d_ent_ids; ra.ent_lo = ent_lo; ra.U = g.U; ra.K = g.K; ra.QW = g.QW;
+    ra.sgn_scale = sgn_scale; ra.b = b;
+    hipLaunchKernelGGL(rank_recheck_kernel, dim3(2048), dim3(256), 0, st, ra);
+    if (int rc = check_launch("rank_recheck")) return rc;
+    hipLaunchKernelGGL(rank_screen_merge_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, st, b, n, d_counts);
+    return check_launch("rank_screen_merge");
+}
+
 }  // namespace kge
 
 using namespace kge;
@@ -1077,7 +1132,7 @@ using namespace kge;
 static int g_rank_kernel = 0;
 
 extern "C" int amdkge_set_rank_kernel(int which) {
-    if (which < 0 || which > 2) return set_error(AMDKGE_EINVAL, "set_rank_kernel: 0 = automatic, 1 = VALU tile kernel, 2 = first MFMA kernel");
+    if (which < 0 || which > 3) return set_error(AMDKGE_EINVAL, "set_rank_kernel: 0 = automatic, 1 = VALU tile kernel, 2 = first MFMA kernel, 3 = pipelined fp32 MFMA kernel without the int8 screening pass");
     g_rank_kernel = which;
     return AMDKGE_OK;
 }
@@ -1093,9 +1148,33 @@ extern "C" int64_t amdkge_rank_workspace_bytes(const amdkge_model* m, int64_t n)
     return 1024 + ((n * 4 + 255) / 256) * 256 + n * qw * 4;
 }
 
+static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
+                            int64_t n, int32_t side, const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
+                            int32_t* d_counts, void* d_work, void* d_screen, int64_t screen_bytes, void* stream);
+
 extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
                                   int64_t n, int32_t side, const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
                                   int32_t* d_counts, void* d_work, void* stream) {
+    return rank_counts_impl(m, d_ent, d_rel, d_triples, n, side, d_ent_ids, ent_lo, ent_hi, d_counts, d_work, nullptr, 0, stream);
+}
+
+extern "C" int64_t amdkge_rank_screen_workspace_bytes(const amdkge_model* m, int64_t n, int64_t n_cand) {
+    if (validate_model(m) != AMDKGE_OK || n < 0 || n_cand < 0) return -1;
+    if (mode_of(m->scoring_type, AMDKGE_SIDE_S) != MODE_DOT) return 0;   // TransE / RotatE: no screening pass
+    int64_t pairs = n * n_cand / 32;   // room for ~3 % of the comparisons (typically ~0.2 % are undecided)
+    if (pairs < (1 << 20)) pairs = 1 << 20;
+    return (int64_t)screen_fixed_bytes(n, n_cand, row_floats(m)) + pairs * 8 + 512;
+}
+
+extern "C" int amdkge_rank_counts_screened(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
+                                           int64_t n, int32_t side, const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
+                                           int32_t* d_counts, void* d_work, void* d_screen, int64_t screen_bytes, void* stream) {
+    return rank_counts_impl(m, d_ent, d_rel, d_triples, n, side, d_ent_ids, ent_lo, ent_hi, d_counts, d_work, d_screen, screen_bytes, stream);
+}
+
+static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
+                            int64_t n, int32_t side, const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
+                            int32_t* d_counts, void* d_work, void* d_screen, int64_t screen_bytes, void* stream) {
     if (int rc = validate_model(m)) return rc;
     if (side != AMDKGE_SIDE_S && side != AMDKGE_SIDE_O) return set_error(AMDKGE_EINVAL, "rank_counts: side must be AMDKGE_SIDE_S or AMDKGE_SIDE_O");
     if (n < 0 || ent_lo < 0 || ent_hi < ent_lo) return set_error(AMDKGE_EINVAL, "rank_counts: bad sizes");
@@ -1114,7 +1193,7 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
     const int mode = mode_of(m->scoring_type, side);
     const bool rot_exact = (mode == MODE_ROT_O || mode == MODE_ROT_S) && !g_rotate_fast;
     const bool v4 = (rot_exact || g.U % 4 == 0) && (g.eplane % 4 == 0) && (g.K % 4 == 0);
-    const int force = g_rank_kernel;   // amdkge_set_rank_kernel (tests): 1 forces the VALU tile kernel, 2 the first MFMA kernel
+    const int force = g_rank_kernel;   // amdkge_set_rank_kernel (tests): 1 forces the VALU tile kernel, 2 the first MFMA kernel, 3 the pipelined one unscreened
     const bool mfma = (mode == MODE_DOT) && force != 1;
     const int qt = mfma ? MQ : QT, et_ = mfma ? ME : ET;
     const int64_t qtiles = (n + qt - 1) / qt;
@@ -1161,6 +1240,14 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
         if (nblk > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch; split the triples or the entity range");
         const dim3 grid1((unsigned)nblk);
         const bool pipe = force != 2;
+        // ---- int8 screening pass + exact recheck (kge_rank_screen.h) when the caller supplied its workspace: same counts, bit
+        //      for bit; the exact kernel below then runs only as the fall-back of an overflowing recheck list ----
+        const int64_t mcand = ent_hi - ent_lo;
+        if (d_screen && force == 0 && v4 && pipe && g.eplane == 0 && n >= 128 && mcand >= 512 && sgn_scale_positive(mc) &&
+            screen_bytes >= (int64_t)screen_fixed_bytes(n, mcand, g.U) + (1 << 16)) {
+            if (int rc = run_screen(m, d_ent, d_ent_ids, ent_lo, mcand, n, g, w, mc, d_counts, d_screen, (size_t)screen_bytes, st)) return rc;
+            a.guard = carve_screen(d_screen, (size_t)screen_bytes, n, mcand, g.U).counter + 1;
+        }
         if (v4 && pipe) hipLaunchKernelGGL(rank_count_mfma_pipe_kernel, grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         else if (v4) hipLaunchKernelGGL((rank_count_mfma_kernel<true>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         else hipLaunchKernelGGL((rank_count_mfma_kernel<false>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);

@@ -1,0 +1,462 @@
+// evaluate(), contraction models (DistMult / ComplEx / HolE): EXACT ranks from an int8 matrix-core screening pass.
+// Included by kge_rank.hip (namespace kge) behind the fp32 kernels, whose CountArgs / quantise / prep it shares.
+//
+// The declared score of a (query i, entity j) pair is the fp32 chain  S_ij = fmaf(q_U e_U, ... fmaf(q_1 e_1, 0))  in table
+// order (rank_op<MODE_DOT>; v_mfma_f32_32x32x2_f32 reproduces it bit for bit at the fp32 VECTOR rate, 157 TFLOP/s).  A rank
+// does not need S_ij, only on which side of two thresholds it lies: with qp = q(positive) and q(.) = int(sgn_scale * S * 1000)
+// monotone in S (sgn_scale > 0 for these models),
+//     "greater"  <=>  S_ij >= T_gt(i)          "equal"  <=>  T_ge(i) <= S_ij < T_gt(i)
+// where T_ge / T_gt are the smallest fp32 values whose quantised score reaches qp / qp + 1 (found per query by bisection over
+// the ordered fp32 bit patterns, with the kernels' own quantise()).  So:
+//   1. rows are converted to 24-bit fixed point with a power-of-two scale PER ROW, as three signed 8-bit limbs
+//      (rank_limbs_kernel; also the row's 1- and 2-norms);
+//   2. the screening kernel forms  D~_ij = sum_k vq_ik ve_jk  with v_mfma_i32_32x32x32_i8 -- INTEGER arithmetic, exact, at ~28x
+//      the fp32 matrix rate per instruction -- keeping the limb products down to weight 2^16 (6 of the 9: three int32
+//      accumulators per output), and bounds |D~_ij A_i B_j - S_ij| RIGOROUSLY by
+//          E_ij = gamma_U |q_i|_2 |e_j|_2                      (the fp32 chain's own rounding, U fused operations)
+//               + (A_i |e_j|_1 + B_j |q_i|_1) / 2 + U A_i B_j / 4   (rounding of the rows to their fixed-point grids)
+//               + U (2^23 + 2^14) A_i B_j                      (the three dropped limb products)
+//               + 8 u |S~|                                     (the epilogue's own fp32 roundings), all inflated by 2^-10;
+//      a pair whose interval [S~ - E, S~ + E] lies on one side of both thresholds (or between them) is DECIDED and counted;
+//   3. the others (a fraction of a per cent: those within ~1e-4 of the positive's quantisation cell) go to a list and are
+//      recomputed by rank_recheck_kernel with the exact fp32 chain -- so the counts are bit-identical to the fp32 kernels
+//      whatever the tables hold (rows with inf / NaN get an infinite bound: everything of theirs is rechecked).
+// If the list overflows its capacity the whole call falls back to the exact fp32 MFMA kernel (device-side flag, no host
+// round trip).  Nothing here approximates a result: the int8 pass only decides which comparisons need the exact chain.
+#pragma once
+
+namespace kge {
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+constexpr int SCR_Q = 128, SCR_K = 32;   // queries per workgroup (4 waves x 32), units per stage
+constexpr int SCR_ROW_SLAB = 96;                       // bytes of one row per K slab: 3 limbs x 32 units
+// Limb storage is FRAGMENT-MAJOR: [block of 32 rows][slab][limb][half][row % 32][16 bytes] -- the 64 lanes of a matrix operand
+// fragment (lane = half * 32 + row % 32, 16 units each) read 1 KB of CONSECUTIVE memory, from global memory as from LDS.
+constexpr int SCR_BLK_SLAB = 32 * SCR_ROW_SLAB;        // bytes of one 32-row block per K slab (3 072)
+
+struct ScreenBufs {
+    int* counter;        // [0] undecided pairs appended, [1] overflow flag
+    int32_t* counts;     // [n][2] this call's (greater, equal) counts (merged into the caller's unless the call fell back)
+    int8_t* qlimbs;      // [ceil(n / 32)][S][3][2][32][16]
+    float4* qm;          // [n] {A = 2^-a, gamma_U |q|_2, |q|_1 / 2, 0}, all rounded up
+    float2* qt;          // [n] {T_ge, T_gt}
+    int8_t* elimbs;      // [ceil(m / 32)][S][3][2][32][16]
+    float4* em;          // [m] {B, |e|_2, |e|_1 / 2, 0}
+    int2* pairs;         // [cap] (query, candidate position)
+    int64_t cap;
+    int S;               // K slabs per row
+};
+
+static inline size_t scr_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// fixed part of the workspace (everything but the pair list), for n queries against m candidates of U units
+static inline size_t screen_fixed_bytes(int64_t n, int64_t m, int U) {
+    const size_t S = (size_t)(U + SCR_K - 1) / SCR_K;
+    const size_t nb = (size_t)(n + 31) / 32 + 4, mb = (size_t)(m + 31) / 32 + 4;   // (+ a tile of slack: loaders read whole 128-row tiles)
+    return 256 + scr_up((size_t)n * 8) + scr_up(nb * S * SCR_BLK_SLAB) + scr_up((size_t)n * 16) + scr_up((size_t)n * 8) +
+           scr_up(mb * S * SCR_BLK_SLAB) + scr_up((size_t)m * 16);
+}
+
+static inline ScreenBufs carve_screen(void* d_screen, size_t bytes, int64_t n, int64_t m, int U) {
+    ScreenBufs b;
+    b.S = (U + SCR_K - 1) / SCR_K;
+    char* p = (char*)(((uintptr_t)d_screen + 255) & ~(uintptr_t)255);
+    const char* end = (char*)d_screen + bytes;
+    b.counter = (int*)p; p += 256;
+    b.counts = (int32_t*)p; p += scr_up((size_t)n * 8);
+    b.qlimbs = (int8_t*)p; p += scr_up(((size_t)(n + 31) / 32 + 4) * b.S * SCR_BLK_SLAB);
+    b.qm = (float4*)p; p += scr_up((size_t)n * 16);
+    b.qt = (float2*)p; p += scr_up((size_t)n * 8);
+    b.elimbs = (int8_t*)p; p += scr_up(((size_t)(m + 31) / 32 + 4) * b.S * SCR_BLK_SLAB);
+    b.em = (float4*)p; p += scr_up((size_t)m * 16);
+    b.pairs = (int2*)p;
+    b.cap = end > p ? (int64_t)((end - p) / 8) : 0;
+    return b;
+}
+
+// ---- 1. rows -> fixed point limbs + norms: one wave per row --------------------------------------------------------------------
+// src row r: table[ids ? ids[lo + r] : lo + r] (stride K floats), U units walked (whole float4s: U % 4 == 0).
+// out: limbs in the fragment-major layout (units beyond U are zero), meta[r] = {scale, n2 * gamma (gamma = 1 for the entity side), n1 / 2, 0}.
+__global__ __launch_bounds__(256) void rank_limbs_kernel(const float* __restrict__ table, int64_t stride, const int32_t* __restrict__ ids, int64_t lo,
+                                                         int64_t nrows, int U, int S, float gamma, int8_t* __restrict__ limbs, float4* __restrict__ meta) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int64_t id = ids ? (int64_t)ids[lo + r] : lo + r;
+    const float4* row = reinterpret_cast<const float4*>(table + id * stride);
+    const int nq = U >> 2;
+    float mx = 0.f, n1 = 0.f, n2 = 0.f;
+    bool bad = false;
+    for (int q = lane; q < nq; q += 64) {
+        const float4 t = row[q];
+        const float a0 = fabsf(t.x), a1 = fabsf(t.y), a2 = fabsf(t.z), a3 = fabsf(t.w);
+        bad |= !(a0 < INFINITY) || !(a1 < INFINITY) || !(a2 < INFINITY) || !(a3 < INFINITY);
+        mx = fmaxf(fmaxf(mx, fmaxf(a0, a1)), fmaxf(a2, a3));
+        n1 += (a0 + a1) + (a2 + a3);
+        n2 = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, fmaf(a3, a3, n2))));
+    }
+    mx = wave_max(mx);
+    n1 = wave_sum_shfl(n1);
+    n2 = wave_sum_shfl(n2);
+    bad = __ballot(bad) != 0ull;
+    // scale: |x| * 2^a <= 2^22 for every unit of the row (limb l0 within +-65); a zero row takes a = 0
+    int ex = 0;
+    if (mx > 0.f) (void)frexpf(mx, &ex);          // mx = f * 2^ex, f in [0.5, 1)
+    int a = 22 - ex;
+    a = a > 120 ? 120 : (a < -100 ? -100 : a);    // (denormal-sized or huge rows: the scale stays a normal fp32; see the norms below)
+    const float up = ldexpf(1.f, a), A = ldexpf(1.f, -a);
+    // norms rounded up: fp32 accumulation of U non-negative terms is within (U + 8) u relative -- 2^-10 covers every U <= 8192
+    const float infl = 1.f + 0x1p-10f;
+    float m_n2 = sqrtf(n2) * infl * infl * gamma, m_n1 = 0.5f * n1 * infl;
+    // rows the fixed-point grid cannot represent to within A / 2 (inf / NaN units, or units that would overflow 2^22 after the
+    // clamp of `a`): an infinite bound sends every pair of the row to the exact recheck
+    if (bad || mx * up > 4194304.f) { m_n2 = INFINITY; m_n1 = INFINITY; }
+    if (lane == 0) meta[r] = make_float4(A, m_n2, m_n1, 0.f);
+    int8_t* out = limbs + (r >> 5) * (int64_t)S * SCR_BLK_SLAB + (r & 31) * 16;
+    for (int q = lane; q < S * 8; q += 64) {   // 4 units per step, 8 steps per slab
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq && !bad) t = row[q];
+        int v[4] = {(int)rintf(t.x * up), (int)rintf(t.y * up), (int)rintf(t.z * up), (int)rintf(t.w * up)};
+        uint32_t p0 = 0, p1 = 0, p2 = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // balanced base-256 digits: v = l0 2^16 + l1 2^8 + l2, l1, l2 in [-128, 127], |l0| <= 65
+            const int l2 = ((v[c] + 128) & 255) - 128;
+            const int v1 = (v[c] - l2) >> 8;
+            const int l1 = ((v1 + 128) & 255) - 128;
+            const int l0 = (v1 - l1) >> 8;
+            p0 |= (uint32_t)(l0 & 255) << (8 * c); p1 |= (uint32_t)(l1 & 255) << (8 * c); p2 |= (uint32_t)(l2 & 255) << (8 * c);
+        }
+        // units 4 w .. 4 w + 3 of slab `slab`: half = w >> 2, dword w & 3 of this row's 16-byte piece; pieces of (limb, half) are
+        // 512 bytes apart, limbs 1 024
+        const int slab = q >> 3, w = q & 7;
+        uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)slab * SCR_BLK_SLAB + (w >> 2) * 512) + (w & 3);
+        o[0] = p0; o[256] = p1; o[512] = p2;
+    }
+}
+
+// ---- thresholds: smallest fp32 S with quantise(sgn_scale * S) >= target, by bisection over the ordered bit patterns ----------
+__device__ __forceinline__ float f_of_ord(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o); }
+__device__ __forceinline__ float least_with_quantised_at_least(float sgn_scale, long long target) {
+    if (target > 2147483647ll) return INFINITY;
+    // ordered patterns of the finite floats: ord(-FLT_MAX) .. ord(+FLT_MAX)
+    uint32_t lo = ~0xFF7FFFFFu, hi = 0x7F7FFFFFu ^ 0x80000000u;   // ord(x) = x < 0 ? ~bits : bits ^ 0x80000000
+    if ((long long)quantise(sgn_scale * f_of_ord(hi)) < target) return INFINITY;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((long long)quantise(sgn_scale * f_of_ord(mid)) >= target) hi = mid; else lo = mid + 1;
+    }
+    return f_of_ord(lo);
+}
+__global__ void rank_thresholds_kernel(const int* __restrict__ qpos, int64_t n, float sgn_scale, float2* __restrict__ qt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long qp = qpos[i];
+    qt[i] = make_float2(least_with_quantised_at_least(sgn_scale, qp), least_with_quantised_at_least(sgn_scale, qp + 1));
+}
+
+// ---- 2. the screening kernel ------------------------------------------------------------------------------------------------------
+struct ScreenArgs {
+    ScreenBufs b;
+    int64_t n, m;          // queries, candidates (positions [0, m) of the call's candidate range)
+    int ent_per_block;     // candidates per workgroup (a multiple of SCR_ET)
+    int qtiles, splits;
+    int U;
+    float drop;            // U * (2^23 + 2^14 + 1/4)
+};
+
+constexpr int SCR_THREADS = 256;   // 4 waves, each a 32-query block against the workgroup's 64-entity tile; TWO workgroups per CU
+constexpr int SCR_ET = 64;         // entities per tile
+constexpr size_t SCR_LDS_BYTES = (size_t)2 * 3 * 2 * SCR_ET * 16 + 128 * 16 + 128 * 8 + SCR_ET * 16;   // E double-buffered + row metas
+
+// Operand feed.  The i8 matrix instruction retires 65 536 multiply-adds in ~33 cycles, so the kernel is bound by how fast the
+// operands arrive and by its epilogue, not by the matrix pipe.  A wave's QUERY fragments come straight from global memory
+// (L2 / L1) into registers, one stage ahead: in the fragment-major limb layout that is one coalesced 1 KB read per limb.  The
+// ENTITY slab, shared by the workgroup's four query blocks, is staged through LDS in the same order (a fragment read is 512
+// contiguous bytes per half-wave).  Two 256-thread workgroups share a CU (2 waves per SIMD, 256 registers each) and run out of
+// phase: one's epilogue (VALU) under the other's matrix work.
+__global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_scr[];
+    typedef uint4 (*slab_t)[3][2][SCR_ET];
+    slab_t Es = reinterpret_cast<slab_t>(smem_scr);
+    float4* qm_s = reinterpret_cast<float4*>(smem_scr + (size_t)2 * 3 * 2 * SCR_ET * 16);
+    float2* qt_s = reinterpret_cast<float2*>(qm_s + 128);
+    float4* em_s = reinterpret_cast<float4*>(qt_s + 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wq = wv * 32;
+    int bx, by;   // XCD-aware work order, as rank_count_mfma_kernel
+    {
+        const int xcd = blockIdx.x & 7;
+        const int64_t i = blockIdx.x >> 3;
+        const int qlo = (int)(((int64_t)a.qtiles * xcd) / 8), qhi = (int)(((int64_t)a.qtiles * (xcd + 1)) / 8);
+        const int nq = qhi - qlo;
+        if (i >= (int64_t)nq * a.splits) return;
+        const int full = nq / 8;
+        const int64_t per_group = (int64_t)8 * a.splits;
+        if (i < full * per_group) {
+            const int64_t r = i % per_group;
+            bx = qlo + (int)(i / per_group) * 8 + (int)(r & 7);
+            by = (int)(r >> 3);
+        } else {
+            const int rem = nq - full * 8;
+            const int64_t r = i - full * per_group;
+            bx = qlo + full * 8 + (int)(r % rem);
+            by = (int)(r / rem);
+        }
+    }
+    const int64_t q0 = (int64_t)bx * SCR_Q;
+    const int64_t e_begin = (int64_t)by * a.ent_per_block;
+    const int64_t e_end = min(a.m, e_begin + a.ent_per_block);
+    const int S = a.b.S;
+    const int64_t ntile = (e_end - e_begin + SCR_ET - 1) / SCR_ET;
+
+    if (tid < 128) {
+        // per query row, the constants of the error bound pre-combined and inflated by c = 1 + 2^-10 (covers the epilogue's own
+        // roundings of the bound):  {2^16 A,  c gamma |q|_2,  c A,  c (|q|_1 / 2 + drop A)}
+        const bool okq = q0 + tid < a.n;
+        const float4 m4 = a.b.qm[okq ? q0 + tid : a.n - 1];
+        const float c = 1.f + 0x1p-10f;
+        qm_s[tid] = make_float4(m4.x * 65536.f, m4.y * c, m4.x * c, fmaf(a.drop, m4.x, m4.z) * c);
+        qt_s[tid] = a.b.qt[okq ? q0 + tid : a.n - 1];
+    }
+    // outputs of rows beyond n (per lane: bits 2 r, 2 r + 1 of its 16 rows) and, per tile, of candidates beyond the range are
+    // cleared from the undecided mask; they cannot be counted either (see the -inf bias below)
+    uint32_t rowmask = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowmask |= (q0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.n) ? (3u << (2 * r)) : 0u;
+    // this wave's query fragments: block (q0 + wq) / 32, one coalesced 1 KB read per limb and slab (rows beyond n: the stale tail
+    // of the last block -- finite integers; their outputs are masked by the thresholds above)
+    const uint4* qsrc = reinterpret_cast<const uint4*>(a.b.qlimbs + ((q0 + wq) >> 5) * (int64_t)S * SCR_BLK_SLAB) + lane;
+    auto load_q = [&](int s, v4i32 (&f)[3]) {
+#pragma unroll
+        for (int lb = 0; lb < 3; ++lb) { const uint4 u = qsrc[(size_t)s * (SCR_BLK_SLAB / 16) + 64 * lb]; f[lb] = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
+    };
+    // entity slab loader: the tile's two 32-row blocks x 192 16-byte pieces per stage; piece p = tid (and tid + 256 < 384):
+    // block = p / 192, w = p % 192 = (limb * 2 + half) * 32 + row: global and LDS order coincide within a block
+    const int p0 = tid, p1 = tid + 256;
+    const bool second = p1 < 384;
+    const int b0 = p0 / 192, w0 = p0 % 192, b1 = (p1 % 384) / 192, w1 = (p1 % 384) % 192;
+    uint4* const lds0 = &Es[0][0][0][0] + (w0 >> 5) * SCR_ET + b0 * 32 + (w0 & 31);
+    uint4* const lds1 = &Es[0][0][0][0] + (w1 >> 5) * SCR_ET + b1 * 32 + (w1 & 31);
+    const uint4* esrc0 = nullptr;
+    const uint4* esrc1 = nullptr;
+    auto set_src = [&](int64_t et) {   // (et is a multiple of 64; blocks beyond the table's end are slack rows of the buffer)
+        esrc0 = reinterpret_cast<const uint4*>(a.b.elimbs + ((et >> 5) + b0) * (int64_t)S * SCR_BLK_SLAB) + w0;
+        esrc1 = reinterpret_cast<const uint4*>(a.b.elimbs + ((et >> 5) + b1) * (int64_t)S * SCR_BLK_SLAB) + w1;
+    };
+    // The (tile, slab) sequence is ONE stream of positions g = 0 .. ntile S - 1, software-pipelined two deep on the entity side:
+    // at position g the global loads of position g + 2 are issued (register set g % 2), the set loaded during g - 1 (position
+    // g + 1) goes to the other LDS buffer at the end, and the query fragments of g + 1 are requested for the next position --
+    // a round trip to L2 / the Infinity Cache (~2 000 cycles) is covered by two stages of matrix work of both resident
+    // workgroups instead of stalling every stage (measured: 2 950 cycles per stage with a one-deep pipeline against 385 of MFMA).
+    uint4 e00 = make_uint4(0, 0, 0, 0), e01 = e00, e10 = e00, e11 = e00;   // register sets 0 / 1 x the thread's two pieces (scalars: an array would live in scratch)
+    int ld_s = 0;
+    int64_t ld_tile = 0;
+    auto advance = [&]() {
+        if (++ld_s == S) {
+            ld_s = 0;
+            ld_tile = ld_tile + 1 < ntile ? ld_tile + 1 : ntile - 1;   // (past the end: harmless re-reads of the last tile)
+            set_src(e_begin + ld_tile * SCR_ET);
+        }
+    };
+    auto load_e = [&](uint4& pa, uint4& pb) {
+        pa = esrc0[(size_t)ld_s * (SCR_BLK_SLAB / 16)];
+        if (second) pb = esrc1[(size_t)ld_s * (SCR_BLK_SLAB / 16)];
+        advance();
+    };
+    auto store_e = [&](int buf, const uint4& pa, const uint4& pb) {
+        lds0[(size_t)buf * (6 * SCR_ET)] = pa;
+        if (second) lds1[(size_t)buf * (6 * SCR_ET)] = pb;
+    };
+
+    int cnt[16];   // per accumulator register (= query row of this lane): greater | equal << 16
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cnt[r] = 0;
+    v16i32 acc[3][2];   // [level][entity block]: level 0 = l0 l0', 1 = l0 l1' + l1 l0', 2 = l0 l2' + l1 l1' + l2 l0'
+#pragma unroll
+    for (int lv = 0; lv < 3; ++lv)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[lv][ni][r] = 0;
+
+    v4i32 qf[2][3];
+    set_src(e_begin);
+    load_e(e00, e01);        // position 0 -> LDS buffer 0
+    load_e(e10, e11);        // position 1 -> register set 1
+    load_q(0, qf[0]);
+    store_e(0, e00, e01);
+    __syncthreads();
+    int st = 0;
+    int64_t t = 0;
+    auto stage = [&](auto par_c) __attribute__((always_inline)) {
+        constexpr int P = decltype(par_c)::value;   // g % 2: this position's LDS buffer and query set, the register set free for g + 2
+        const int64_t et = e_begin + t * SCR_ET;
+        if (st == 0 && tid < SCR_ET) {   // candidates beyond the range: a bias of -inf on the score -- never counted
+            const bool oke = et + tid < e_end;
+            float4 m4 = a.b.em[oke ? et + tid : e_end - 1];
+            m4.w = oke ? 0.f : -INFINITY;
+            em_s[tid] = m4;   // (read in the epilogue: behind the stage barriers)
+        }
+        if constexpr (P == 0) load_e(e00, e01); else load_e(e10, e11);
+        load_q(st + 1 == S ? 0 : st + 1, qf[P ^ 1]);   // (the query rows do not change with the entity tile)
+        // both entity blocks' fragments first, then the 12 matrix instructions ordered so that two of them on the SAME accumulator
+        // are never adjacent (a dependent pair would wait out the first one's latency: twice its issue time)
+        v4i32 eb[2][3];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int lb = 0; lb < 3; ++lb) { const uint4 u = Es[P][lb][lh][ni * 32 + l31]; eb[ni][lb] = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
+        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][0], eb[0][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][0], eb[1][0], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][0], eb[0][1], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][0], eb[1][1], acc[1][1], 0, 0, 0);
+        acc[2][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][0], eb[0][2], acc[2][0], 0, 0, 0);
+        acc[2][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][0], eb[1][2], acc[2][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][1], eb[0][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][1], eb[1][0], acc[1][1], 0, 0, 0);
+        acc[2][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][1], eb[0][1], acc[2][0], 0, 0, 0);
+        acc[2][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][1], eb[1][1], acc[2][1], 0, 0, 0);
+        acc[2][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][2], eb[0][0], acc[2][0], 0, 0, 0);
+        acc[2][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][2], eb[1][0], acc[2][1], 0, 0, 0);
+        if constexpr (P == 0) store_e(1, e10, e11); else store_e(0, e00, e01);
+        __syncthreads();
+        if (++st == S) {
+        // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+            // Undecided outputs are only MARKED here (bit 2 r + ni of a per-lane mask); the appends to the recheck list happen once
+            // per tile behind the loop: one atomic per wave instead of a ballot, a branch and an atomic per output.
+            uint32_t undm = 0u;
+#pragma unroll 8
+            for (int r = 0; r < 16; ++r) {
+                asm volatile("" ::: "memory");   // (the row metas are read here, not hoisted for all 16 rows at once)
+                const int row = wq + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float4 qm = qm_s[row];
+                const float2 qt = qt_s[row];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float4 em = em_s[ni * 32 + l31];   // {B, |e|_2, |e|_1 / 2, 0 or -inf}
+                    // S~ = (L0 2^16 + L1 2^8 + L2) 2^16 A B   (+ the -inf bias of a candidate beyond the range)
+                    const float f = fmaf((float)acc[0][ni][r], 65536.f, fmaf((float)acc[1][ni][r], 256.f, (float)acc[2][ni][r]));
+                    const float s0 = f * (qm.x * em.x);
+                    const float sc = s0 + em.w;
+                    // E = c (gamma |q|_2 |e|_2 + A |e|_1 / 2 + B (|q|_1 / 2 + drop A)) + 2^-20 |S~|
+                    const float e = fmaf(0x1p-20f, fabsf(s0), fmaf(qm.y, em.y, fmaf(qm.z, em.z, qm.w * em.x)));
+                    const float lo = sc - e, hi = sc + e;
+                    const bool gt = lo >= qt.y, lt = hi < qt.x, eq = (lo >= qt.x) && (hi < qt.y);
+                    cnt[r] += gt ? 1 : 0;
+                    cnt[r] += eq ? 0x10000 : 0;
+                    undm |= !(gt || lt || eq) ? (1u << (2 * r + ni)) : 0u;   // (NaN bounds compare false everywhere: undecided)
+                }
+            }
+            undm &= rowmask;
+            if (et + l31 >= e_end) undm &= 0xAAAAAAAAu;        // candidate of block 0 beyond the range
+            if (et + 32 + l31 >= e_end) undm &= 0x55555555u;   // candidate of block 1 beyond the range
+            {
+                const int mine = __popc(undm);
+                int incl = mine;   // inclusive prefix over the wave
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
+                const int total = __shfl(incl, 63, 64);
+                if (total) {
+                    int base = 0;
+                    if (lane == 63) base = atomicAdd(a.b.counter, total);
+                    base = __shfl(base, 63, 64);
+                    int64_t at = (int64_t)base + incl - mine;
+                    uint32_t mm = undm;
+                    while (mm) {
+                        const int bit = __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const int r = bit >> 1, ni = bit & 1;
+                        if (at < a.b.cap) a.b.pairs[at] = make_int2((int)(q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh), (int)(et + ni * 32 + l31));
+                        else a.b.counter[1] = 1;   // the list is full: the call falls back to the exact kernel
+                        ++at;
+                    }
+                }
+            }
+
+#pragma unroll
+            for (int lv = 0; lv < 3; ++lv)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[lv][ni][r] = 0;
+            st = 0;
+            ++t;
+            __syncthreads();   // em_s is rewritten by the next tile
+        }
+    };
+    const int64_t G = ntile * S;
+    for (int64_t g = 0; g < G; g += 2) {
+        stage(std::integral_constant<int, 0>{});
+        if (g + 1 < G) stage(std::integral_constant<int, 1>{});
+    }
+    // ---- per query row: sum over the 32 lanes that share it ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int g = cnt[r] & 0xFFFF, e = cnt[r] >> 16;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); e += __shfl_xor(e, o, 64); }
+        const int64_t qi = q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (l31 == 0 && qi < a.n) {
+            if (g) atomicAdd(&a.b.counts[2 * qi + 0], g);
+            if (e) atomicAdd(&a.b.counts[2 * qi + 1], e);
+        }
+    }
+}
+
+// ---- 3. exact recheck of the undecided pairs: one lane per pair, the fp32 chain of rank_op<MODE_DOT> --------------------------
+struct RecheckArgs {
+    const float* ent;
+    const float* Q;
+    const int* qpos;
+    const int32_t* ent_ids;
+    int64_t ent_lo;
+    int U, K, QW;
+    float sgn_scale;
+    ScreenBufs b;
+};
+
+__global__ __launch_bounds__(256) void rank_recheck_kernel(RecheckArgs a) {
+    const int64_t npairs = min((int64_t)a.b.counter[0], a.b.cap);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (int64_t)gridDim.x * blockDim.x) {
+        const int2 pr = a.b.pairs[p];
+        const int64_t pos = a.ent_lo + pr.y;
+        const int64_t id = a.ent_ids ? (int64_t)a.ent_ids[pos] : pos;
+        const float4* q = reinterpret_cast<const float4*>(a.Q + (int64_t)pr.x * a.QW);
+        const float4* e = reinterpret_cast<const float4*>(a.ent + id * a.K);
+        float acc = 0.f;
+        const int nq = a.U >> 2;
+        int u = 0;
+        for (; u + 8 <= nq; u += 8) {   // a 128-byte line of each row per step: the eight loads are issued together
+            float4 qv[8], ev[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { qv[c] = q[u + c]; ev[c] = e[u + c]; }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                acc = fmaf(qv[c].x, ev[c].x, acc); acc = fmaf(qv[c].y, ev[c].y, acc);
+                acc = fmaf(qv[c].z, ev[c].z, acc); acc = fmaf(qv[c].w, ev[c].w, acc);
+            }
+        }
+        for (; u < nq; ++u) {
+            const float4 qv = q[u], ev = e[u];
+            acc = fmaf(qv.x, ev.x, acc); acc = fmaf(qv.y, ev.y, acc); acc = fmaf(qv.z, ev.z, acc); acc = fmaf(qv.w, ev.w, acc);
+        }
+        const int qs = quantise(a.sgn_scale * acc), qp = a.qpos[pr.x];
+        if (qp < qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 0], 1);
+        else if (qp == qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 1], 1);
+    }
+}
+
+// the call's counts join the caller's (+=) unless the pair list overflowed (then the exact kernel, guarded by the same flag,
+// produces them)
+__global__ void rank_screen_merge_kernel(ScreenBufs b, int64_t n, int32_t* __restrict__ counts) {
+    if (b.counter[1] != 0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * n && b.counts[i]) counts[i] += b.counts[i];
+}
+
+}  // namespace kge

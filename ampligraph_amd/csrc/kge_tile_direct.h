@@ -9,7 +9,11 @@
 // streams (profiles/r03a_c5_shard_kernels_and_pmc.json).  It also reads a touched row's x twice: once as the operand of its
 // RotatE / TransE corruption entries, once more in the flush.
 //
-// Here a workgroup is ONE wave group (gw waves, every lane one quad of each half of the row) and owns one tile's bucket:
+// Here a workgroup is ONE wave group (gw waves, every lane one quad of each half of the row) and owns one tile's bucket -- and a
+// tile is LARGE (make_plan: ~150 rows instead of the 18 the LDS accumulators allowed; the pass keeps only an entry list in LDS):
+// with 18-row tiles one step launched 347 000 workgroups whose start-up (bucket load, sort, bookkeeping) cost more than their
+// rows did -- measured on the shard: tile budget 150 KB 61.0 / 83.1 ms per step (touched-rows / dense), 600 KB 41.2 / 65.9,
+// 1 200 KB 40.4 / 65.3, 2 400 KB 41.3 / 67.8 (profiles/r03_c5_direct_variants.txt).
 //   1. the bucket (+ this tile's share of the overflow list) is copied to LDS and counting-sorted by local row (a few dozen
 //      16-byte entries: microseconds, and other workgroups of the CU cover it);
 //   2. rows are taken one at a time: x, m, v of the row are requested, the row's entries are folded into a REGISTER
@@ -23,22 +27,30 @@
 
 namespace kge {
 
-constexpr int DIRECT_UN = 4;          // entries whose operand rows are in flight together
+constexpr int DIRECT_UN = 2;          // entries whose operand rows are in flight together (rows with more than DIRECT_PRE entries)
+#ifndef KGE_DIRECT_PRE
+#define KGE_DIRECT_PRE 0   // (measured at one GPU's C5 shard: 0 and 2 within noise once the tiles are large -- 40.4 / 65.3 ms vs 41.2 / 65.9)
+#endif
+constexpr int DIRECT_PRE = KGE_DIRECT_PRE;   // entries of the NEXT row whose operand rows are requested ahead, with its x / m / v
+constexpr int DIRECT_PRE_N = DIRECT_PRE > 0 ? DIRECT_PRE : 1;   // (array extent)
 constexpr int DIRECT_OVF_SLACK = 256; // overflow-list entries of this tile the LDS list has room for beyond the bucket capacity
 
 __host__ __device__ inline size_t direct_lds_bytes(int cap, int tile_rows) {
     const size_t n = (size_t)cap + DIRECT_OVF_SLACK;
-    return n * 16 + n * 2 + (size_t)(tile_rows + 2) * 4 * 2 + 64;
+    return n * 16 + n * 2 + (size_t)(tile_rows + 2) * 4 * 2 + (size_t)tile_rows * 2 + 64;
 }
 
 template <int MODEL, int GW>
+#ifdef KGE_DIRECT_WAVES   // development builds: force an occupancy
+__attribute__((amdgpu_waves_per_eu(KGE_DIRECT_WAVES, KGE_DIRECT_WAVES)))
+#endif
 __global__ __launch_bounds__(GW * 64) void tile_direct_kernel(TileArgs a) {
     using T = ModelTraits<MODEL>;
     constexpr int NC = T::NC;
     constexpr bool TRILINEAR = (MODEL == AMDKGE_DISTMULT || MODEL == AMDKGE_COMPLEX);
     constexpr int THREADS = GW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_last, s_total;
+    __shared__ int s_last, s_total, s_nact;
 
     const int tid = threadIdx.x, lane = tid & 63, wg = tid >> 6;
     const int tile = blockIdx.x;
@@ -72,12 +84,16 @@ __global__ __launch_bounds__(GW * 64) void tile_direct_kernel(TileArgs a) {
     uint16_t* order = reinterpret_cast<uint16_t*>(smem + (size_t)lcap * 16);                 // [lcap] entry indices, by row
     int* rstart = reinterpret_cast<int*>(smem + (((size_t)lcap * 18 + 15) & ~(size_t)15));   // [nrow + 1]
     int* rfill = rstart + nrow + 2;                                                          // [nrow + 1]
+    uint16_t* active = reinterpret_cast<uint16_t*>(rfill + nrow + 2);                        // [nrow] rows this pass visits
     const StageEntry* list = a.lists + (size_t)tile * a.cap;
-    if (tid == 0) s_total = cnt;
+    if (tid == 0) { s_total = cnt; s_nact = 0; }
     for (int r = tid; r <= nrow; r += THREADS) { rstart[r] = 0; rfill[r] = 0; }
     for (int i = tid; i < cnt; i += THREADS) ents[i] = reinterpret_cast<const uint4*>(list)[i];
     __syncthreads();
-    for (int base = 0; base < on; base += THREADS) {   // entries of buckets that were full: every tile filters the shared list
+    // Entries of buckets that were full (the shared overflow list): this tile's share joins the LDS list.  Should it not fit
+    // (a pathologically hot tile: thousands of positives on one row without the hot-row replicas) the list keeps the bucket
+    // only and every row also scans the overflow list in memory (ovf_slow below): slow, but complete.
+    for (int base = 0; base < on; base += THREADS) {
         uint4 e = make_uint4(0, 0, 0, 0xFFFFFFFFu);
         if (base + tid < on) e = reinterpret_cast<const uint4*>(a.ovf)[base + tid];
         if (e.w != 0xFFFFFFFFu && (e.w / RB) % NT == (uint32_t)tile) {
@@ -87,10 +103,8 @@ __global__ __launch_bounds__(GW * 64) void tile_direct_kernel(TileArgs a) {
     }
     __syncthreads();
     int total = s_total;
-    if (total > lcap) {   // more entries than the LDS list holds (a pathologically hot tile): flagged, the host raises
-        if (tid == 0) atomicExch(a.status_flag, 2);
-        total = lcap;
-    }
+    const bool ovf_slow = total > lcap;
+    if (ovf_slow) total = cnt;
     for (int i = tid; i < total; i += THREADS) atomicAdd(&rstart[entry_local(ents[i].y) + 1], 1);
     __syncthreads();
     if (wg == 0) {   // exclusive prefix over the rows (nrow is small: one wave, 64 rows per step)
@@ -109,87 +123,157 @@ __global__ __launch_bounds__(GW * 64) void tile_direct_kernel(TileArgs a) {
         const int lr = (int)entry_local(ents[i].y);
         order[rstart[lr] + atomicAdd(&rfill[lr], 1)] = (uint16_t)i;
     }
+    // the rows this pass visits, in row order: all of the tile's rows, or (touched-rows mode, in place) those with an entry, a
+    // mark of the forward kernel's atomics or hot-row replicas
+    if (wg == 0) {
+        int n = 0;
+        for (int b = 0; b < nrow; b += 64) {
+            const int r = b + lane;
+            bool take = false;
+            if (r < nrow) {
+                const int64_t row = row_of(r);
+                take = row < a.n_rows;
+                if (take && a.lazy && a.apply_update && !ovf_slow)
+                    take = rstart[r + 1] > rstart[r] || (a.hot_map && a.hot_map[row]) || (a.touched && a.touched[row]);
+            }
+            const unsigned long long mk = __ballot(take);
+            if (take) active[n + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0))] = (uint16_t)r;
+            n += __popcll(mk);
+        }
+        if (lane == 0) s_nact = n;
+    }
     __syncthreads();
+    const int nact = s_nact;
     // (within a row the order of its entries is their arrival order in the scatter above: fp32 summation order only)
 
-    // ---- 2. rows, one at a time, through registers --------------------------------------------------------------------
+    // ---- 2. rows through registers, software-pipelined over the visited rows ------------------------------------------------
+    // x, m, v of row i + 1 and the operand rows of its first DIRECT_PRE entries are REQUESTED before row i is computed and stored:
+    // vmcnt retires in issue order, so a wave that loaded, computed and stored one row at a time waited for its own stores
+    // before every load (measured: 13 us per row).  Issued ahead of the stores, the next row's loads are what the wave waits
+    // for, with the stores still in flight behind them.
     const int q = lane + 64 * wg;
     const bool qok = q < a.nq;
     const int qoff = (qok ? q : 0) * 4;
     float reg_acc = 0.f;
-    {
-        for (int r = 0; r < nrow; ++r) {
-            const int64_t row = row_of(r);
-            if (row >= a.n_rows) continue;
-            const int e0 = rstart[r], e1 = rstart[r + 1];
-            const int hot = a.hot_map ? a.hot_map[row] : 0;
-            const bool marked = a.touched && a.touched[row];
-            if (a.lazy && a.apply_update && !hot && !marked && e0 == e1) continue;   // untouched row: keeps its bits
-            const int64_t off = row * a.K + qoff;
-            float4 x[NC], m[NC], v[NC], g[NC];
+    struct RowRegs {
+        float4 x[NC], m[NC], v[NC];
+        float4 sv[DIRECT_PRE_N][NC], pv[DIRECT_PRE_N];
+        uint32_t meta[DIRECT_PRE_N];
+        float gg[DIRECT_PRE_N];
+        int e0, e1, hot, marked;
+        int64_t off;
+    };
+    auto entry_loads = [&](int idx, uint32_t& meta, float& gg, float4 (&sv)[NC], float4& pv) KGE_TILE_INLINE {
+        const uint4 e = ents[order[idx]];   // same address in every lane: LDS broadcast, then scalars
+        const uint32_t pos = __builtin_amdgcn_readfirstlane(e.x);
+        meta = __builtin_amdgcn_readfirstlane(e.y);
+        gg = __uint_as_float(__builtin_amdgcn_readfirstlane(e.z));
+        const int role = meta & 3;   // 0 / 1: corruption with object / subject replaced; 2 / 3: the positive's own s / o row
+        const int which = (role == 0) ? 2 : (role == 1) ? 3 : (role == 2) ? 0 : 1;
+        const float* src = a.stage_rows + ((int64_t)pos * a.ns + which) * a.K + qoff;
+#pragma unroll
+        for (int h = 0; h < NC; ++h) sv[h] = KGE_LD4(src + h * a.k);
+        if constexpr (MODEL == AMDKGE_TRANSE) {
+            if (role < 2) pv = KGE_LD4(a.rel + (int64_t)a.triples[3 * (int64_t)pos + 1] * a.K + qoff);
+        }
+    };
+    auto request = [&](int i, RowRegs& R) KGE_TILE_INLINE {
+        const int r = active[i];
+        const int64_t row = row_of(r);
+        R.e0 = rstart[r]; R.e1 = rstart[r + 1];
+        R.hot = a.hot_map ? a.hot_map[row] : 0;
+        R.marked = (a.touched && a.touched[row]) ? 1 : 0;
+        R.off = row * a.K + qoff;
+#pragma unroll
+        for (int h = 0; h < NC; ++h) {
+            R.m[h] = make_float4(0.f, 0.f, 0.f, 0.f); R.v[h] = R.m[h];
+            R.x[h] = KGE_LD4(a.x + R.off + h * a.k);   // the live row: operand of its corruption entries AND of the update
+            if (a.apply_update) {   // (the slot pointers an update rule does not use are NULL)
+                if (a.s0) R.m[h] = KGE_LD4(a.s0 + R.off + h * a.k);
+                if (a.s1) R.v[h] = KGE_LD4(a.s1 + R.off + h * a.k);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DIRECT_PRE; ++u)
+            if (R.e0 + u < R.e1) entry_loads(R.e0 + u, R.meta[u], R.gg[u], R.sv[u], R.pv[u]);
+    };
+    auto fold = [&](uint32_t meta, float ge, const float4 (&sv)[NC], const float4& pv, const float4 (&x)[NC], float4 (&g)[NC]) KGE_TILE_INLINE {
+        const int role = meta & 3;
+        if (TRILINEAR || role >= 2) {
 #pragma unroll
             for (int h = 0; h < NC; ++h) {
-                g[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                m[h] = g[h]; v[h] = g[h];
-                x[h] = KGE_LD4(a.x + off + h * a.k);   // the live row: operand of its corruption entries AND of the update
-                if (a.apply_update) {   // (the slot pointers an update rule does not use are NULL)
-                    if (a.s0) m[h] = KGE_LD4(a.s0 + off + h * a.k);
-                    if (a.s1) v[h] = KGE_LD4(a.s1 + off + h * a.k);
+                g[h].x += ge * sv[h].x; g[h].y += ge * sv[h].y; g[h].z += ge * sv[h].z; g[h].w += ge * sv[h].w;
+            }
+        } else if constexpr (MODEL == AMDKGE_ROTATE) {
+            // g (e - S) / |e - S|, S the staged side row (A = s o r, or B = o o conj(r)), e this row (see add_entry)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float dr = (&x[0].x)[c] - (&sv[0].x)[c], di = (&x[NC - 1].x)[c] - (&sv[NC - 1].x)[c];
+                const float mm = KGE_SQRT(dr * dr + di * di) + ((qoff + c >= a.k_live) ? 1.f : 0.f);
+                const float gm = KGE_DIV(ge, mm);
+                (&g[0].x)[c] += gm * dr;
+                (&g[NC - 1].x)[c] += gm * di;
+            }
+        } else if constexpr (MODEL == AMDKGE_TRANSE) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float p[1] = {(&pv.x)[c]}, e[1] = {(&x[0].x)[c]}, sd[1] = {(&sv[0].x)[c]}, ds[1], dp[1], dd[1];
+                if (role == 0) grad_unit<AMDKGE_TRANSE>(sd, p, e, ge, ds, dp, dd);
+                else grad_unit<AMDKGE_TRANSE>(e, p, sd, ge, ds, dp, dd);
+                (&g[0].x)[c] += (role == 0) ? dd[0] : ds[0];
+            }
+        }
+    };
+    RowRegs cur, nxt;
+    if (nact > 0) request(0, cur);
+    for (int i = 0; i < nact; ++i) {
+        if (i + 1 < nact) request(i + 1, nxt);
+        float4 g[NC];
+#pragma unroll
+        for (int h = 0; h < NC; ++h) g[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < DIRECT_PRE; ++u)
+            if (cur.e0 + u < cur.e1) fold(cur.meta[u], cur.gg[u], cur.sv[u], cur.pv[u], cur.x, g);
+        for (int i0 = cur.e0 + DIRECT_PRE; i0 < cur.e1; i0 += DIRECT_UN) {   // rows with more entries than were requested ahead
+            uint32_t meta[DIRECT_UN];
+            float gg[DIRECT_UN];
+            float4 sv[DIRECT_UN][NC], pv[DIRECT_UN];
+#pragma unroll
+            for (int u = 0; u < DIRECT_UN; ++u)
+                if (i0 + u < cur.e1) entry_loads(i0 + u, meta[u], gg[u], sv[u], pv[u]);
+#pragma unroll
+            for (int u = 0; u < DIRECT_UN; ++u)
+                if (i0 + u < cur.e1) fold(meta[u], gg[u], sv[u], pv[u], cur.x, g);
+        }
+        bool row_touched = cur.e1 > cur.e0 || cur.hot || cur.marked;
+        if (ovf_slow) {   // the overflow list did not fit the LDS list: this row's entries are picked out of it in memory
+            const uint32_t row32 = (uint32_t)((cur.off - qoff) / a.K);
+            for (int base = 0; base < on; base += 64) {
+                uint4 e = make_uint4(0, 0, 0, 0xFFFFFFFFu);
+                if (base + lane < on) e = reinterpret_cast<const uint4*>(a.ovf)[base + lane];
+                unsigned long long mk = __ballot(e.w == row32);
+                row_touched = row_touched || mk != 0ull;
+                while (mk) {
+                    const int tt = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    const uint32_t pos = __builtin_amdgcn_readlane(e.x, tt), meta = __builtin_amdgcn_readlane(e.y, tt);
+                    const float ge = __uint_as_float(__builtin_amdgcn_readlane(e.z, tt));
+                    const int role = meta & 3, which = (role == 0) ? 2 : (role == 1) ? 3 : (role == 2) ? 0 : 1;
+                    const float* src = a.stage_rows + ((int64_t)pos * a.ns + which) * a.K + qoff;
+                    float4 sv[NC], pv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) sv[h] = KGE_LD4(src + h * a.k);
+                    if constexpr (MODEL == AMDKGE_TRANSE) {
+                        if (role < 2) pv = KGE_LD4(a.rel + (int64_t)a.triples[3 * (int64_t)pos + 1] * a.K + qoff);
+                    }
+                    fold(meta, ge, sv, pv, cur.x, g);
                 }
             }
-            for (int i0 = e0; i0 < e1; i0 += DIRECT_UN) {
-                uint32_t meta[DIRECT_UN];
-                float gg[DIRECT_UN];
-                float4 sv[DIRECT_UN][NC], pv[DIRECT_UN][NC];
-#pragma unroll
-                for (int u = 0; u < DIRECT_UN; ++u) {
-                    if (i0 + u < e1) {
-                        const uint4 e = ents[order[i0 + u]];   // same address in every lane: LDS broadcast, then scalars
-                        const uint32_t pos = __builtin_amdgcn_readfirstlane(e.x);
-                        meta[u] = __builtin_amdgcn_readfirstlane(e.y);
-                        gg[u] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.z));
-                        const int role = meta[u] & 3;   // 0 / 1: corruption with object / subject replaced; 2 / 3: the positive's own s / o row
-                        const int which = (role == 0) ? 2 : (role == 1) ? 3 : (role == 2) ? 0 : 1;
-                        const float* src = a.stage_rows + ((int64_t)pos * a.ns + which) * a.K + qoff;
-#pragma unroll
-                        for (int h = 0; h < NC; ++h) sv[u][h] = KGE_LD4(src + h * a.k);
-                        if constexpr (MODEL == AMDKGE_TRANSE) {
-                            if (role < 2) pv[u][0] = KGE_LD4(a.rel + (int64_t)a.triples[3 * (int64_t)pos + 1] * a.K + qoff);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < DIRECT_UN; ++u) {
-                    if (i0 + u >= e1) continue;
-                    const int role = meta[u] & 3;
-                    const float ge = gg[u];
-                    if (TRILINEAR || role >= 2) {
-#pragma unroll
-                        for (int h = 0; h < NC; ++h) {
-                            g[h].x += ge * sv[u][h].x; g[h].y += ge * sv[u][h].y; g[h].z += ge * sv[u][h].z; g[h].w += ge * sv[u][h].w;
-                        }
-                    } else if constexpr (MODEL == AMDKGE_ROTATE) {
-                        // g (e - S) / |e - S|, S the staged side row (A = s o r, or B = o o conj(r)), e this row (see add_entry)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float dr = (&x[0].x)[c] - (&sv[u][0].x)[c], di = (&x[NC - 1].x)[c] - (&sv[u][NC - 1].x)[c];
-                            const float mm = KGE_SQRT(dr * dr + di * di) + ((qoff + c >= a.k_live) ? 1.f : 0.f);
-                            const float gm = KGE_DIV(ge, mm);
-                            (&g[0].x)[c] += gm * dr;
-                            (&g[NC - 1].x)[c] += gm * di;
-                        }
-                    } else if constexpr (MODEL == AMDKGE_TRANSE) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            float p[1] = {(&pv[u][0].x)[c]}, e[1] = {(&x[0].x)[c]}, sd[1] = {(&sv[u][0].x)[c]}, ds[1], dp[1], dd[1];
-                            if (role == 0) grad_unit<AMDKGE_TRANSE>(sd, p, e, ge, ds, dp, dd);
-                            else grad_unit<AMDKGE_TRANSE>(e, p, sd, ge, ds, dp, dd);
-                            (&g[0].x)[c] += (role == 0) ? dd[0] : ds[0];
-                        }
-                    }
-                }
-            }
-            if (!qok) continue;
+        }
+        // (ovf_slow visits every row of the tile: in touched-rows mode one without any entry keeps its bits)
+        if (qok && !(a.lazy && a.apply_update && !row_touched)) {
+            const int64_t off = cur.off;
+            const int hot = cur.hot;
 #pragma unroll
             for (int h = 0; h < NC; ++h) {
                 float4* gp4 = (a.pos_atomic || !a.apply_update) ? reinterpret_cast<float4*>(a.g_ent + off + h * a.k) : nullptr;
@@ -213,15 +297,16 @@ __global__ __launch_bounds__(GW * 64) void tile_direct_kernel(TileArgs a) {
                 }
                 // (the update rule is dispatched per row half: a wave-uniform switch, one compiled rule body each)
 #define KGE_UPD(KIND) do { \
-                    opt_elem<KIND>(a.opt, x[h].x, g[h].x, m[h].x, v[h].x, reg_acc); opt_elem<KIND>(a.opt, x[h].y, g[h].y, m[h].y, v[h].y, reg_acc); \
-                    opt_elem<KIND>(a.opt, x[h].z, g[h].z, m[h].z, v[h].z, reg_acc); opt_elem<KIND>(a.opt, x[h].w, g[h].w, m[h].w, v[h].w, reg_acc); \
-                    if constexpr (opt_nslots(KIND) >= 1) *reinterpret_cast<float4*>(a.s0 + off + h * a.k) = m[h]; \
-                    if constexpr (opt_nslots(KIND) == 2) *reinterpret_cast<float4*>(a.s1 + off + h * a.k) = v[h]; } while (0)
+                    opt_elem<KIND>(a.opt, cur.x[h].x, g[h].x, cur.m[h].x, cur.v[h].x, reg_acc); opt_elem<KIND>(a.opt, cur.x[h].y, g[h].y, cur.m[h].y, cur.v[h].y, reg_acc); \
+                    opt_elem<KIND>(a.opt, cur.x[h].z, g[h].z, cur.m[h].z, cur.v[h].z, reg_acc); opt_elem<KIND>(a.opt, cur.x[h].w, g[h].w, cur.m[h].w, cur.v[h].w, reg_acc); \
+                    if constexpr (opt_nslots(KIND) >= 1) *reinterpret_cast<float4*>(a.s0 + off + h * a.k) = cur.m[h]; \
+                    if constexpr (opt_nslots(KIND) == 2) *reinterpret_cast<float4*>(a.s1 + off + h * a.k) = cur.v[h]; } while (0)
                 KGE_OPT_DISPATCH(a.opt.kind, KGE_UPD)
 #undef KGE_UPD
-                *reinterpret_cast<float4*>(a.x + off + h * a.k) = x[h];
+                *reinterpret_cast<float4*>(a.x + off + h * a.k) = cur.x[h];
             }
         }
+        cur = nxt;
     }
     if (a.apply_update && a.reg_loss && a.opt.lam != 0.f) {
         const float w = wave_sum(reg_acc);

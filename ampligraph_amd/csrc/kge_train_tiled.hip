@@ -761,11 +761,21 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     // (few entries per row -- one GPU's C5 shard sees 0.7 -- would only halve the tiles)
     p.own_cache = !det && m->scoring_type == AMDKGE_ROTATE && queue_bytes != 0 && B * (int64_t)eta >= 4 * m->n_ents;
     const size_t row_bytes = (size_t)K * 4 * (p.own_cache ? 2 : 1);
-    for (size_t budget = det ? 96 * 1024 : 150 * 1024 - queue_bytes;; budget = budget * 3 / 4) {
+#ifndef KGE_DIRECT_BUDGET_KB
+#define KGE_DIRECT_BUDGET_KB 1200
+#endif
+    // (long rows on the row-direct pass keep nothing but their entry list in LDS: the tile size is not an LDS question there)
+    // The row-direct pass pays off while a row sees few entries per step (one GPU's C5 shard: 0.7; a 1 M-row table at the same
+    // batch: 4.3 -- 21.8 vs 26.2 ms); where rows collect many (ComplEx k = 1000 on 14 505 entities: 15 -- 0.88 vs 0.72 ms) the
+    // LDS accumulators win, so the form is chosen by the batch's mean entries per row.
+    const bool direct_shape = g_tile_direct && !det && ks / 4 > 128 && B * (int64_t)(eta + 2) <= 8 * m->n_ents;
+    const size_t nodet_budget = direct_shape ? (size_t)KGE_DIRECT_BUDGET_KB * 1024 : 150 * 1024 - queue_bytes;
+    for (size_t budget = det ? 96 * 1024 : nodet_budget;; budget = budget * 3 / 4) {
         // Whole ownership blocks per tile (block-interleaved ownership, see tile_backward_kernel).  The block size is the largest
         // power of two <= TILE_RB that still lets the tiles fill the 256 CUs evenly: a tile's rows come in multiples of the
         // block, and at C2 (14 505 rows, ~57 per tile) blocks of 8 would leave 11 % of the CUs without a tile.
-        const int fit = (int)(budget / row_bytes);
+        int fit = (int)(budget / row_bytes);
+        if (direct_shape && fit > 160) fit = 160;   // (<= 8 entries per row: a bucket of at most 2 * 1 280 + 256 entries -- the row-direct pass's LDS list)
         if (fit < 1) return false;
         double best_eff = -1.0;
         for (int rb = (int)TILE_RB; rb >= 1; rb >>= 1) {
@@ -802,7 +812,7 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     p.ovf_cap = (int)(entries > 0 ? entries : 1);
     // row-direct pass: one wave group per tile, the bucket sorted in LDS, rows through registers -- long rows only, and only
     // while a bucket (+ slack for overflow entries) is a small LDS list
-    p.direct = g_tile_direct && !det && ks / 4 > 128 && p.cap <= 3000 && p.tile_rows <= 2048;
+    p.direct = direct_shape && p.cap <= 3000 && p.tile_rows <= 2048;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
     p.off_loss = o; o += up((size_t)LOSS_PARTS * LOSS_PART_STRIDE * 8);   // first: the same place in every plan (kept zero between steps)

@@ -524,6 +524,17 @@ class KgeEngine:
             self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._work
 
+    SCREEN_MAX_BYTES = 4 << 30
+
+    def screen_stats(self):
+        """(rechecked pairs, fell back to the exact kernel?) of the last rank_side call's screening pass, or None when it ran
+        without one (TransE / RotatE, tiny or huge problems).  Synchronises."""
+        s = getattr(self, "_last_screen", None)
+        if s is None:
+            return None
+        v = s[:8].view(torch.int32).cpu().numpy()
+        return int(v[0]), bool(v[1])
+
     def rank_side(self, triples, side, strategy="worst", flt=None, ent_ids=None, subset_pos=None,
                   ent_lo=0, ent_hi=None, out=None, out_stride=1, flt_range=None):
         """Ranks (1-based, reference semantics) of `triples` for one corruption side.
@@ -535,9 +546,17 @@ class KgeEngine:
             ent_hi = self.n_ents if ent_ids is None else int(ent_ids.shape[0])
         work = self._workspace(n)
         counts = torch.zeros(n, 2, dtype=torch.int32, device=self.device)
-        check(self.lib.amdkge_rank_counts(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples), n,
-                                          side, _ptr(ent_ids), int(ent_lo), int(ent_hi), _ptr(counts),
-                                          _ptr(work), _stream()))
+        # contraction models: the int8 screening pass + exact recheck (kge_rank_screen.h) -- the same counts, bit for bit, at a
+        # multiple of the fp32 matrix rate; its workspace (fixed-point copies of the query vectors and the candidate rows, the
+        # recheck list) is kept between calls.  Beyond SCREEN_MAX_BYTES (huge candidate ranges) the exact kernel runs alone.
+        screen, sbytes = None, 0
+        need = int(self.lib.amdkge_rank_screen_workspace_bytes(C.byref(self.model), n, int(ent_hi) - int(ent_lo))) if n > 0 else 0
+        if 0 < need <= self.SCREEN_MAX_BYTES:
+            screen, sbytes = self._buf("rank_screen", (need,), torch.uint8), need
+        self._last_screen = screen
+        check(self.lib.amdkge_rank_counts_screened(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples), n,
+                                                   side, _ptr(ent_ids), int(ent_lo), int(ent_hi), _ptr(counts),
+                                                   _ptr(work), _ptr(screen), sbytes, _stream()))
         sub = None
         if flt is not None:
             lo, hi, ids = flt

@@ -162,10 +162,15 @@ def eval_bench(eng, data, rank):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     r = ranks.cpu().numpy()
+    scr = eng.screen_stats()   # int8 screening pass (contraction models): pairs the exact fp32 chain had to recheck (last side)
     flops = 2.0 * data["n_ents"] * eng.K * n * 2
     return {"ranks_per_s": 2 * n / dt, "ms": dt * 1e3, "n_test": int(n), "sides": 2, "filtered": True,
             "filter_index_ms": index_ms, "filter_index": "built on the device (upload + amdkge_filter_build + amdkge_filter_ranges, both sides)",
             "achieved_tflops_fp32": flops / dt / 1e12,
+            "screening": (None if scr is None else {"rechecked_pairs_per_side": scr[0], "fraction": scr[0] / float(n * data["n_ents"]),
+                                                    "fell_back_to_exact_kernel": scr[1],
+                                                    "note": "int8 matrix-core pass decides the comparisons a rigorous error bound allows; the "
+                                                            "rest are recomputed with the exact fp32 chain: counts bit-identical to the fp32 kernels"}),
             "mrr_untrained_tables": float(np.mean(1.0 / r)), "note": "tables as left by the timed training steps"}
 
 
@@ -221,6 +226,10 @@ def main():
     from ampligraph_amd.latent_features import loss_functions, optimizers
     from ampligraph_amd.trainer import StepLoop
 
+    if os.environ.get("AMDKGE_TILE_DIRECT", "1") == "0":   # development A/B: long rows on the LDS-accumulator tile kernel
+        from ampligraph_amd import _ffi as _f
+
+        _f.lib().amdkge_set_tile_direct(0)
     stream = SYNTH_STREAM.get(args.dataset)
     if stream is not None:     # no host-side triples at all: (s, p, o) number i comes from the counter RNG on the device
         N, R = (args.ents_per_gpu or stream["ents_per_gpu"]) * world, stream["n_rels"]

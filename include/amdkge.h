@@ -264,8 +264,9 @@ int amdkge_platt_step(const float* d_scores_pos, int64_t n_pos, const float* d_s
  *   d_work    : scratch of amdkge_rank_workspace_bytes(m, n) bytes */
 int64_t amdkge_rank_workspace_bytes(const amdkge_model* m, int64_t n);
 /* Testing aid (process-wide): which tile kernel amdkge_rank_counts launches.  0 = automatic (the default: pipelined MFMA
- * kernel for DistMult / ComplEx / HolE, VALU tile kernel for TransE / RotatE), 1 = always the VALU tile kernel, 2 = the
- * first (un-pipelined) MFMA kernel.  All three produce the same bits; the parity tests compare them. */
+ * kernel for DistMult / ComplEx / HolE -- behind the int8 screening pass when amdkge_rank_counts_screened is given its
+ * workspace --, VALU tile kernel for TransE / RotatE), 1 = always the VALU tile kernel, 2 = the first (un-pipelined) MFMA
+ * kernel, 3 = the pipelined MFMA kernel with the screening pass off.  All produce the same bits; the parity tests compare them. */
 int amdkge_set_rank_kernel(int which);
 /* RotatE's per-unit modulus in the rank / filter / corruption-score kernels (process-wide, set before the calls it should apply to).
  *   0 (default) = EXACT: cos / sin of the phase correctly rounded to fp32 (fp64 evaluation, one rounding) and the modulus a
@@ -280,6 +281,19 @@ int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d
                        const int32_t* d_triples, int64_t n, int32_t side,
                        const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
                        int32_t* d_counts, void* d_work, void* stream);
+/* The same counts, bit for bit, through the INT8 SCREENING PASS for the contraction models (DistMult / ComplEx / HolE;
+ * kge_rank_screen.h): rows become 24-bit fixed point (three int8 limbs, a power-of-two scale per row), v_mfma_i32_32x32x32_i8
+ * forms the integer dot products exactly, a rigorous per-pair error bound (the fp32 chain's own rounding + the fixed-point
+ * rounding + the dropped limb products) decides every comparison whose outcome it cannot change, and the rest -- a fraction of a
+ * per cent -- are recomputed with the exact fp32 chain.  d_screen: amdkge_rank_screen_workspace_bytes(m, n, ent_hi - ent_lo)
+ * bytes (0 = this model has no screening pass); NULL / too small, TransE / RotatE, tiny problems: the call is amdkge_rank_counts.
+ * After the stream is synchronised the first int32 of d_screen (aligned up to 256 bytes) holds the number of rechecked pairs,
+ * the second is non-zero if the recheck list overflowed and the call fell back to the exact kernel. */
+int64_t amdkge_rank_screen_workspace_bytes(const amdkge_model* m, int64_t n, int64_t n_cand);
+int amdkge_rank_counts_screened(const amdkge_model* m, const float* d_ent, const float* d_rel,
+                                const int32_t* d_triples, int64_t n, int32_t side,
+                                const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
+                                int32_t* d_counts, void* d_work, void* d_screen, int64_t screen_bytes, void* stream);
 
 /* get_ranks step (3): filter correction (AbstractScoringLayer.py:260-307,368-417).  For triple i
  * the true-positive ids are d_flt_ids[d_flt_lo[i] .. d_flt_hi[i]) (a CSR when lo=off[i],

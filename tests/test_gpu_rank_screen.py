@@ -1,0 +1,112 @@
+"""The int8 screening pass of evaluate() (kge_rank_screen.h): counts bit-identical to the exact fp32 kernels -- it only decides
+WHICH comparisons need the exact chain.  Against the unscreened pipelined MFMA kernel (amdkge_set_rank_kernel(3)), itself held
+bit for bit to the declared-order oracle in test_gpu_fullsize, on real-valued tables, tables with wild dynamic range, ties,
+inf / NaN rows, candidate subsets and ranges; and the recheck statistics (a fraction of a per cent of the comparisons)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _counts(eng, gpu_lib, Xd, side, which, **kw):
+    from ampligraph_amd import _ffi
+
+    try:
+        _ffi.check(gpu_lib.amdkge_set_rank_kernel(which))
+        _, counts, _ = eng.rank_side(Xd, side, "worst", **kw)
+        stats = eng.screen_stats()
+        return counts.cpu().numpy().copy(), stats
+    finally:
+        gpu_lib.amdkge_set_rank_kernel(0)
+
+
+@pytest.mark.parametrize("model,k,N,n", [("ComplEx", 200, 14505, 2000), ("DistMult", 400, 9000, 1500), ("HolE", 350, 3000, 700),
+                                          ("DistMult", 50, 5000, 300), ("ComplEx", 1000, 2000, 256), ("ComplEx", 16, 700, 130)])
+@pytest.mark.parametrize("tables", ["gaussian", "wild", "ties"])
+def test_screened_counts_equal_exact_counts(gpu_lib, model, k, N, n, tables):
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+
+    R = 11
+    rng = np.random.default_rng(k + N)
+    eng = KgeEngine(model, k, N, R, max_rel_size=R)
+    K = eng.K
+    if tables == "gaussian":
+        ent = (rng.normal(size=(N, K)) * 0.25).astype(np.float32)
+        rel = (rng.normal(size=(R, K)) * 0.25).astype(np.float32)
+    elif tables == "wild":   # rows 12 orders of magnitude apart, units 6 orders apart inside a row, exact zeros, one huge unit
+        ent = (rng.normal(size=(N, K)) * np.exp(rng.uniform(-14, 14, size=(N, 1))) * np.exp(rng.uniform(-7, 7, size=(N, K)))).astype(np.float32)
+        ent[rng.random((N, K)) < 0.1] = 0.0
+        ent[5, 3] = 3e18
+        rel = (rng.normal(size=(R, K)) * np.exp(rng.uniform(-3, 3, size=(R, K)))).astype(np.float32)
+    else:                    # many exactly equal scores: small integers / 8
+        ent = (rng.integers(-4, 5, size=(N, K)) / 8.0).astype(np.float32)
+        rel = (rng.integers(-2, 3, size=(R, K)) / 4.0).astype(np.float32)
+    eng.set_tables(ent, rel)
+    X = np.stack([rng.integers(0, N, n), rng.integers(0, R, n), rng.integers(0, N, n)], 1).astype(np.int32)
+    Xd = torch.as_tensor(X).cuda()
+    for side in (_ffi.SIDE_S, _ffi.SIDE_O):
+        exact, st0 = _counts(eng, gpu_lib, Xd, side, 3)
+        scr, st = _counts(eng, gpu_lib, Xd, side, 0)
+        assert np.array_equal(scr, exact), (side, int((scr != exact).sum()), st)
+        assert st is not None and not st[1]
+        if tables == "gaussian" and k >= 50:
+            assert st[0] < 0.02 * n * N, st    # the recheck list is a small fraction of the comparisons
+    print("rechecked pairs", model, k, tables, st, "of", n * N)
+
+
+def test_screened_counts_subsets_ranges_and_bad_rows(gpu_lib):
+    """entities_subset (candidate id list), a candidate range (row-sharded evaluation) and rows holding inf / NaN / denormals."""
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+
+    N, R, k, n = 6000, 5, 64, 600
+    rng = np.random.default_rng(3)
+    eng = KgeEngine("ComplEx", k, N, R, max_rel_size=R)
+    ent = (rng.normal(size=(N, eng.K)) * 0.3).astype(np.float32)
+    rel = (rng.normal(size=(R, eng.K)) * 0.3).astype(np.float32)
+    ent[17, 5] = np.inf
+    ent[99, :] = np.nan
+    ent[200, :] = 1e-42      # denormal row
+    ent[201, :] = 0.0
+    eng.set_tables(ent, rel)
+    X = np.stack([rng.integers(0, N, n), rng.integers(0, R, n), rng.integers(0, N, n)], 1).astype(np.int32)
+    X[:4, 0] = [17, 99, 200, 201]
+    Xd = torch.as_tensor(X).cuda()
+    ids = torch.as_tensor(rng.permutation(N)[:3000].astype(np.int32)).cuda()
+    for kw in (dict(), dict(ent_ids=ids), dict(ent_lo=1000, ent_hi=5200), dict(ent_ids=ids, ent_lo=128, ent_hi=2900)):
+        for side in (_ffi.SIDE_S, _ffi.SIDE_O):
+            exact, _ = _counts(eng, gpu_lib, Xd, side, 3, **kw)
+            scr, st = _counts(eng, gpu_lib, Xd, side, 0, **kw)
+            assert np.array_equal(scr, exact), (kw.keys(), side, int((scr != exact).sum()), st)
+
+
+def test_screened_overflowing_recheck_list_falls_back(gpu_lib):
+    """A recheck list too small for the call's undecided pairs (a deliberately tiny workspace through the C ABI): the device-side
+    flag sends the whole call to the guarded exact kernel -- same counts, no host round trip."""
+    import ctypes as C
+
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine, _ptr, _stream
+
+    N, R, k, n = 14505, 7, 200, 2048
+    rng = np.random.default_rng(5)
+    eng = KgeEngine("ComplEx", k, N, R, max_rel_size=R)
+    eng.set_tables((rng.normal(size=(N, eng.K)) * 0.25).astype(np.float32), (rng.normal(size=(R, eng.K)) * 0.25).astype(np.float32))
+    X = np.stack([rng.integers(0, N, n), rng.integers(0, R, n), rng.integers(0, N, n)], 1).astype(np.int32)
+    Xd = torch.as_tensor(X).cuda()
+    exact, _ = _counts(eng, gpu_lib, Xd, _ffi.SIDE_O, 3)
+    full, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_O, 0)
+    assert np.array_equal(full, exact) and not st[1] and st[0] > 4096
+    need = int(gpu_lib.amdkge_rank_screen_workspace_bytes(C.byref(eng.model), n, N))
+    small = need - (max(1 << 20, n * N // 32) - 2048) * 8          # room for 2 048 pairs only
+    buf = torch.empty(small, dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(n, 2, dtype=torch.int32, device="cuda")
+    work = eng._workspace(n)
+    _ffi.check(gpu_lib.amdkge_rank_counts_screened(C.byref(eng.model), _ptr(eng.ent), _ptr(eng.rel), _ptr(Xd), n, _ffi.SIDE_O, None, 0, N,
+                                                   _ptr(counts), _ptr(work), _ptr(buf), small, _stream()))
+    torch.cuda.synchronize()
+    flag = buf[:8].view(torch.int32).cpu().numpy()
+    assert flag[1] != 0 and flag[0] > 2048
+    assert np.array_equal(counts.cpu().numpy(), exact)
