@@ -57,7 +57,7 @@ def test_abi_argument_validation_without_gpu():
     assert lib.amdkge_train_tiled_workspace_bytes(ctypes.byref(mp), 100, 5) > 0
     assert lib.amdkge_row_floats(ctypes.byref(_ffi.Model(2, 10, 5, 5, 0, 8))) == -1              # k_pad < k
     assert lib.amdkge_pack_rows(ctypes.byref(mp), None, 0, None, None) == 0 and lib.amdkge_pack_rows(ctypes.byref(mp), None, 2, None, None) == -1
-    assert lib.amdkge_set_rank_kernel(3) == -1 and lib.amdkge_set_rank_kernel(0) == 0
+    assert lib.amdkge_set_rank_kernel(4) == -1 and lib.amdkge_set_rank_kernel(3) == 0 and lib.amdkge_set_rank_kernel(0) == 0
     m4 = _ffi.Model(2, 200, 14505, 237, 0, 0)
     assert lib.amdkge_train_tiled_workspace_bytes(ctypes.byref(m4), 10000, 20) > 10000 * 4 * 400 * 4
     assert lib.amdkge_train_step_tiled(ctypes.byref(m4), None, ctypes.byref(o), *([None] * 6), 0.0, None, 1, 1, 0, 1,
