@@ -130,6 +130,12 @@ SIGNATURES = {
     "amdkge_session_set_hot_rows": (C.c_int, [P, P, I32]),
     "amdkge_session_score": (C.c_int, [P, P, I64, P]),
     "amdkge_session_rank": (C.c_int, [P, P, I64, P, P, P, P, P, I64, I32, I32, P]),
+    "amdkge_session_group_create": (C.c_int, [C.POINTER(SessionConfig), P, I32, C.POINTER(C.c_void_p)]),
+    "amdkge_session_group_destroy": (None, [P]),
+    "amdkge_session_group_size": (I32, [P]),
+    "amdkge_session_group_replica": (C.c_int, [P, I32, C.POINTER(C.c_void_p)]),
+    "amdkge_session_group_set_rows": (C.c_int, [P, I32, I64, I64, P]),
+    "amdkge_session_group_train_step": (C.c_int, [P, P, I64, P, C.POINTER(C.c_double)]),
 }
 
 _lib = None

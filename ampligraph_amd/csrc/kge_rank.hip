@@ -1086,7 +1086,7 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     ScreenBufs b = carve_screen(d_screen, screen_bytes, n, mcand, g.U);
     const float sgn_scale = mc.score_sign * mc.score_scale;
     if (hipError_t e = hipMemsetAsync(b.counter, 0, 256 + scr_up((size_t)n * 8), st)) return set_error_hip(e, "hipMemsetAsync(screen counters)");
-    const double u = ldexp(1.0, -24), gam = (double)g.U * u / (1.0 - (double)g.U * u);
+    const double u = ldexp(1.0, -24), gam = u * (1.0 + 2.0 * (double)g.U * u);   // x |W q|_2 |W e|_2: the chain's rounding bound
     hipLaunchKernelGGL(rank_limbs_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.Q, (int64_t)g.QW, (const int32_t*)nullptr, (int64_t)0, n, g.U, b.S,
                        (float)(gam * (1.0 + 1e-6)), b.qlimbs, b.qm);
     if (int rc = check_launch("rank_limbs(Q)")) return rc;
@@ -1119,7 +1119,13 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     RecheckArgs ra{};
     ra.ent = d_ent; ra.Q = w.Q; ra.qpos = w.qpos; ra.ent_ids = d_ent_ids; ra.ent_lo = ent_lo; ra.U = g.U; ra.K = g.K; ra.QW = g.QW;
     ra.sgn_scale = sgn_scale; ra.b = b;
-    hipLaunchKernelGGL(rank_recheck_kernel, dim3(2048), dim3(256), 0, st, ra);
+    static bool rck_attr = false;
+    if (!rck_attr) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)rank_recheck_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCK_LDS_BYTES))
+            return set_error_hip(e, "hipFuncSetAttribute(rank_recheck)");
+        rck_attr = true;
+    }
+    hipLaunchKernelGGL(rank_recheck_kernel, dim3(1024), dim3(256), RCK_LDS_BYTES, st, ra);
     if (int rc = check_launch("rank_recheck")) return rc;
     hipLaunchKernelGGL(rank_screen_merge_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, st, b, n, d_counts);
     return check_launch("rank_screen_merge");

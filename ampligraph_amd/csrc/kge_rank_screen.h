@@ -13,7 +13,10 @@
 //   2. the screening kernel forms  D~_ij = sum_k vq_ik ve_jk  with v_mfma_i32_32x32x32_i8 -- INTEGER arithmetic, exact, at ~28x
 //      the fp32 matrix rate per instruction -- keeping the limb products down to weight 2^16 (6 of the 9: three int32
 //      accumulators per output), and bounds |D~_ij A_i B_j - S_ij| RIGOROUSLY by
-//          E_ij = gamma_U |q_i|_2 |e_j|_2                      (the fp32 chain's own rounding, U fused operations)
+//          E_ij = u (1 + 2 U u) |W q_i|_2 |W e_j|_2            (the fp32 chain's own rounding: the partial sum behind unit j is
+//                                                               rounded U - j more times, |acc_k| <= sum_{j<=k} |q_j e_j| (1+u)^k,
+//                                                               so |S - D| <= u sum_j (U - j) |q_j e_j| (1 + u)^U, and Cauchy-Schwarz
+//                                                               with W = diag(sqrt(U - j)): half of the classic gamma_U |q| |e|)
 //               + (A_i |e_j|_1 + B_j |q_i|_1) / 2 + U A_i B_j / 4   (rounding of the rows to their fixed-point grids)
 //               + U (2^23 + 2^14) A_i B_j                      (the three dropped limb products)
 //               + 8 u |S~|                                     (the epilogue's own fp32 roundings), all inflated by 2^-10;
@@ -40,10 +43,10 @@ struct ScreenBufs {
     int* counter;        // [0] undecided pairs appended, [1] overflow flag
     int32_t* counts;     // [n][2] this call's (greater, equal) counts (merged into the caller's unless the call fell back)
     int8_t* qlimbs;      // [ceil(n / 32)][S][3][2][32][16]
-    float4* qm;          // [n] {A = 2^-a, gamma_U |q|_2, |q|_1 / 2, 0}, all rounded up
+    float4* qm;          // [n] {A = 2^-a, u (1 + 2 U u) |W q|_2, |q|_1 / 2, 0}, all rounded up
     float2* qt;          // [n] {T_ge, T_gt}
     int8_t* elimbs;      // [ceil(m / 32)][S][3][2][32][16]
-    float4* em;          // [m] {B, |e|_2, |e|_1 / 2, 0}
+    float4* em;          // [m] {B, |W e|_2, |e|_1 / 2, 0}
     int2* pairs;         // [cap] (query, candidate position)
     int64_t cap;
     int S;               // K slabs per row
@@ -95,7 +98,9 @@ __global__ __launch_bounds__(256) void rank_limbs_kernel(const float* __restrict
         bad |= !(a0 < INFINITY) || !(a1 < INFINITY) || !(a2 < INFINITY) || !(a3 < INFINITY);
         mx = fmaxf(fmaxf(mx, fmaxf(a0, a1)), fmaxf(a2, a3));
         n1 += (a0 + a1) + (a2 + a3);
-        n2 = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, fmaf(a3, a3, n2))));
+        // position-weighted square norm: unit j of the chain passes through U - j roundings (see the bound in the header comment)
+        const float w = (float)(U - 4 * q);
+        n2 = fmaf(w * a0, a0, fmaf((w - 1.f) * a1, a1, fmaf((w - 2.f) * a2, a2, fmaf((w - 3.f) * a3, a3, n2))));
     }
     mx = wave_max(mx);
     n1 = wave_sum_shfl(n1);
@@ -169,7 +174,8 @@ struct ScreenArgs {
 
 constexpr int SCR_THREADS = 256;   // 4 waves, each a 32-query block against the workgroup's 64-entity tile; TWO workgroups per CU
 constexpr int SCR_ET = 64;         // entities per tile
-constexpr size_t SCR_LDS_BYTES = (size_t)2 * 3 * 2 * SCR_ET * 16 + 128 * 16 + 128 * 8 + SCR_ET * 16;   // E double-buffered + row metas
+constexpr int SCR_PEND = 256;      // undecided pairs a wave parks in LDS before they go to the list
+constexpr size_t SCR_LDS_BYTES = (size_t)2 * 3 * 2 * SCR_ET * 16 + 128 * 16 + 128 * 8 + SCR_ET * 16 + 4 * SCR_PEND * 8;   // E double-buffered + row metas + parked pairs
 
 // Operand feed.  The i8 matrix instruction retires 65 536 multiply-adds in ~33 cycles, so the kernel is bound by how fast the
 // operands arrive and by its epilogue, not by the matrix pipe.  A wave's QUERY fragments come straight from global memory
@@ -293,6 +299,22 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
     __syncthreads();
     int st = 0;
     int64_t t = 0;
+    int npend = 0;   // pairs parked in this wave's LDS buffer (wave-uniform)
+    int2* const pend = reinterpret_cast<int2*>(em_s + SCR_ET) + wv * SCR_PEND;
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int b0 = 0;
+        if (lane == 63) b0 = atomicAdd(a.b.counter, npend);
+        const int64_t base = __shfl(b0, 63, 64);
+        for (int i = lane; i < npend; i += 64) {
+            if (base + i < a.b.cap) a.b.pairs[base + i] = pend[i];
+            else a.b.counter[1] = 1;   // the list is full: the call falls back to the exact kernel
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        npend = 0;
+    };
     auto stage = [&](auto par_c) __attribute__((always_inline)) {
         constexpr int P = decltype(par_c)::value;   // g % 2: this position's LDS buffer and query set, the register set free for g + 2
         const int64_t et = e_begin + t * SCR_ET;
@@ -356,28 +378,38 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
             if (et + l31 >= e_end) undm &= 0xAAAAAAAAu;        // candidate of block 0 beyond the range
             if (et + 32 + l31 >= e_end) undm &= 0x55555555u;   // candidate of block 1 beyond the range
             {
+                // Undecided pairs are parked in this wave's LDS buffer and go to the list SCR_PEND at a time (one returning atomic
+                // and coalesced stores per flush): one atomic per wave and tile on the single counter -- 145 000 of them at C2 --
+                // serialised at the L2 and cost more than the matrix work.
                 const int mine = __popc(undm);
                 int incl = mine;   // inclusive prefix over the wave
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
                 const int total = __shfl(incl, 63, 64);
                 if (total) {
-                    int base = 0;
-                    if (lane == 63) base = atomicAdd(a.b.counter, total);
-                    base = __shfl(base, 63, 64);
-                    int64_t at = (int64_t)base + incl - mine;
+                    if (npend + total > SCR_PEND) flush();
+                    const bool direct = total > SCR_PEND;   // (a tile of undecided outputs: straight to the list)
+                    int64_t base = 0;
+                    if (direct) {
+                        int b0 = 0;
+                        if (lane == 63) b0 = atomicAdd(a.b.counter, total);
+                        base = __shfl(b0, 63, 64);
+                    }
+                    int at = incl - mine;
                     uint32_t mm = undm;
                     while (mm) {
                         const int bit = __builtin_ctz(mm);
                         mm &= mm - 1;
                         const int r = bit >> 1, ni = bit & 1;
-                        if (at < a.b.cap) a.b.pairs[at] = make_int2((int)(q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh), (int)(et + ni * 32 + l31));
+                        const int2 pr = make_int2((int)(q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh), (int)(et + ni * 32 + l31));
+                        if (!direct) pend[npend + at] = pr;
+                        else if (base + at < a.b.cap) a.b.pairs[base + at] = pr;
                         else a.b.counter[1] = 1;   // the list is full: the call falls back to the exact kernel
                         ++at;
                     }
+                    if (!direct) npend += total;
                 }
             }
-
 #pragma unroll
             for (int lv = 0; lv < 3; ++lv)
 #pragma unroll
@@ -394,6 +426,7 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
         stage(std::integral_constant<int, 0>{});
         if (g + 1 < G) stage(std::integral_constant<int, 1>{});
     }
+    if (npend) flush();
     // ---- per query row: sum over the 32 lanes that share it ----
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -420,34 +453,64 @@ struct RecheckArgs {
     ScreenBufs b;
 };
 
+// One lane per pair, 64 pairs per wave -- but the rows are NOT read lane by lane (64 lanes x 16 bytes of 64 different rows per
+// load instruction: the address path, not the bytes, bound the first version at ~2 TB/s for 650 000 pairs).  A wave fetches
+// 32-unit chunks of its 64 query rows and 64 entity rows COALESCED (8 rows x one 128-byte line per instruction), parks them in
+// its private LDS region (row stride 144 bytes: a lane walking its own row is conflict-free) and every lane then runs its
+// 32 fused multiply-adds in unit order from LDS.  Same chain, same bits as rank_op<MODE_DOT>.
+constexpr int RCK_CH = 32;                 // units per chunk
+constexpr int RCK_LD = RCK_CH + 4;         // LDS row stride in floats
+constexpr size_t RCK_LDS_BYTES = (size_t)4 * 2 * 64 * RCK_LD * sizeof(float);   // 4 waves x (Q, E) x 64 rows
+
 __global__ __launch_bounds__(256) void rank_recheck_kernel(RecheckArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_rck[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* Qb = reinterpret_cast<float*>(smem_rck) + (size_t)wv * 2 * 64 * RCK_LD;
+    float* Eb = Qb + 64 * RCK_LD;
     const int64_t npairs = min((int64_t)a.b.counter[0], a.b.cap);
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (int64_t)gridDim.x * blockDim.x) {
-        const int2 pr = a.b.pairs[p];
+    const int64_t ngroups = (npairs + 63) / 64;
+    const int lrow = lane >> 3, lpc = lane & 7;   // loader: 8 rows per instruction, 8 16-byte pieces per row chunk
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t p = grp * 64 + lane;
+        const bool have = p < npairs;
+        const int2 pr = a.b.pairs[have ? p : npairs - 1];
         const int64_t pos = a.ent_lo + pr.y;
-        const int64_t id = a.ent_ids ? (int64_t)a.ent_ids[pos] : pos;
-        const float4* q = reinterpret_cast<const float4*>(a.Q + (int64_t)pr.x * a.QW);
-        const float4* e = reinterpret_cast<const float4*>(a.ent + id * a.K);
+        const int64_t qoff = (int64_t)pr.x * a.QW, eoff = (a.ent_ids ? (int64_t)a.ent_ids[pos] : pos) * a.K;
         float acc = 0.f;
-        const int nq = a.U >> 2;
-        int u = 0;
-        for (; u + 8 <= nq; u += 8) {   // a 128-byte line of each row per step: the eight loads are issued together
-            float4 qv[8], ev[8];
+        for (int u0 = 0; u0 < a.U; u0 += RCK_CH) {
+            // rows 8 i + lrow of this wave's 64 pairs: their offsets come from the lanes that own them
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { qv[c] = q[u + c]; ev[c] = e[u + c]; }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                acc = fmaf(qv[c].x, ev[c].x, acc); acc = fmaf(qv[c].y, ev[c].y, acc);
-                acc = fmaf(qv[c].z, ev[c].z, acc); acc = fmaf(qv[c].w, ev[c].w, acc);
+            for (int i = 0; i < 8; ++i) {
+                const int64_t qo = __shfl(qoff, 8 * i + lrow, 64), eo = __shfl(eoff, 8 * i + lrow, 64);
+                const int uu = u0 + 4 * lpc;
+                float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), ev = qv;
+                if (uu < a.U) {   // (U % 4 == 0: a piece is inside or outside as a whole)
+                    qv = *reinterpret_cast<const float4*>(a.Q + qo + uu);
+                    ev = *reinterpret_cast<const float4*>(a.ent + eo + uu);
+                }
+                *reinterpret_cast<float4*>(Qb + (8 * i + lrow) * RCK_LD + 4 * lpc) = qv;
+                *reinterpret_cast<float4*>(Eb + (8 * i + lrow) * RCK_LD + 4 * lpc) = ev;
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int lim = min(RCK_CH, a.U - u0) >> 2;
+#pragma unroll
+            for (int c = 0; c < RCK_CH / 4; ++c) {
+                if (c < lim) {
+                    const float4 qv = *reinterpret_cast<const float4*>(Qb + lane * RCK_LD + 4 * c);
+                    const float4 ev = *reinterpret_cast<const float4*>(Eb + lane * RCK_LD + 4 * c);
+                    acc = fmaf(qv.x, ev.x, acc); acc = fmaf(qv.y, ev.y, acc);
+                    acc = fmaf(qv.z, ev.z, acc); acc = fmaf(qv.w, ev.w, acc);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        for (; u < nq; ++u) {
-            const float4 qv = q[u], ev = e[u];
-            acc = fmaf(qv.x, ev.x, acc); acc = fmaf(qv.y, ev.y, acc); acc = fmaf(qv.z, ev.z, acc); acc = fmaf(qv.w, ev.w, acc);
+        if (have) {
+            const int qs = quantise(a.sgn_scale * acc), qp = a.qpos[pr.x];
+            if (qp < qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 0], 1);
+            else if (qp == qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 1], 1);
         }
-        const int qs = quantise(a.sgn_scale * acc), qp = a.qpos[pr.x];
-        if (qp < qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 0], 1);
-        else if (qp == qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 1], 1);
     }
 }
 

@@ -6,30 +6,11 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <vector>
-
 #include "kge_opt.h"
 
 using namespace kge;
 
-struct amdkge_session {
-    amdkge_session_config cfg;   // cfg.model.k_pad = amdkge_padded_k(k): the session owns the tables and stores them padded
-    int K = 0;                   // floats per DENSE row (what the host hands over and gets back)
-    int Ks = 0;                  // floats per STORED row
-    hipStream_t st = nullptr;
-    float* tab[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // AMDKGE_TABLE_* order
-    float* g_ent = nullptr;
-    float* g_rel = nullptr;
-    double* acc = nullptr;          // [data loss, regulariser loss]
-    void* twork = nullptr;          // owner-computes workspace (zero-filled when (re)allocated)
-    int64_t twork_bytes = 0;
-    void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // growable scratch
-    int64_t buf_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t step = 0;
-    int64_t iteration = 0;
-    std::vector<int32_t> hot_ids;   // AMDKGE_TILED_HOT_ROWS: declared hot rows, (re)applied whenever the workspace is (re)allocated
-    bool hot_dirty = false;
-};
+#include "kge_session_impl.h"
 
 namespace {
 
@@ -248,6 +229,67 @@ extern "C" int amdkge_session_train_step(amdkge_session* s, const int32_t* tripl
     s->step += 1;
     s->iteration += 1;
     if (loss_out) *loss_out = h[0] + h[1];
+    return AMDKGE_OK;
+}
+
+// ---- data-parallel phases of a step (session group) ----------------------------------------------------------------------
+int amdkge_session_grad_step(amdkge_session* s, const int32_t* triples, int64_t b, const float* focus_w, int64_t row_offset, int64_t b_global) {
+    if (!s || b < 0 || (b > 0 && !triples)) return set_error(AMDKGE_EINVAL, "session_grad_step: bad arguments");
+    if (focus_w && !s->cfg.loss.focus_nonlinearity) return set_error(AMDKGE_EINVAL, "session_grad_step: FocusE weights given but the session's loss has focus_nonlinearity == 0");
+    KGE_RC(check_triples(s, triples, b, "session_grad_step"));
+    KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+    KGE_HIP(hipMemsetAsync(s->acc, 0, 2 * sizeof(double), s->st), "hipMemsetAsync");
+    if (b == 0) return AMDKGE_OK;   // (a replica without a share: its zero gradients still take part in the sum)
+    const amdkge_model* m = &s->cfg.model;
+    void *d_tri, *d_fw = nullptr;
+    KGE_RC(upload(s, 0, triples, b * 3 * (int64_t)sizeof(int32_t), &d_tri));
+    amdkge_loss loss = s->cfg.loss;
+    if (focus_w) { KGE_RC(upload(s, 1, focus_w, b * (int64_t)sizeof(float), &d_fw)); loss.d_focus_w = (const float*)d_fw; }
+    else { loss.focus_nonlinearity = AMDKGE_FOCUS_OFF; loss.d_focus_w = nullptr; }
+    amdkge_opt opt = s->cfg.opt;
+    opt.iteration = s->iteration + 1;
+    const int64_t need = amdkge_train_tiled_workspace_bytes(m, b, s->cfg.eta);
+    if (need > 0) {
+        if (need > s->twork_bytes) {
+            if (s->twork) KGE_HIP(hipFree(s->twork), "hipFree(twork)");
+            s->twork = nullptr; s->twork_bytes = 0;
+            KGE_HIP(hipMalloc(&s->twork, (size_t)need), "hipMalloc(twork)");
+            KGE_HIP(hipMemsetAsync(s->twork, 0, (size_t)need, s->st), "hipMemsetAsync(twork)");
+            s->twork_bytes = need;
+        }
+        const int32_t flags = s->cfg.flags & (AMDKGE_TILED_POS_ATOMIC | AMDKGE_TILED_DETERMINISTIC);   // (hot-row replicas: single-GPU steps only)
+        const int rc = amdkge_train_step_tiled(m, &loss, &opt, s->tab[0], s->tab[1], nullptr, nullptr, nullptr, nullptr, 0.f,
+                                               (const int32_t*)d_tri, b, s->cfg.eta, 0, m->n_ents, s->cfg.seed, s->step, row_offset, b_global,
+                                               nullptr, s->g_ent, s->g_rel, 0, flags, s->acc, s->acc + 1, nullptr, nullptr, s->twork, s->st);
+        if (rc != AMDKGE_OK) { (void)hipFree(s->twork); s->twork = nullptr; s->twork_bytes = 0; return rc; }
+        return AMDKGE_OK;
+    }
+    return amdkge_train_fwdbwd(m, &loss, s->tab[0], s->tab[1], (const int32_t*)d_tri, b, s->cfg.eta, 0, m->n_ents, s->cfg.seed, s->step,
+                               row_offset, b_global, nullptr, s->g_ent, s->g_rel, s->acc, nullptr, nullptr, s->st);
+}
+
+int amdkge_session_apply_step(amdkge_session* s) {
+    if (!s) return set_error(AMDKGE_EINVAL, "session_apply_step: NULL session");
+    KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+    const amdkge_model* m = &s->cfg.model;
+    amdkge_opt opt = s->cfg.opt;
+    opt.iteration = s->iteration + 1;
+    KGE_RC(amdkge_opt_step(&opt, s->tab[0], s->g_ent, s->tab[2], s->tab[3], m->n_ents * (int64_t)s->Ks, s->acc + 1, s->st));
+    amdkge_opt orel = opt;
+    orel.reg_lambda = s->cfg.rel_reg_lambda;
+    if (opt.rel_reg_p > 0) orel.reg_p = opt.rel_reg_p;
+    orel.reg2_p = opt.rel_reg2_p; orel.reg2_lambda = opt.rel_reg2_lambda;
+    return amdkge_opt_step(&orel, s->tab[1], s->g_rel, s->tab[4], s->tab[5], m->n_rels * (int64_t)s->Ks, s->acc + 1, s->st);
+}
+
+int amdkge_session_finish_step(amdkge_session* s, double (&h)[2]) {
+    h[0] = h[1] = 0.0;
+    if (!s) return set_error(AMDKGE_EINVAL, "session_finish_step: NULL session");
+    KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+    KGE_HIP(hipMemcpyAsync(h, s->acc, sizeof(h), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
+    KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+    s->step += 1;
+    s->iteration += 1;
     return AMDKGE_OK;
 }
 

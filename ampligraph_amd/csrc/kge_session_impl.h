@@ -1,0 +1,33 @@
+// Private to the session translation units (kge_session.hip, kge_session_group.hip): the state behind the opaque handle.
+#pragma once
+#include <vector>
+
+#include "kge_opt.h"
+
+struct amdkge_session {
+    amdkge_session_config cfg;   // cfg.model.k_pad = amdkge_padded_k(k): the session owns the tables and stores them padded
+    int K = 0;                   // floats per DENSE row (what the host hands over and gets back)
+    int Ks = 0;                  // floats per STORED row
+    hipStream_t st = nullptr;
+    float* tab[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // AMDKGE_TABLE_* order
+    float* g_ent = nullptr;
+    float* g_rel = nullptr;
+    double* acc = nullptr;          // [data loss, regulariser loss]
+    void* twork = nullptr;          // owner-computes workspace (zero-filled when (re)allocated)
+    int64_t twork_bytes = 0;
+    void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // growable scratch
+    int64_t buf_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t step = 0;
+    int64_t iteration = 0;
+    std::vector<int32_t> hot_ids;   // AMDKGE_TILED_HOT_ROWS: declared hot rows, (re)applied whenever the workspace is (re)allocated
+    bool hot_dirty = false;
+};
+
+
+// The three phases of a data-parallel step on one replica (kge_session.hip; used by the session group): gradients of the
+// replica's share of a global batch (nothing is updated), the dense sweep over both tables with whatever the gradient
+// buffers then hold, and the read-back of the loss accumulators (synchronises; counts the step).
+__attribute__((visibility("hidden"))) int amdkge_session_grad_step(amdkge_session* s, const int32_t* triples, int64_t b, const float* focus_w,
+                                                                   int64_t row_offset, int64_t b_global);
+__attribute__((visibility("hidden"))) int amdkge_session_apply_step(amdkge_session* s);
+__attribute__((visibility("hidden"))) int amdkge_session_finish_step(amdkge_session* s, double (&h)[2]);

@@ -26,34 +26,45 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
 
 
+def _config(scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer, rel_regularizer, seed, device, pos_atomic,
+            focus_nonlinearity, deterministic):
+    cfg = _ffi.SessionConfig()
+    cfg.model = _ffi.Model(_ffi.SCORING_TYPES[scoring_type], int(k), int(n_ents), int(n_rels), int(n_rels), 0)
+    cfg.loss = loss.to_ffi()
+    if focus_nonlinearity is not None:
+        cfg.loss.focus_nonlinearity = _ffi.FOCUS_NONLINEARITY[focus_nonlinearity]
+    from .engine import reg_fields
+
+    cfg.opt = optimizer.to_ffi(1, 2)
+    cfg.opt.reg_p, cfg.opt.reg_lambda, cfg.opt.reg2_p, cfg.opt.reg2_lambda = reg_fields(regularizer, 2)
+    rr = rel_regularizer if rel_regularizer is not None else regularizer
+    rp1, rl1, rp2, rl2 = reg_fields(rr, 2)
+    if rl1 == 0.0 and rl2 != 0.0:
+        rp1, rl1, rl2 = rp2, rl2, 0.0
+    cfg.rel_reg_lambda, cfg.opt.rel_reg_p, cfg.opt.rel_reg2_p, cfg.opt.rel_reg2_lambda = rl1, rp1, rp2, rl2
+    cfg.eta, cfg.seed, cfg.device, cfg.flags = int(eta), int(seed), int(device), (1 if pos_atomic else 0) | (2 if deterministic else 0)
+    return cfg
+
+
 class Session:
     def __init__(self, scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer=None, rel_regularizer=None, seed=0,
-                 device=0, pos_atomic=False, focus_nonlinearity=None, deterministic=False):
+                 device=0, pos_atomic=False, focus_nonlinearity=None, deterministic=False, _handle=None):
         self.lib = _ffi.lib()
         self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], int(k)))
         self.n_ents, self.n_rels = int(n_ents), int(n_rels)
-        cfg = _ffi.SessionConfig()
-        cfg.model = _ffi.Model(_ffi.SCORING_TYPES[scoring_type], int(k), self.n_ents, self.n_rels, self.n_rels, 0)
-        cfg.loss = loss.to_ffi()
-        if focus_nonlinearity is not None:
-            cfg.loss.focus_nonlinearity = _ffi.FOCUS_NONLINEARITY[focus_nonlinearity]
-        from .engine import reg_fields
-
-        cfg.opt = optimizer.to_ffi(1, 2)
-        cfg.opt.reg_p, cfg.opt.reg_lambda, cfg.opt.reg2_p, cfg.opt.reg2_lambda = reg_fields(regularizer, 2)
-        rr = rel_regularizer if rel_regularizer is not None else regularizer
-        rp1, rl1, rp2, rl2 = reg_fields(rr, 2)
-        if rl1 == 0.0 and rl2 != 0.0:
-            rp1, rl1, rl2 = rp2, rl2, 0.0
-        cfg.rel_reg_lambda, cfg.opt.rel_reg_p, cfg.opt.rel_reg2_p, cfg.opt.rel_reg2_lambda = rl1, rp1, rp2, rl2
-        cfg.eta, cfg.seed, cfg.device, cfg.flags = int(eta), int(seed), int(device), (1 if pos_atomic else 0) | (2 if deterministic else 0)
+        if _handle is not None:   # a replica of a SessionGroup: the group owns the handle
+            self._h, self._owned = _handle, False
+            return
+        self._owned = True
+        cfg = _config(scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer, rel_regularizer, seed, device, pos_atomic,
+                      focus_nonlinearity, deterministic)
         self._h = C.c_void_p()
         check(self.lib.amdkge_session_create(C.byref(cfg), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if getattr(self, "_h", None) is not None and self._h.value and getattr(self, "_owned", True):
             self.lib.amdkge_session_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -114,3 +125,52 @@ class Session:
                                            int(sub.shape[0]) if sub is not None else 0, _ffi.CORRUPT_SIDES[corrupt_side],
                                            _ffi.RANK_STRATEGY[ranking_strategy], _p(out)))
         return out
+
+
+class SessionGroup:
+    """amdkge_session_group_*: the session layer on several GPUs from ONE process, numpy only -- data-parallel training with the
+    library's own RCCL communicators (kge_session_group.hip).  `devices`: distinct ordinals (RCCL all-reduce over xGMI) or the
+    same ordinal repeated (replicas share one GPU and sum with a kernel: tests on a one-GPU box).  Every replica holds the whole
+    model: replica(i) is an ordinary Session view for get_rows / score / rank."""
+
+    def __init__(self, devices, scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer=None, rel_regularizer=None, seed=0,
+                 pos_atomic=False, focus_nonlinearity=None, deterministic=False):
+        self.lib = _ffi.lib()
+        self._args = (scoring_type, int(k), int(n_ents), int(n_rels), int(eta), loss, optimizer)
+        self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], int(k)))
+        cfg = _config(scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer, rel_regularizer, seed, 0, pos_atomic,
+                      focus_nonlinearity, deterministic)
+        dev = _i32(list(devices))
+        self._g = C.c_void_p()
+        check(self.lib.amdkge_session_group_create(C.byref(cfg), _p(dev), int(dev.shape[0]), C.byref(self._g)))
+        self.size = int(self.lib.amdkge_session_group_size(self._g))
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g.value:
+            self.lib.amdkge_session_group_destroy(self._g)
+        self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def replica(self, i):
+        h = C.c_void_p()
+        check(self.lib.amdkge_session_group_replica(self._g, int(i), C.byref(h)))
+        st, k, ne, nr, eta, loss, opt = self._args
+        return Session(st, k, ne, nr, eta, loss, opt, _handle=h)
+
+    def set_rows(self, table, values, row0=0):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        if v.ndim != 2 or v.shape[1] != self.K:
+            raise ValueError(f"rows must have {self.K} floats")
+        check(self.lib.amdkge_session_group_set_rows(self._g, _ffi.TABLES[table], int(row0), int(v.shape[0]), _p(v)))
+
+    def train_step(self, triples, focus_w=None):
+        t = _i32(triples)
+        fw = np.ascontiguousarray(focus_w, dtype=np.float32) if focus_w is not None else None
+        loss = C.c_double(0.0)
+        check(self.lib.amdkge_session_group_train_step(self._g, _p(t), int(t.shape[0]), _p(fw), C.byref(loss)))
+        return float(loss.value)

@@ -40,6 +40,7 @@ extern "C" {
 #define AMDKGE_OK 0
 #define AMDKGE_EINVAL (-1)       /* invalid argument */
 #define AMDKGE_EHIP (-2)         /* HIP runtime error */
+#define AMDKGE_ERCCL (-3)        /* RCCL error (session groups: librccl not found, communicator or collective failed) */
 #define AMDKGE_ENOMEM (-4)       /* device allocation failed */
 #define AMDKGE_EUNSUPPORTED (-5) /* shape outside the compiled kernels' range */
 
@@ -447,6 +448,29 @@ int amdkge_session_rank(amdkge_session* s, const int32_t* triples, int64_t n,
                         const int64_t* fs_off, const int32_t* fs_ids, const int64_t* fo_off, const int32_t* fo_ids,
                         const int32_t* ent_subset, int64_t n_subset, int32_t corrupt_side, int32_t strategy,
                         int32_t* ranks_out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Session GROUP: the session layer on several GPUs of one node from ONE process (kge_session_group.hip) -- what a host
+ * without torch binds to train data-parallel.  One session (replicated tables, optimizer state, stream) per device; the
+ * library owns the RCCL communicators (librccl is bound at run time; errors: AMDKGE_ERCCL) and issues the collectives.
+ *   devices : n_gpus HIP device ordinals, all distinct (gradient sum = ncclAllReduce over xGMI inside one
+ *             ncclGroupStart / End), or all the same (the replicas share one GPU and sum with a kernel: development /
+ *             tests on a one-GPU box); NULL = 0 .. n_gpus - 1.  n_gpus = 1 is a plain session.
+ *   amdkge_session_group_train_step : ONE global batch of B positives (ScoringBasedEmbeddingModel.train_step,
+ *             ScoringBasedEmbeddingModel.py:370-429): replica d computes the gradients of rows [B d / n, B (d + 1) / n) with
+ *             the negatives one GPU would draw for the whole batch (keyed by the global corruption row), the dense gradients of
+ *             both tables are summed over the replicas, every replica applies the same dense update: replicas stay
+ *             bit-identical, and n replicas compute the step of one GPU up to fp32 summation order.  The reference has no
+ *             multi-device path at all.
+ *   amdkge_session_group_set_rows   : rows of a table on every replica;   amdkge_session_group_replica : replica i, for
+ *             amdkge_session_get_rows / _score / _rank (every replica holds the whole model). */
+typedef struct amdkge_session_group amdkge_session_group;
+int amdkge_session_group_create(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, amdkge_session_group** out);
+void amdkge_session_group_destroy(amdkge_session_group* g);
+int32_t amdkge_session_group_size(const amdkge_session_group* g);
+int amdkge_session_group_replica(amdkge_session_group* g, int32_t i, amdkge_session** out);
+int amdkge_session_group_set_rows(amdkge_session_group* g, int32_t table, int64_t row0, int64_t nrows, const float* host);
+int amdkge_session_group_train_step(amdkge_session_group* g, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out);
 
 #ifdef __cplusplus
 }

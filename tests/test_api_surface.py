@@ -201,3 +201,20 @@ def test_regulariser_forms_the_reference_accepts():
 
     assert reg_fields(None, 2) == (2, 0.0, 2, 0.0) and reg_fields(0.5, 3) == (3, 0.5, 3, 0.0)
     assert reg_fields(regularizers.get("l1_l2"), 2) == (1, 0.01, 2, 0.01)
+
+
+def test_session_group_argument_validation_without_gpu():
+    """Error paths of the group layer that return before touching a device; the RCCL error class exists."""
+    import ctypes
+
+    from ampligraph_amd import _ffi
+
+    lib = _ffi.lib()
+    h = ctypes.c_void_p()
+    assert lib.amdkge_session_group_create(None, None, 2, ctypes.byref(h)) == -1
+    cfg = _ffi.SessionConfig()
+    assert lib.amdkge_session_group_create(ctypes.byref(cfg), None, 0, ctypes.byref(h)) == -1
+    assert lib.amdkge_session_group_create(ctypes.byref(cfg), None, 17, ctypes.byref(h)) == -1
+    assert lib.amdkge_session_group_size(None) == 0
+    assert lib.amdkge_session_group_train_step(None, None, 1, None, None) == -1
+    assert "AMDKGE_ERCCL (-3)" in open(os.path.join(ROOT, "include", "amdkge.h")).read()

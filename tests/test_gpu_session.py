@@ -107,3 +107,49 @@ def test_session_deterministic_and_hot_rows(gpu_lib):
             s.set_hot_rows([N + 3])
         finally:
             s.close()
+
+
+@pytest.mark.parametrize("model,k,opt,n_rep", [("ComplEx", 8, "adam", 2), ("TransE", 12, "adagrad", 3), ("RotatE", 200, "adam", 2), ("DistMult", 600, "sgd", 4)])
+def test_session_group_matches_single_session(gpu_lib, model, k, opt, n_rep):
+    """amdkge_session_group_*: n replicas (here all on device 0: the gradient sum is the library's local kernel instead of
+    ncclAllReduce -- everything else of the multi-GPU path) == one session on the whole batch == the oracle; the replicas stay
+    bit-identical; a group of one is a plain session; RotatE k = 200 / DistMult k = 600 take the owner-computes pair in its
+    gradient-only form (the second one its row-direct tile pass), TransE k = 12 the atomic path."""
+    from ampligraph_amd.latent_features import loss_functions, optimizers, regularizers
+    from ampligraph_amd.session import Session, SessionGroup
+
+    rng = np.random.default_rng(3)
+    N, R, B, eta, seed = 120, 4, 301, 4, 5   # B not divisible by the replica count: ragged shares
+    K = O.internal_k(model, k)
+    ent = (rng.normal(size=(N, K)) * (0.3 if k < 100 else 0.08)).astype(np.float32)
+    rel = (rng.normal(size=(R, K)) * (0.3 if k < 100 else 0.08)).astype(np.float32)
+    X = np.stack([rng.integers(0, N, 3 * B), rng.integers(0, R, 3 * B), rng.integers(0, N, 3 * B)], 1).astype(np.int32)
+    reg = regularizers.get("LP", {"p": 3, "lambda": 1e-3})
+    mk = lambda: (loss_functions.get("self_adversarial"), optimizers.get(opt, {"learning_rate": 1e-2}))   # noqa: E731
+    single = Session(model, k, N, R, eta, *mk(), reg, seed=seed)
+    group = SessionGroup([0] * n_rep, model, k, N, R, eta, *mk(), reg, seed=seed)
+    one = SessionGroup([0], model, k, N, R, eta, *mk(), reg, seed=seed)
+    assert group.size == n_rep and one.size == 1
+    for s in (single, group, one):
+        s.set_rows("ent", ent)
+        s.set_rows("rel", rel)
+    st = O.TrainState(ent, rel, opt, 1e-2)
+    for t in range(3):
+        xb = X[t * B:(t + 1) * B]
+        l1, lg, lo = single.train_step(xb), group.train_step(xb), one.train_step(xb)
+        ref = float(O.train_step(st, model, xb, eta, "self_adversarial", seed, t, max_rel_size=R, reg=dict(p=3, lam_e=1e-3, lam_r=1e-3)))
+        # (fp64 loss partials are added with atomics: two runs of the same step agree to ~1e-13, not bit for bit)
+        assert abs(lg - ref) <= 3e-5 * abs(ref) and abs(l1 - ref) <= 3e-5 * abs(ref) and abs(lo - l1) <= 1e-8 * abs(l1), (t, l1, lg, lo, ref)
+    reps = [group.replica(i) for i in range(n_rep)]
+    e0, r0 = reps[0].get_rows("ent"), reps[0].get_rows("rel")
+    for rp in reps[1:]:
+        assert np.array_equal(rp.get_rows("ent"), e0) and np.array_equal(rp.get_rows("rel"), r0)   # replicas: bit-identical
+    es = single.get_rows("ent")
+    assert np.mean(np.abs(e0 - es) <= 1e-5 + 1e-3 * np.abs(es)) > 0.99 and np.abs(e0 - es).max() < 2.5e-2
+    assert np.mean(np.abs(e0 - st.ent) <= 1e-5 + 1e-3 * np.abs(st.ent)) > 0.99
+    eo = one.replica(0).get_rows("ent")                                                             # a group of one == a session (up to the arrival order of fp32 atomics)
+    assert np.mean(np.abs(eo - es) <= 1e-5 + 1e-3 * np.abs(es)) > 0.99
+    T = X[:32]
+    assert np.allclose(reps[-1].score(T), single.score(T), rtol=1e-4, atol=1e-5)
+    for s in (single, group, one):
+        s.close()
