@@ -174,7 +174,7 @@ struct ScreenArgs {
 
 constexpr int SCR_THREADS = 256;   // 4 waves, each a 32-query block against the workgroup's 64-entity tile; TWO workgroups per CU
 constexpr int SCR_ET = 64;         // entities per tile
-constexpr int SCR_PEND = 256;      // undecided pairs a wave parks in LDS before they go to the list
+constexpr int SCR_PEND = 512;      // undecided pairs a wave parks in LDS before they go to the list
 constexpr size_t SCR_LDS_BYTES = (size_t)2 * 3 * 2 * SCR_ET * 16 + 128 * 16 + 128 * 8 + SCR_ET * 16 + 4 * SCR_PEND * 8;   // E double-buffered + row metas + parked pairs
 
 // Operand feed.  The i8 matrix instruction retires 65 536 multiply-adds in ~33 cycles, so the kernel is bound by how fast the
@@ -185,7 +185,7 @@ constexpr size_t SCR_LDS_BYTES = (size_t)2 * 3 * 2 * SCR_ET * 16 + 128 * 16 + 12
 // phase: one's epilogue (VALU) under the other's matrix work.
 __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_scr[];
-    typedef uint4 (*slab_t)[3][2][SCR_ET];
+    typedef uint4 (*slab_t)[2][3][2][32];   // [buffer][entity block][limb][half][row]: a buffer is the two blocks' slabs back to back
     slab_t Es = reinterpret_cast<slab_t>(smem_scr);
     float4* qm_s = reinterpret_cast<float4*>(smem_scr + (size_t)2 * 3 * 2 * SCR_ET * 16);
     float2* qt_s = reinterpret_cast<float2*>(qm_s + 128);
@@ -236,47 +236,50 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
     for (int r = 0; r < 16; ++r) rowmask |= (q0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.n) ? (3u << (2 * r)) : 0u;
     // this wave's query fragments: block (q0 + wq) / 32, one coalesced 1 KB read per limb and slab (rows beyond n: the stale tail
     // of the last block -- finite integers; their outputs are masked by the thresholds above)
-    const uint4* qsrc = reinterpret_cast<const uint4*>(a.b.qlimbs + ((q0 + wq) >> 5) * (int64_t)S * SCR_BLK_SLAB) + lane;
+    // Addresses are a wave-uniform base (scalar registers, advanced once per stage) plus a per-lane byte offset fixed for the
+    // whole kernel: no 64-bit vector address arithmetic inside the stage loop.
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    const char* const qbase = reinterpret_cast<const char*>(a.b.qlimbs) + ((q0 + 32 * wv_s) >> 5) * (int64_t)S * SCR_BLK_SLAB;
+    const uint32_t qoff = (uint32_t)lane * 16u;
     auto load_q = [&](int s, v4i32 (&f)[3]) {
+        const char* const qs = qbase + (size_t)s * SCR_BLK_SLAB;
 #pragma unroll
-        for (int lb = 0; lb < 3; ++lb) { const uint4 u = qsrc[(size_t)s * (SCR_BLK_SLAB / 16) + 64 * lb]; f[lb] = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
+        for (int lb = 0; lb < 3; ++lb) { const uint4 u = *reinterpret_cast<const uint4*>(qs + (qoff + 1024u * lb)); f[lb] = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
     };
-    // entity slab loader: the tile's two 32-row blocks x 192 16-byte pieces per stage; piece p = tid (and tid + 256 < 384):
-    // block = p / 192, w = p % 192 = (limb * 2 + half) * 32 + row: global and LDS order coincide within a block
-    const int p0 = tid, p1 = tid + 256;
-    const bool second = p1 < 384;
-    const int b0 = p0 / 192, w0 = p0 % 192, b1 = (p1 % 384) / 192, w1 = (p1 % 384) % 192;
-    uint4* const lds0 = &Es[0][0][0][0] + (w0 >> 5) * SCR_ET + b0 * 32 + (w0 & 31);
-    uint4* const lds1 = &Es[0][0][0][0] + (w1 >> 5) * SCR_ET + b1 * 32 + (w1 & 31);
-    const uint4* esrc0 = nullptr;
-    const uint4* esrc1 = nullptr;
-    auto set_src = [&](int64_t et) {   // (et is a multiple of 64; blocks beyond the table's end are slack rows of the buffer)
-        esrc0 = reinterpret_cast<const uint4*>(a.b.elimbs + ((et >> 5) + b0) * (int64_t)S * SCR_BLK_SLAB) + w0;
-        esrc1 = reinterpret_cast<const uint4*>(a.b.elimbs + ((et >> 5) + b1) * (int64_t)S * SCR_BLK_SLAB) + w1;
-    };
+    // entity slab loader: a stage's LDS image is the two 32-row blocks' 3 072-byte slabs back to back (6 144 bytes), exactly as
+    // they lie in memory.  Every thread copies 16 bytes at 16 tid (the first 4 096) and 8 bytes at 4 096 + 8 tid: both loads of
+    // ALL threads are unconditional (a predicated load leaves the compiler without a vmcnt it can count on -- it then waited for
+    // loads it had just issued) and every instruction reads and writes one contiguous run.
+    const uint32_t blk_stride = (uint32_t)S * SCR_BLK_SLAB;   // bytes between consecutive 32-row blocks (S <= 64 slabs: < 2^18)
+    const uint32_t offA = tid < 192 ? (uint32_t)tid * 16u : blk_stride + (uint32_t)(tid - 192) * 16u;
+    const uint32_t offB = blk_stride + 1024u + (uint32_t)tid * 8u;
+    const uint32_t emoff = (uint32_t)(tid & (SCR_ET - 1)) * 16u;
+    uint4* const ldsA = &Es[0][0][0][0][0] + tid;
+    uint2* const ldsB = reinterpret_cast<uint2*>(reinterpret_cast<char*>(&Es[0][0][0][0][0]) + 4096) + tid;
+    const char* ebase = nullptr;   // slab ld_s of the tile's first block (et is a multiple of 64; blocks beyond the table's end are slack rows of the buffer)
     // The (tile, slab) sequence is ONE stream of positions g = 0 .. ntile S - 1, software-pipelined two deep on the entity side:
     // at position g the global loads of position g + 2 are issued (register set g % 2), the set loaded during g - 1 (position
     // g + 1) goes to the other LDS buffer at the end, and the query fragments of g + 1 are requested for the next position --
     // a round trip to L2 / the Infinity Cache (~2 000 cycles) is covered by two stages of matrix work of both resident
     // workgroups instead of stalling every stage (measured: 2 950 cycles per stage with a one-deep pipeline against 385 of MFMA).
-    uint4 e00 = make_uint4(0, 0, 0, 0), e01 = e00, e10 = e00, e11 = e00;   // register sets 0 / 1 x the thread's two pieces (scalars: an array would live in scratch)
+    uint4 eA0 = make_uint4(0, 0, 0, 0), eA1 = eA0;   // register sets 0 / 1 x the thread's two pieces (scalars: an array would live in scratch)
+    uint2 eB0 = make_uint2(0, 0), eB1 = eB0;
     int ld_s = 0;
     int64_t ld_tile = 0;
-    auto advance = [&]() {
+    auto set_src = [&](int64_t et) { ebase = reinterpret_cast<const char*>(a.b.elimbs) + (et >> 5) * (int64_t)blk_stride; };
+    auto load_e = [&](uint4& pa, uint2& pb) {
+        pa = *reinterpret_cast<const uint4*>(ebase + offA);
+        pb = *reinterpret_cast<const uint2*>(ebase + offB);
+        ebase += SCR_BLK_SLAB;
         if (++ld_s == S) {
             ld_s = 0;
             ld_tile = ld_tile + 1 < ntile ? ld_tile + 1 : ntile - 1;   // (past the end: harmless re-reads of the last tile)
             set_src(e_begin + ld_tile * SCR_ET);
         }
     };
-    auto load_e = [&](uint4& pa, uint4& pb) {
-        pa = esrc0[(size_t)ld_s * (SCR_BLK_SLAB / 16)];
-        if (second) pb = esrc1[(size_t)ld_s * (SCR_BLK_SLAB / 16)];
-        advance();
-    };
-    auto store_e = [&](int buf, const uint4& pa, const uint4& pb) {
-        lds0[(size_t)buf * (6 * SCR_ET)] = pa;
-        if (second) lds1[(size_t)buf * (6 * SCR_ET)] = pb;
+    auto store_e = [&](int buf, const uint4& pa, const uint2& pb) {
+        ldsA[(size_t)buf * 384] = pa;
+        ldsB[(size_t)buf * 768] = pb;
     };
 
     int cnt[16];   // per accumulator register (= query row of this lane): greater | equal << 16
@@ -292,47 +295,73 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
 
     v4i32 qf[2][3];
     set_src(e_begin);
-    load_e(e00, e01);        // position 0 -> LDS buffer 0
-    load_e(e10, e11);        // position 1 -> register set 1
+    load_e(eA0, eB0);        // position 0 -> LDS buffer 0
+    load_e(eA1, eB1);        // position 1 -> register set 1
     load_q(0, qf[0]);
-    store_e(0, e00, e01);
+    store_e(0, eA0, eB0);
     __syncthreads();
     int st = 0;
-    int64_t t = 0;
+    int t = 0;   // tile of the current position
     int npend = 0;   // pairs parked in this wave's LDS buffer (wave-uniform)
     int2* const pend = reinterpret_cast<int2*>(em_s + SCR_ET) + wv * SCR_PEND;
+    // The list writes are issued as inline assembly and end with their own vmcnt(0): a store (or returning atomic) the compiler
+    // knows about, pending next to the stage loop's prefetch loads, makes it give up counting vmcnt -- the first wait of every
+    // stage became a vmcnt(0) on loads issued a moment earlier.  Memory operations it does not know about only make its waits
+    // stricter (vmcnt retires in order), never wrong.
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         int b0 = 0;
-        if (lane == 63) b0 = atomicAdd(a.b.counter, npend);
+        if (lane == 63) asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(b0) : "v"(a.b.counter), "v"(npend) : "memory");
         const int64_t base = __shfl(b0, 63, 64);
         for (int i = lane; i < npend; i += 64) {
-            if (base + i < a.b.cap) a.b.pairs[base + i] = pend[i];
-            else a.b.counter[1] = 1;   // the list is full: the call falls back to the exact kernel
+            if (base + i < a.b.cap) {
+                const uint64_t v = *reinterpret_cast<const uint64_t*>(pend + i);
+                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(a.b.pairs + base + i), "v"(v) : "memory");
+            } else {   // the list is full: the call falls back to the exact kernel
+                const int one = 1;
+                asm volatile("global_store_dword %0, %1, off" :: "v"(a.b.counter + 1), "v"(one) : "memory");
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         npend = 0;
     };
+    auto append = [&](uint32_t msk, int64_t et) {   // park the marked outputs (bit 2 r + ni of a lane) of this wave; <= SCR_PEND of them
+        const int mine = __popc(msk);
+        int incl = mine;   // inclusive prefix over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
+        const int total = __shfl(incl, 63, 64);
+        if (!total) return;
+        if (npend + total > SCR_PEND) flush();
+        int at = npend + incl - mine;
+        while (msk) {
+            const int bit = __builtin_ctz(msk);
+            msk &= msk - 1;
+            const int r = bit >> 1, ni = bit & 1;
+            pend[at++] = make_int2((int)(q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh), (int)(et + ni * 32 + l31));
+        }
+        npend += total;
+    };
     auto stage = [&](auto par_c) __attribute__((always_inline)) {
         constexpr int P = decltype(par_c)::value;   // g % 2: this position's LDS buffer and query set, the register set free for g + 2
         const int64_t et = e_begin + t * SCR_ET;
-        if (st == 0 && tid < SCR_ET) {   // candidates beyond the range: a bias of -inf on the score -- never counted
-            const bool oke = et + tid < e_end;
-            float4 m4 = a.b.em[oke ? et + tid : e_end - 1];
-            m4.w = oke ? 0.f : -INFINITY;
-            em_s[tid] = m4;   // (read in the epilogue: behind the stage barriers)
-        }
-        if constexpr (P == 0) load_e(e00, e01); else load_e(e10, e11);
+        // Loads of a stage, in THIS order and all unconditional (vmcnt retires in order and the compiler counts it): the tile's
+        // candidate metas (used at stage 0 only), the entity pieces of position g + 2, the query fragments of g + 1.
+        // (the metas of up to 63 candidates beyond the range are read: rows of later candidates or the head of the recheck list)
+        float4 m4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.b.em + et) + emoff);
+        if constexpr (P == 0) load_e(eA0, eB0); else load_e(eA1, eB1);
         load_q(st + 1 == S ? 0 : st + 1, qf[P ^ 1]);   // (the query rows do not change with the entity tile)
+        __builtin_amdgcn_sched_barrier(0);
         // both entity blocks' fragments first, then the 12 matrix instructions ordered so that two of them on the SAME accumulator
         // are never adjacent (a dependent pair would wait out the first one's latency: twice its issue time)
         v4i32 eb[2][3];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int lb = 0; lb < 3; ++lb) { const uint4 u = Es[P][lb][lh][ni * 32 + l31]; eb[ni][lb] = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
+            for (int lb = 0; lb < 3; ++lb) { const uint4 u = Es[P][ni][lb][lh][l31]; eb[ni][lb] = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
         acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][0], eb[0][0], acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][0], eb[1][0], acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][0], eb[0][1], acc[1][0], 0, 0, 0);
@@ -345,9 +374,13 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
         acc[2][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][1], eb[1][1], acc[2][1], 0, 0, 0);
         acc[2][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][2], eb[0][0], acc[2][0], 0, 0, 0);
         acc[2][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qf[P][2], eb[1][0], acc[2][1], 0, 0, 0);
-        if constexpr (P == 0) store_e(1, e10, e11); else store_e(0, e00, e01);
+        if constexpr (P == 0) store_e(1, eA1, eB1); else store_e(0, eA0, eB0);
+        if (st == 0 && tid < SCR_ET) {   // candidates beyond the range: an infinite error bound -- never decided, never counted
+            if (et + tid >= e_end) m4.y = INFINITY;
+            em_s[tid] = m4;   // (read in the epilogue, behind this stage's barrier; the previous epilogue ended with one)
+        }
         __syncthreads();
-        if (++st == S) {
+        if (++st == S && t < ntile) {
         // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
             // Undecided outputs are only MARKED here (bit 2 r + ni of a per-lane mask); the appends to the recheck list happen once
             // per tile behind the loop: one atomic per wave instead of a ballot, a branch and an atomic per output.
@@ -360,56 +393,29 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
                 const float2 qt = qt_s[row];
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    const float4 em = em_s[ni * 32 + l31];   // {B, |e|_2, |e|_1 / 2, 0 or -inf}
-                    // S~ = (L0 2^16 + L1 2^8 + L2) 2^16 A B   (+ the -inf bias of a candidate beyond the range)
+                    const float4 em = em_s[ni * 32 + l31];   // {B, |W e|_2 (infinite: row with inf / NaN, candidate beyond the range), |e|_1 / 2, -}
+                    // S~ = (L0 2^16 + L1 2^8 + L2) 2^16 A B
                     const float f = fmaf((float)acc[0][ni][r], 65536.f, fmaf((float)acc[1][ni][r], 256.f, (float)acc[2][ni][r]));
                     const float s0 = f * (qm.x * em.x);
-                    const float sc = s0 + em.w;
-                    // E = c (gamma |q|_2 |e|_2 + A |e|_1 / 2 + B (|q|_1 / 2 + drop A)) + 2^-20 |S~|
+                    // E = c (gamma |W q|_2 |W e|_2 + A |e|_1 / 2 + B (|q|_1 / 2 + drop A)) + 2^-20 |S~|
                     const float e = fmaf(0x1p-20f, fabsf(s0), fmaf(qm.y, em.y, fmaf(qm.z, em.z, qm.w * em.x)));
-                    const float lo = sc - e, hi = sc + e;
+                    // greater: S~ - E >= T_gt;  smaller: S~ + E < T_ge;  equal after quantisation: [S~ - E, S~ + E] inside
+                    // [T_ge, T_gt) -- the quantisation bins are wide enough for that to settle a third of the near-ties
+                    const float lo = s0 - e, hi = s0 + e;
                     const bool gt = lo >= qt.y, lt = hi < qt.x, eq = (lo >= qt.x) && (hi < qt.y);
                     cnt[r] += gt ? 1 : 0;
                     cnt[r] += eq ? 0x10000 : 0;
-                    undm |= !(gt || lt || eq) ? (1u << (2 * r + ni)) : 0u;   // (NaN bounds compare false everywhere: undecided)
+                    undm |= !(gt || lt || eq) ? (1u << (2 * r + ni)) : 0u;   // (NaN / infinite bounds compare false everywhere: undecided)
                 }
             }
             undm &= rowmask;
             if (et + l31 >= e_end) undm &= 0xAAAAAAAAu;        // candidate of block 0 beyond the range
             if (et + 32 + l31 >= e_end) undm &= 0x55555555u;   // candidate of block 1 beyond the range
-            {
-                // Undecided pairs are parked in this wave's LDS buffer and go to the list SCR_PEND at a time (one returning atomic
-                // and coalesced stores per flush): one atomic per wave and tile on the single counter -- 145 000 of them at C2 --
-                // serialised at the L2 and cost more than the matrix work.
-                const int mine = __popc(undm);
-                int incl = mine;   // inclusive prefix over the wave
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
-                const int total = __shfl(incl, 63, 64);
-                if (total) {
-                    if (npend + total > SCR_PEND) flush();
-                    const bool direct = total > SCR_PEND;   // (a tile of undecided outputs: straight to the list)
-                    int64_t base = 0;
-                    if (direct) {
-                        int b0 = 0;
-                        if (lane == 63) b0 = atomicAdd(a.b.counter, total);
-                        base = __shfl(b0, 63, 64);
-                    }
-                    int at = incl - mine;
-                    uint32_t mm = undm;
-                    while (mm) {
-                        const int bit = __builtin_ctz(mm);
-                        mm &= mm - 1;
-                        const int r = bit >> 1, ni = bit & 1;
-                        const int2 pr = make_int2((int)(q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh), (int)(et + ni * 32 + l31));
-                        if (!direct) pend[npend + at] = pr;
-                        else if (base + at < a.b.cap) a.b.pairs[base + at] = pr;
-                        else a.b.counter[1] = 1;   // the list is full: the call falls back to the exact kernel
-                        ++at;
-                    }
-                    if (!direct) npend += total;
-                }
-            }
+            // Undecided pairs are parked in this wave's LDS buffer and go to the list when it is full (one returning atomic and
+            // coalesced stores per flush): one atomic per wave and tile on the single counter -- 145 000 of them at C2 --
+            // serialised at the L2 and cost more than the matrix work.
+            if (__popcll(__ballot(undm != 0u)) <= SCR_PEND / 32) append(undm, et);   // (<= 32 outputs per lane)
+            else for (int ps = 0; ps < 4; ++ps) append(undm & (0xFFu << (8 * ps)), et);   // (<= 8 per lane: 512 per wave)
 #pragma unroll
             for (int lv = 0; lv < 3; ++lv)
 #pragma unroll
@@ -421,10 +427,13 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
             __syncthreads();   // em_s is rewritten by the next tile
         }
     };
-    const int64_t G = ntile * S;
-    for (int64_t g = 0; g < G; g += 2) {
+    // Always whole pairs of stages: with an odd number of positions the last pair's second stage multiplies re-read rows of the
+    // last tile into accumulators nobody reads (its epilogue is guarded by t < ntile).  A conditional second stage gives the
+    // loop a path on which the first stage's loads are still pending, and the compiler then waits for them on EVERY path.
+    const int G = (int)(ntile * S);   // (< 2^31: a block's tiles x slabs)
+    for (int g = 0; g < G; g += 2) {
         stage(std::integral_constant<int, 0>{});
-        if (g + 1 < G) stage(std::integral_constant<int, 1>{});
+        stage(std::integral_constant<int, 1>{});
     }
     if (npend) flush();
     // ---- per query row: sum over the 32 lanes that share it ----

@@ -526,6 +526,12 @@ class KgeEngine:
 
     SCREEN_MAX_BYTES = 4 << 30
 
+    def _side_stream(self):
+        """Second stream of this engine's device (the filter pass of rank_side runs on it beside the count pass)."""
+        if getattr(self, "_fstream", None) is None:
+            self._fstream = torch.cuda.Stream(device=self.device)
+        return self._fstream
+
     def screen_stats(self):
         """(rechecked pairs, fell back to the exact kernel?) of the last rank_side call's screening pass, or None when it ran
         without one (TransE / RotatE, tiny or huge problems).  Synchronises."""
@@ -554,17 +560,25 @@ class KgeEngine:
         if 0 < need <= self.SCREEN_MAX_BYTES:
             screen, sbytes = self._buf("rank_screen", (need,), torch.uint8), need
         self._last_screen = screen
-        check(self.lib.amdkge_rank_counts_screened(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples), n,
-                                                   side, _ptr(ent_ids), int(ent_lo), int(ent_hi), _ptr(counts),
-                                                   _ptr(work), _ptr(screen), sbytes, _stream()))
-        sub = None
+        # The filter pass (a latency-bound walk over each triple's known positives) is independent of the count pass: it runs
+        # beside it on a second stream with a workspace of its own and is joined before the two are composed.
+        sub, main, fstream = None, torch.cuda.current_stream(), None
         if flt is not None:
             lo, hi, ids = flt
             sub = torch.zeros(n, dtype=torch.int32, device=self.device)
             f_lo, f_hi = (ent_lo, ent_hi) if flt_range is None else flt_range
-            check(self.lib.amdkge_rank_filter(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples),
-                                              n, side, _ptr(lo), _ptr(hi), _ptr(ids), _ptr(subset_pos),
-                                              int(f_lo), int(f_hi), _ptr(sub), _ptr(work), _stream()))
+            fwork = self._buf("rank_work_filter", (work.numel(),), torch.uint8)
+            fstream = self._side_stream()
+            fstream.wait_stream(main)
+            with torch.cuda.stream(fstream):
+                check(self.lib.amdkge_rank_filter(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples),
+                                                  n, side, _ptr(lo), _ptr(hi), _ptr(ids), _ptr(subset_pos),
+                                                  int(f_lo), int(f_hi), _ptr(sub), _ptr(fwork), _stream()))
+        check(self.lib.amdkge_rank_counts_screened(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples), n,
+                                                   side, _ptr(ent_ids), int(ent_lo), int(ent_hi), _ptr(counts),
+                                                   _ptr(work), _ptr(screen), sbytes, _stream()))
+        if fstream is not None:
+            main.wait_stream(fstream)
         if out is None:
             out = torch.empty(n, dtype=torch.int32, device=self.device)
             out_stride = 1

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-O=$PWD/gpurun_out/r03p; mkdir -p $O
+O=$PWD/gpurun_out/r03s; mkdir -p $O
 R=$PWD
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_rank_screen.py -m gpu -q > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log; grep -E "passed|failed|^E  |FAILED" $O/pytest.log | tail -12

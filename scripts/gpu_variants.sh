@@ -1,12 +1,14 @@
 #!/bin/bash
-# development: compare library variants (build/<name>/libamdkge.so) on bench shapes: $1 = "lib1,lib2", rest = bench flag strings
-set -u
-IFS=',' read -ra LIBS <<< "$1"; shift
-for lib in "${LIBS[@]}"; do
-  if [ "$lib" != default ]; then export AMDKGE_LIB=$PWD/build/$lib/libamdkge.so; else unset AMDKGE_LIB; fi
-  for a in "$@"; do
-    timeout 300 python bench.py $a --no-cpu-baseline --no-eval --steps 200 --warmup 20 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.readline()); print('$lib | $a |', round(d['ms_per_step'],4), 'frac', round(d['roofline']['frac'],3), round(d['phases_ms']['kernels'],4))"
-  done
+# development: per-kernel times of scripts/screen_time.py for the default library and the named build_variants/
+R=$PWD; export TMPDIR=/tmp; cd /tmp
+for v in "" $@; do
+  if [ -n "$v" ]; then export AMDKGE_LIB=$R/build_variants/$v/libamdkge.so; fi
+  O=$R/gpurun_out/var_${v:-default}; rm -rf $O; mkdir -p $O
+  timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o r -- python $R/scripts/screen_time.py 2>$O/err.log | tail -1; tail -2 $O/err.log | cut -c1-200
+  python - <<PY
+import csv, glob
+f = glob.glob("$O/**/*kernel_stats.csv", recursive=True)
+for r in csv.DictReader(open(f[0])):
+    if any(s in r["Name"] for s in ("rank_screen_kernel", "rank_recheck", "rank_filter")): print("  ${v:-default}", r["Name"].split("(")[0][:40], "avg us", round(float(r["AverageNs"])/1e3, 1))
+PY
 done
