@@ -164,6 +164,22 @@ def eval_bench(eng, data, rank):
     dt = (time.perf_counter() - t0) / reps
     r = ranks.cpu().numpy()
     scr = eng.screen_stats()   # int8 screening pass (contraction models): pairs the exact fp32 chain had to recheck (last side)
+    # the same evaluation through the exact fp32 matrix-core kernel alone (round 2's path): ranks must be identical, time beside it
+    exact = None
+    if scr is not None:
+        try:
+            _ffi.check(eng.lib.amdkge_set_rank_kernel(3))
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize()
+            dte = (time.perf_counter() - t0) / reps
+            exact = {"ms": dte * 1e3, "ranks_per_s": 2 * n / dte, "ranks_identical_to_screened": bool(np.array_equal(ranks.cpu().numpy(), r)),
+                     "kernel": "rank_count_mfma_pipe_kernel (v_mfma_f32_32x32x2_f32) for every pair"}
+        finally:
+            eng.lib.amdkge_set_rank_kernel(0)
     flops = 2.0 * data["n_ents"] * eng.K * n * 2
     return {"ranks_per_s": 2 * n / dt, "ms": dt * 1e3, "n_test": int(n), "sides": 2, "filtered": True,
             "filter_index_ms": index_ms, "filter_index": "built on the device (upload + amdkge_filter_build + amdkge_filter_ranges, both sides)",
@@ -172,6 +188,7 @@ def eval_bench(eng, data, rank):
                                                     "fell_back_to_exact_kernel": scr[1],
                                                     "note": "int8 matrix-core pass decides the comparisons a rigorous error bound allows; the "
                                                             "rest are recomputed with the exact fp32 chain: counts bit-identical to the fp32 kernels"}),
+            "exact_fp32_kernel_alone": exact,
             "mrr_untrained_tables": float(np.mean(1.0 / r)), "note": "tables as left by the timed training steps"}
 
 
@@ -376,7 +393,7 @@ def main():
         # the committed counter passes of the headline workload (scripts/profile_bench.sh) and labelled as such; null otherwise
         traffic, traffic_source = None, None
         if world == 1 and args.preset == "C2" and args.popularity == "uniform" and not opt.lazy:
-            for cand in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+            for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
                 pmc = os.path.join(ROOT, "profiles", cand)
                 if os.path.exists(pmc):
                     try:
