@@ -19,7 +19,7 @@
 //                                                               with W = diag(sqrt(U - j)): half of the classic gamma_U |q| |e|)
 //               + (A_i |e_j|_1 + B_j |q_i|_1) / 2 + U A_i B_j / 4   (rounding of the rows to their fixed-point grids)
 //               + U (2^23 + 2^14) A_i B_j                      (the three dropped limb products)
-//               + 8 u |S~|                                     (the epilogue's own fp32 roundings), all inflated by 2^-10;
+//               + 2^-20 |S~|                                  (the epilogue's own fp32 roundings), the rest inflated by 2^-10;
 //      a pair whose interval [S~ - E, S~ + E] lies on one side of both thresholds (or between them) is DECIDED and counted;
 //   3. the others (a fraction of a per cent: those within ~1e-4 of the positive's quantisation cell) go to a list and are
 //      recomputed by rank_recheck_kernel with the exact fp32 chain -- so the counts are bit-identical to the fp32 kernels
