@@ -1097,7 +1097,9 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     if (int rc = check_launch("rank_thresholds")) return rc;
     ScreenArgs sa{};
     sa.b = b; sa.n = n; sa.m = mcand; sa.U = g.U;
-    sa.drop = (float)((double)g.U * (8388608.0 + 16384.0 + 0.25) * (1.0 + 1e-6));
+    // per unit: the three dropped limb products (2^23 + 2^14) and the cross term of the two fixed-point roundings (1/4), in units of
+    // A B; + 2^25: the fp32 reconstruction of the 40-bit integer sum in the epilogue (inner sum rounds by <= 2^8 in units of 2^16 A B)
+    sa.drop = (float)(((double)g.U * (8388608.0 + 16384.0 + 0.25) + 33554432.0) * (1.0 + 1e-6));
     const int64_t qtiles = (n + SCR_Q - 1) / SCR_Q, etiles = (mcand + SCR_ET - 1) / SCR_ET;
     // two workgroups per CU: ~8 rounds of blocks, each block a run of entity tiles (its query fragments stay in L1 / L2)
     int64_t tiles_per = (qtiles * etiles + 16 * 256 - 1) / (16 * 256);

@@ -19,7 +19,8 @@
 //                                                               with W = diag(sqrt(U - j)): half of the classic gamma_U |q| |e|)
 //               + (A_i |e_j|_1 + B_j |q_i|_1) / 2 + U A_i B_j / 4   (rounding of the rows to their fixed-point grids)
 //               + U (2^23 + 2^14) A_i B_j                      (the three dropped limb products)
-//               + 2^-20 |S~|                                  (the epilogue's own fp32 roundings), the rest inflated by 2^-10;
+//               + 2^25 A_i B_j + 2^-22 |S~|                   (the epilogue's own fp32 roundings; the relative part sits in the
+//                                                               thresholds), the rest inflated by 2^-10;
 //      a pair whose interval [S~ - E, S~ + E] lies on one side of both thresholds (or between them) is DECIDED and counted;
 //   3. the others (a fraction of a per cent: those within ~1e-4 of the positive's quantisation cell) go to a list and are
 //      recomputed by rank_recheck_kernel with the exact fp32 chain -- so the counts are bit-identical to the fp32 kernels
@@ -175,7 +176,7 @@ struct ScreenArgs {
 constexpr int SCR_THREADS = 256;   // 4 waves, each a 32-query block against the workgroup's 64-entity tile; TWO workgroups per CU
 constexpr int SCR_ET = 64;         // entities per tile
 constexpr int SCR_PEND = 512;      // undecided pairs a wave parks in LDS before they go to the list
-constexpr size_t SCR_LDS_BYTES = (size_t)2 * 3 * 2 * SCR_ET * 16 + 128 * 16 + 128 * 8 + SCR_ET * 16 + 4 * SCR_PEND * 8;   // E double-buffered + row metas + parked pairs
+constexpr size_t SCR_LDS_BYTES = (size_t)2 * 3 * 2 * SCR_ET * 16 + 128 * 16 + 128 * 16 + SCR_ET * 16 + 4 * SCR_PEND * 8;   // E double-buffered + row metas + parked pairs
 
 // Operand feed.  The i8 matrix instruction retires 65 536 multiply-adds in ~33 cycles, so the kernel is bound by how fast the
 // operands arrive and by its epilogue, not by the matrix pipe.  A wave's QUERY fragments come straight from global memory
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
     typedef uint4 (*slab_t)[2][3][2][32];   // [buffer][entity block][limb][half][row]: a buffer is the two blocks' slabs back to back
     slab_t Es = reinterpret_cast<slab_t>(smem_scr);
     float4* qm_s = reinterpret_cast<float4*>(smem_scr + (size_t)2 * 3 * 2 * SCR_ET * 16);
-    float2* qt_s = reinterpret_cast<float2*>(qm_s + 128);
-    float4* em_s = reinterpret_cast<float4*>(qt_s + 128);
+    float4* qt_s = qm_s + 128;
+    float4* em_s = qt_s + 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -227,7 +228,15 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
         const float4 m4 = a.b.qm[okq ? q0 + tid : a.n - 1];
         const float c = 1.f + 0x1p-10f;
         qm_s[tid] = make_float4(m4.x * 65536.f, m4.y * c, m4.x * c, fmaf(a.drop, m4.x, m4.z) * c);
-        qt_s[tid] = a.b.qt[okq ? q0 + tid : a.n - 1];
+        // The epilogue's own fp32 roundings.  Rebuilding f = L0 2^16 + L1 2^8 + L2 (an integer below 2^40) in fp32 costs at most
+        // 2^8 in the inner sum (absolute: part of `drop`, see run_screen) and 2^-24 |f| in the outer; the scales are powers of two;
+        // S~ -+ E' rounds by 2^-24 (|S~| + E').  The part relative to |S~| (eps = 2^-23, taken as 2^-22) is moved into the
+        // thresholds:  S~ - E' >= T + 2 eps |T|  implies  S~ - E' - eps |S~| >= T  (|S~| <= 2 (|T| + E'): directly, the 2^-10
+        // inflation of E' taking the E' part; larger |S~|: its sign decides) -- 2^-20 |T| here, which also covers these sums' own
+        // rounding.  {G: greater, L: smaller, EL / EH: equal}; non-finite thresholds (nothing can be greater / smaller) stay.
+        const float2 t2 = a.b.qt[okq ? q0 + tid : a.n - 1];
+        const float s1 = isfinite(t2.x) ? 0x1p-20f * fabsf(t2.x) : 0.f, s2 = isfinite(t2.y) ? 0x1p-20f * fabsf(t2.y) : 0.f;
+        qt_s[tid] = make_float4(t2.y + s2, t2.x - s1, t2.x + s1, t2.y - s2);
     }
     // outputs of rows beyond n (per lane: bits 2 r, 2 r + 1 of its 16 rows) and, per tile, of candidates beyond the range are
     // cleared from the undecided mask; they cannot be counted either (see the -inf bias below)
@@ -385,27 +394,38 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
             // Undecided outputs are only MARKED here (bit 2 r + ni of a per-lane mask); the appends to the recheck list happen once
             // per tile behind the loop: one atomic per wave instead of a ballot, a branch and an atomic per output.
             uint32_t undm = 0u;
-#pragma unroll 8
-            for (int r = 0; r < 16; ++r) {
-                asm volatile("" ::: "memory");   // (the row metas are read here, not hoisted for all 16 rows at once)
-                const int row = wq + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float4 qm = qm_s[row];
-                const float2 qt = qt_s[row];
+            {
+                // Fully unrolled over the lane's 16 rows, the two candidate columns of a row as packed fp32 pairs
+                // (v_pk_fma / mul / add_f32), the next row's constants requested before this row's arithmetic; a scheduling
+                // barrier per row keeps the compare masks (SGPR pairs) of one row from piling up behind those of all sixteen.
+                const float4 E0 = em_s[l31], E1 = em_s[32 + l31];   // {B, |W e|_2 (infinite: inf / NaN row, candidate beyond the range), |e|_1 / 2, -}
+                const f32x2 B2 = {E0.x, E1.x}, Y2 = {E0.y, E1.y}, Z2 = {E0.z, E1.z};
+                const int row0 = wq + 4 * lh;
+                float4 qm = qm_s[row0], qt = qt_s[row0];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const float4 em = em_s[ni * 32 + l31];   // {B, |W e|_2 (infinite: row with inf / NaN, candidate beyond the range), |e|_1 / 2, -}
+                for (int r = 0; r < 16; ++r) {
+                    float4 qm_n = qm, qt_n = qt;
+                    if (r < 15) { const int rn = row0 + ((r + 1) & 3) + 8 * ((r + 1) >> 2); qm_n = qm_s[rn]; qt_n = qt_s[rn]; }
                     // S~ = (L0 2^16 + L1 2^8 + L2) 2^16 A B
-                    const float f = fmaf((float)acc[0][ni][r], 65536.f, fmaf((float)acc[1][ni][r], 256.f, (float)acc[2][ni][r]));
-                    const float s0 = f * (qm.x * em.x);
-                    // E = c (gamma |W q|_2 |W e|_2 + A |e|_1 / 2 + B (|q|_1 / 2 + drop A)) + 2^-20 |S~|
-                    const float e = fmaf(0x1p-20f, fabsf(s0), fmaf(qm.y, em.y, fmaf(qm.z, em.z, qm.w * em.x)));
-                    // greater: S~ - E >= T_gt;  smaller: S~ + E < T_ge;  equal after quantisation: [S~ - E, S~ + E] inside
-                    // [T_ge, T_gt) -- the quantisation bins are wide enough for that to settle a third of the near-ties
-                    const float lo = s0 - e, hi = s0 + e;
-                    const bool gt = lo >= qt.y, lt = hi < qt.x, eq = (lo >= qt.x) && (hi < qt.y);
-                    cnt[r] += gt ? 1 : 0;
-                    cnt[r] += eq ? 0x10000 : 0;
-                    undm |= !(gt || lt || eq) ? (1u << (2 * r + ni)) : 0u;   // (NaN / infinite bounds compare false everywhere: undecided)
+                    const f32x2 c0 = {(float)acc[0][0][r], (float)acc[0][1][r]}, c1 = {(float)acc[1][0][r], (float)acc[1][1][r]},
+                                c2 = {(float)acc[2][0][r], (float)acc[2][1][r]};
+                    const f32x2 f = __builtin_elementwise_fma(c0, f32x2{65536.f, 65536.f}, __builtin_elementwise_fma(c1, f32x2{256.f, 256.f}, c2));
+                    const f32x2 s0 = f * (f32x2{qm.x, qm.x} * B2);
+                    // E' = c (gamma |W q|_2 |W e|_2 + A |e|_1 / 2 + B (|q|_1 / 2 + drop A)); the term relative to |S~| sits in the thresholds
+                    const f32x2 e = __builtin_elementwise_fma(f32x2{qm.y, qm.y}, Y2, __builtin_elementwise_fma(f32x2{qm.z, qm.z}, Z2, f32x2{qm.w, qm.w} * B2));
+                    const f32x2 lo = s0 - e, hi = s0 + e;
+                    // greater: lo >= G;  smaller: hi < L;  equal after quantisation: lo >= EL and hi < EH (the quantisation bins are
+                    // wide enough for that to settle a third of the near-ties)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const bool gt = lo[ni] >= qt.x, lt = hi[ni] < qt.y, eq = (lo[ni] >= qt.z) && (hi[ni] < qt.w);
+                        cnt[r] += gt ? 1 : 0;
+                        cnt[r] += eq ? 0x10000 : 0;
+                        undm |= !(gt || lt || eq) ? (1u << (2 * r + ni)) : 0u;   // (NaN / infinite bounds compare false everywhere: undecided)
+                    }
+                    asm volatile("" : "+v"(cnt[r]), "+v"(undm));   // (the counts are formed HERE: left to itself the compiler keeps all 64 compare masks for later)
+                    qm = qm_n; qt = qt_n;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             undm &= rowmask;

@@ -14,6 +14,9 @@ def _as_labels(a):
     return a
 
 
+_LUTS = {}   # id(sorted key array) -> (the array, its ids, dense lookup table): see DataIndexer._lookup
+
+
 try:   # hash-based first-seen numbering / lookups for text labels (the reference depends on pandas as well); numpy otherwise
     import pandas as _pd
 except Exception:   # pragma: no cover
@@ -67,11 +70,22 @@ class DataIndexer:
             order = np.argsort(sorted_keys)
             sorted_keys, ids = sorted_keys[order], ids[order]
         if sorted_keys.dtype.kind in "iu" and q.dtype.kind in "iu" and sorted_keys.size:
-            # dense integer labels: direct lookup table instead of a binary search per key (13x faster on 816 k lookups)
+            # dense integer labels: direct lookup table instead of a binary search per key (13x faster on 816 k lookups); the
+            # table is kept with the key array it was made from (evaluate() maps three filter datasets x three columns per call)
             lo, hi = int(sorted_keys[0]), int(sorted_keys[-1])
             if hi - lo < 8 * sorted_keys.size + 1024:
-                lut = np.full(hi - lo + 1, -1, dtype=np.int32)
-                lut[sorted_keys.astype(np.int64) - lo] = ids
+                hit = _LUTS.get(id(sorted_keys))
+                if hit is not None and hit[0] is sorted_keys and hit[1] is ids:
+                    lut = hit[2]
+                else:
+                    lut = np.full(hi - lo + 1, -1, dtype=np.int32)
+                    lut[sorted_keys.astype(np.int64) - lo] = ids
+                    if len(_LUTS) > 64:
+                        _LUTS.clear()
+                    _LUTS[id(sorted_keys)] = (sorted_keys, ids, lut)
+                if q.size and int(q.min()) >= lo and int(q.max()) <= hi:   # every key inside the table: one gather
+                    out = lut[q - lo] if lo else lut[q]
+                    return out, out >= 0
                 qq = q.astype(np.int64) - lo
                 inside = (qq >= 0) & (qq <= hi - lo)
                 out = np.where(inside, lut[np.clip(qq, 0, hi - lo)], -1).astype(np.int32)
@@ -96,9 +110,10 @@ class DataIndexer:
                 p, okp = self._lookup(self._rel_sorted, self._rel_ids, X[:, 1])
                 o, oko = self._lookup(self._ent_sorted, self._ent_ids, X[:, 2])
                 ok = oks & okp & oko
+                if ok.all():
+                    return np.stack([s, p, o], 1).astype(np.int32, copy=False)
                 bad = int((~ok).sum())
-                if bad:
-                    print(f"\n{bad} triples containing invalid keys skipped!\n")
+                print(f"\n{bad} triples containing invalid keys skipped!\n")
                 return np.stack([s[ok], p[ok], o[ok]], 1).astype(np.int32)
             X = X.astype(np.int64)
             return np.stack([self._ent_raw[X[:, 0]], self._rel_raw[X[:, 1]], self._ent_raw[X[:, 2]]], 1)
