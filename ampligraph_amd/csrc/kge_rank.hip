@@ -927,7 +927,58 @@ struct FilterArgs {
     int64_t ent_lo, ent_hi;
     RankGeom g;
     float sgn_scale;
+    const int* guard;    // non-NULL: run only if *guard != 0 (the pair list of the contraction models' filter pass overflowed)
 };
+
+// Filter pass, contraction models: the (query, known positive) pairs as a flat list for rank_recheck_kernel<true> -- 64 pairs
+// per wave with coalesced row fetches, instead of one wave per query whose lanes each walk a whole row 16 bytes at a time
+// (at C2 a query has 1.1 known positives on average: 63 idle lanes, 100 dependent load steps: 150 us).  A block takes 256
+// queries, scans their list lengths, reserves its run of the list with ONE atomic and writes it cooperatively (pair j of the
+// block: its query by binary search in the scanned offsets), so a query with thousands of known positives is no slower than
+// thousands of queries with one.  An id outside the candidate set is listed as (query, -1).
+__global__ __launch_bounds__(256) void filter_pairs_kernel(FilterArgs a, int2* __restrict__ pairs, int* __restrict__ counter, int64_t cap) {
+    __shared__ long long off_s[257];
+    __shared__ long long lo_s[256];
+    __shared__ long long base_s;
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    long long lo = 0, c = 0;
+    if (i < a.n) { lo = a.flt_lo[i]; c = a.flt_hi[i] - lo; if (c < 0) c = 0; }
+    lo_s[tid] = lo;
+    off_s[tid + 1] = c;
+    if (tid == 0) off_s[0] = 0;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {   // inclusive scan of the 256 lengths (off_s[1..256])
+        const long long v = (tid >= o) ? off_s[tid + 1 - o] : 0;
+        __syncthreads();
+        off_s[tid + 1] += v;
+        __syncthreads();
+    }
+    const long long total = off_s[256];
+    if (tid == 0) {
+        long long b = -1;
+        if (total > 0 && total <= cap) b = (long long)atomicAdd(counter, (int)total);
+        if (total > cap || (b >= 0 && b + total > cap)) { counter[1] = 1; b = -1; }
+        base_s = b;
+    }
+    __syncthreads();
+    const long long base = base_s;
+    if (base < 0) return;
+    for (long long j = tid; j < total; j += 256) {
+        int x = 0, y = 256;   // the query q with off_s[q] <= j < off_s[q + 1]
+        while (y - x > 1) { const int mid = (x + y) >> 1; if (off_s[mid] <= j) x = mid; else y = mid; }
+        const int64_t q = (int64_t)blockIdx.x * 256 + x;
+        int64_t id = (int64_t)a.flt_ids[lo_s[x] + (j - off_s[x])];
+        bool ok;
+        if (a.subset_pos) {   // mapping_dict.lookup + drop -1 (AbstractScoringLayer.py:266-275)
+            const int pos = a.subset_pos[id];
+            ok = pos >= 0 && pos >= a.ent_lo && pos < a.ent_hi;
+        } else {
+            ok = id >= a.ent_lo && id < a.ent_hi;   // partition rule :280-288
+        }
+        pairs[base + j] = make_int2((int)q, ok ? (int)id : -1);
+    }
+}
 
 // One unit of RotatE's exact-mode chain for ONE (query, entity) pair: the operations of rot_micro, scalar (sqrt_rn == the
 // packed sequence inside its domain, libm's sqrtf outside: bitwise the tile kernel's value either way).
@@ -945,6 +996,7 @@ __global__ __launch_bounds__(256) void rank_filter_kernel(FilterArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.n) return;
+    if (a.guard && *a.guard == 0) return;
     const int64_t lo = a.flt_lo[i], hi = a.flt_hi[i];
     const float* qrow = a.Q + i * (int64_t)a.g.QW;
     const int qp = a.qpos[i];
@@ -1049,7 +1101,13 @@ static inline char* align_up(char* p, size_t a) { return (char*)(((uintptr_t)p +
 struct Workspace {
     float* Q;
     int* qpos;
+    int* flt_counter;    // filter pass, contraction models: [0] pairs listed, [1] overflow flag
+    int2* flt_pairs;     // (query, table row of a known positive)
+    int64_t flt_cap;
 };
+
+static int64_t query_row_floats(const amdkge_model* m) { return (m->scoring_type == AMDKGE_ROTATE) ? 4ll * stored_k(m) : row_floats(m); }
+static int64_t filter_pair_cap(int64_t n) { return n * 64 > 65536 ? n * 64 : 65536; }   // 64 known positives per query on average
 
 static Workspace carve(void* d_work, const amdkge_model* m, int64_t n) {
     Workspace w;
@@ -1057,6 +1115,10 @@ static Workspace carve(void* d_work, const amdkge_model* m, int64_t n) {
     w.qpos = (int*)p;
     p = align_up(p + n * sizeof(int), 256);
     w.Q = (float*)p;
+    p = align_up(p + n * query_row_floats(m) * sizeof(float), 256);
+    w.flt_counter = (int*)p;
+    w.flt_pairs = (int2*)(p + 256);
+    w.flt_cap = filter_pair_cap(n);
     return w;
 }
 
@@ -1123,11 +1185,11 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     ra.sgn_scale = sgn_scale; ra.b = b;
     static bool rck_attr = false;
     if (!rck_attr) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)rank_recheck_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCK_LDS_BYTES))
+        if (hipError_t e = hipFuncSetAttribute((const void*)rank_recheck_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCK_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_recheck)");
         rck_attr = true;
     }
-    hipLaunchKernelGGL(rank_recheck_kernel, dim3(1024), dim3(256), RCK_LDS_BYTES, st, ra);
+    hipLaunchKernelGGL(rank_recheck_kernel<false>, dim3(1024), dim3(256), RCK_LDS_BYTES, st, ra);
     if (int rc = check_launch("rank_recheck")) return rc;
     hipLaunchKernelGGL(rank_screen_merge_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, st, b, n, d_counts);
     return check_launch("rank_screen_merge");
@@ -1152,8 +1214,7 @@ extern "C" int amdkge_set_rank_rotate_fast(int fast) {
 
 extern "C" int64_t amdkge_rank_workspace_bytes(const amdkge_model* m, int64_t n) {
     if (validate_model(m) != AMDKGE_OK || n < 0) return -1;
-    const int64_t qw = (m->scoring_type == AMDKGE_ROTATE) ? 4ll * stored_k(m) : row_floats(m);
-    return 1024 + ((n * 4 + 255) / 256) * 256 + n * qw * 4;
+    return 1024 + ((n * 4 + 255) / 256) * 256 + n * query_row_floats(m) * 4 + 512 + filter_pair_cap(n) * 8;
 }
 
 static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const float* d_rel, const int32_t* d_triples,
@@ -1336,6 +1397,27 @@ extern "C" int amdkge_rank_filter(const amdkge_model* m, const float* d_ent, con
         if (mode == MODE_ROT_S) hipLaunchKernelGGL((rank_filter_kernel<MODE_ROT_S, true, true>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((rank_filter_kernel<MODE_ROT_O, true, true>), dim3(grid), dim3(256), 0, st, a);
         return check_launch("rank_filter_rot");
+    }
+    if (mode == MODE_DOT && v4 && g_rank_kernel == 0) {   // (a forced count kernel, amdkge_set_rank_kernel, also keeps round 2's filter pass)
+        // contraction models: flat pair list + the coalesced exact-chain kernel; the one-wave-per-query kernel behind it runs
+        // only if the list overflowed (device-side flag, no host round trip)
+        if (hipError_t e = hipMemsetAsync(w.flt_counter, 0, 8, st)) return set_error_hip(e, "hipMemsetAsync(filter pair counter)");
+        hipLaunchKernelGGL(filter_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, w.flt_pairs, w.flt_counter, w.flt_cap);
+        if (int rc = check_launch("filter_pairs")) return rc;
+        RecheckArgs ra{};
+        ra.ent = d_ent; ra.Q = w.Q; ra.qpos = w.qpos; ra.ent_ids = nullptr; ra.ent_lo = 0; ra.U = g.U; ra.K = g.K; ra.QW = g.QW;
+        ra.sgn_scale = a.sgn_scale;
+        ra.b.counter = w.flt_counter; ra.b.pairs = w.flt_pairs; ra.b.cap = w.flt_cap; ra.b.counts = d_sub;
+        static bool flt_attr = false;
+        if (!flt_attr) {
+            if (hipError_t e = hipFuncSetAttribute((const void*)rank_recheck_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCK_LDS_BYTES))
+                return set_error_hip(e, "hipFuncSetAttribute(rank_recheck<filter>)");
+            flt_attr = true;
+        }
+        const int64_t groups = (w.flt_cap + 63) / 64;
+        hipLaunchKernelGGL(rank_recheck_kernel<true>, dim3((unsigned)(groups / 4 < 1024 ? (groups + 3) / 4 : 1024)), dim3(256), RCK_LDS_BYTES, st, ra);
+        if (int rc = check_launch("rank_filter_pairs")) return rc;
+        a.guard = w.flt_counter + 1;
     }
 #define KGE_FLT(MODE) do { if (v4) hipLaunchKernelGGL((rank_filter_kernel<MODE, true>), dim3(grid), dim3(256), 0, st, a); \
                            else hipLaunchKernelGGL((rank_filter_kernel<MODE, false>), dim3(grid), dim3(256), 0, st, a); } while (0)

@@ -491,20 +491,26 @@ constexpr int RCK_CH = 32;                 // units per chunk
 constexpr int RCK_LD = RCK_CH + 4;         // LDS row stride in floats
 constexpr size_t RCK_LDS_BYTES = (size_t)4 * 2 * 64 * RCK_LD * sizeof(float);   // 4 waves x (Q, E) x 64 rows
 
+// FILTER = true: the same chain for the FILTER pass of get_ranks (amdkge_rank_filter, contraction models): the pairs are (query,
+// known positive's table row) from filter_pairs_kernel ((q, -1): an id outside the candidate set), the outcome "the filtered
+// entity scores at least the positive" is subtracted -- b.counts is the caller's `sub` array there, one int per query.
+template <bool FILTER>
 __global__ __launch_bounds__(256) void rank_recheck_kernel(RecheckArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_rck[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float* Qb = reinterpret_cast<float*>(smem_rck) + (size_t)wv * 2 * 64 * RCK_LD;
     float* Eb = Qb + 64 * RCK_LD;
+    if (FILTER && a.b.counter[1]) return;   // the pair list overflowed: rank_filter_kernel does the whole pass
     const int64_t npairs = min((int64_t)a.b.counter[0], a.b.cap);
     const int64_t ngroups = (npairs + 63) / 64;
     const int lrow = lane >> 3, lpc = lane & 7;   // loader: 8 rows per instruction, 8 16-byte pieces per row chunk
     for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
         const int64_t p = grp * 64 + lane;
-        const bool have = p < npairs;
-        const int2 pr = a.b.pairs[have ? p : npairs - 1];
-        const int64_t pos = a.ent_lo + pr.y;
-        const int64_t qoff = (int64_t)pr.x * a.QW, eoff = (a.ent_ids ? (int64_t)a.ent_ids[pos] : pos) * a.K;
+        bool have = p < npairs;
+        int2 pr = a.b.pairs[have ? p : npairs - 1];
+        if (FILTER && pr.y < 0) { have = false; pr.y = 0; }
+        const int64_t pos = FILTER ? (int64_t)pr.y : a.ent_lo + pr.y;
+        const int64_t qoff = (int64_t)pr.x * a.QW, eoff = (!FILTER && a.ent_ids ? (int64_t)a.ent_ids[pos] : pos) * a.K;
         float acc = 0.f;
         for (int u0 = 0; u0 < a.U; u0 += RCK_CH) {
             // rows 8 i + lrow of this wave's 64 pairs: their offsets come from the lanes that own them
@@ -537,8 +543,12 @@ __global__ __launch_bounds__(256) void rank_recheck_kernel(RecheckArgs a) {
         }
         if (have) {
             const int qs = quantise(a.sgn_scale * acc), qp = a.qpos[pr.x];
-            if (qp < qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 0], 1);
-            else if (qp == qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 1], 1);
+            if constexpr (FILTER) {
+                if (qp <= qs) atomicAdd(&a.b.counts[pr.x], 1);   // always <=, whatever the tie strategy (AbstractScoringLayer.py:292-307)
+            } else {
+                if (qp < qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 0], 1);
+                else if (qp == qs) atomicAdd(&a.b.counts[2 * (int64_t)pr.x + 1], 1);
+            }
         }
     }
 }
