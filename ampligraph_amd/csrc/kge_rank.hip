@@ -1163,11 +1163,25 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     // A B; + 2^25: the fp32 reconstruction of the 40-bit integer sum in the epilogue (inner sum rounds by <= 2^8 in units of 2^16 A B)
     sa.drop = (float)(((double)g.U * (8388608.0 + 16384.0 + 0.25) + 33554432.0) * (1.0 + 1e-6));
     const int64_t qtiles = (n + SCR_Q - 1) / SCR_Q, etiles = (mcand + SCR_ET - 1) / SCR_ET;
-    // two workgroups per CU: ~8 rounds of blocks, each block a run of entity tiles (its query fragments stay in L1 / L2)
-    int64_t tiles_per = (qtiles * etiles + 16 * 256 - 1) / (16 * 256);
-    if (tiles_per < 1) tiles_per = 1;
-    if (tiles_per > 16384) tiles_per = 16384;   // (a lane's packed 16-bit counters see 2 candidates per tile)
-    if (tiles_per > etiles) tiles_per = etiles;
+    // Each block takes a run of entity tiles of one 128-query block (its query fragments stay in L1 / L2); two workgroups per CU,
+    // 256 CUs.  The run length is the one with the shortest schedule: rounds of 512 co-resident blocks x (tiles + ~0.35 of a
+    // tile for a block's start-up) -- at C2 (160 x 227 tiles) runs of 9 gave 8.1 rounds, i.e. a ninth round for an eighth of the
+    // chip; runs of 4 give 17.8 -> 18 rounds of 4: 78 tile-times instead of 84.
+    int64_t tiles_per = 1;
+    {
+        const int64_t qt8 = 8 * ((qtiles + 7) / 8), lim = etiles < 64 ? etiles : 64;
+        double best = 1e300;
+        for (int64_t tp = 1; tp <= lim; ++tp) {
+            const int64_t blocks = qt8 * ((etiles + tp - 1) / tp);
+            const double cost = (double)((blocks + 511) / 512) * ((double)tp + 0.35);
+            if (cost <= best) { best = cost; tiles_per = tp; }   // (ties: the longer run)
+        }
+        // very large problems: keep the launch below 2^31 blocks and a lane's packed 16-bit counters (2 candidates per tile) in range
+        while (tiles_per < etiles && tiles_per < 16384 && qt8 * ((etiles + tiles_per - 1) / tiles_per) > (1ll << 24)) tiles_per *= 2;
+        if (tiles_per > 16384) tiles_per = 16384;
+        if (tiles_per > etiles) tiles_per = etiles;
+        if (tiles_per < 1) tiles_per = 1;
+    }
     const int64_t splits = (etiles + tiles_per - 1) / tiles_per;
     sa.ent_per_block = (int)(tiles_per * SCR_ET); sa.qtiles = (int)qtiles; sa.splits = (int)splits;
     const int64_t nblk = 8 * ((qtiles + 7) / 8) * splits;
