@@ -1107,7 +1107,10 @@ struct Workspace {
 };
 
 static int64_t query_row_floats(const amdkge_model* m) { return (m->scoring_type == AMDKGE_ROTATE) ? 4ll * stored_k(m) : row_floats(m); }
-static int64_t filter_pair_cap(int64_t n) { return n * 64 > 65536 ? n * 64 : 65536; }   // 64 known positives per query on average
+static int64_t filter_pair_cap(int64_t n) {   // 64 known positives per query on average; the list counter is an int32
+    const int64_t c = n * 64 > 65536 ? n * 64 : 65536;
+    return c < (1ll << 30) ? c : (1ll << 30);
+}
 
 static Workspace carve(void* d_work, const amdkge_model* m, int64_t n) {
     Workspace w;
