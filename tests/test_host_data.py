@@ -245,3 +245,27 @@ def test_indexer_hash_path_equals_sort_path(monkeypatch):
     assert np.array_equal(ia, b.get_indexes(Q)) and np.array_equal(ma, b.valid_row_mask(Q))
     # the reference's rule on its own docstring-sized example: ids in order of first appearance, subject before object
     assert list(a.get_indexes(X[:1])[0]) == [0, 0, 1 if X[0, 0] != X[0, 2] else 0]
+
+
+def test_integer_label_lookup_table_cache():
+    """Dense integer labels go through a cached lookup table (evaluate() maps three filter datasets per call): same ids as the
+    binary search, unknown / negative / out-of-range keys drop the row, and two indexers do not share a table."""
+    from ampligraph_amd.datasets.indexer import DataIndexer
+
+    rng = np.random.default_rng(0)
+    X = np.stack([rng.integers(100, 600, 5000), rng.integers(0, 7, 5000), rng.integers(100, 600, 5000)], 1).astype(np.int32)
+    ix = DataIndexer(X)
+    ref = DataIndexer(X.astype(str))                         # text labels: the hash / binary-search path
+    q = X[rng.permutation(5000)[:800]]
+    assert np.array_equal(ix.get_indexes(q), ref.get_indexes(q.astype(str)))
+    assert np.array_equal(ix.get_indexes(q), ix.get_indexes(q))           # second call: cached table
+    bad = q.copy()
+    bad[3, 0], bad[10, 2], bad[20, 1], bad[30, 0] = 10 ** 6, -5, 99, 99    # above, below, unknown relation, inside the span but unseen?
+    seen = set(X[:, 0]) | set(X[:, 2])
+    keep = np.array([(r[0] in seen) and (r[2] in seen) and (0 <= r[1] < 7) for r in bad])
+    out = ix.get_indexes(bad)
+    assert out.shape[0] == int(keep.sum()) and np.array_equal(out, ix.get_indexes(bad[keep]))
+    other = DataIndexer(X[::-1].copy())                      # different first-seen order: different ids, its own table
+    assert not np.array_equal(other.get_indexes(q), ix.get_indexes(q))
+    assert np.array_equal(other.get_indexes(q), DataIndexer(X[::-1].astype(str)).get_indexes(q.astype(str)))
+    assert ix.get_indexes(q[:0]).shape == (0, 3)
