@@ -96,6 +96,10 @@ class StepLoop:
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
+        # the multi-rank form of the step (gradient-only kernels + merge through the collectives).  AMDKGE_FORCE_DIST=1 takes it
+        # with a process group of ONE rank too: every collective of the merge then really goes through the backend (RCCL on a GPU)
+        # -- the first-contact run a one-GPU box allows (bench.py AMDKGE_BENCH_FORCE_DIST, tests/test_dp_gloo.py)
+        self.multi = self.world > 1 or (dist is not None and os.environ.get("AMDKGE_FORCE_DIST", "0") == "1")
         if merge is None:
             merge = os.environ.get("AMDKGE_DP_MERGE", "sharded")
         # "auto": start with the sharded merge and let the caller run tune_merge() on the first steps (fit() does)
@@ -122,7 +126,7 @@ class StepLoop:
         engine.prepare_training(optimizer.name)
         if hasattr(optimizer, "bind"):
             optimizer.bind(engine)   # get_weights() / set_weights() of the wrapper read and write the engine's state tensors
-        if self.merge == "sharded" and self.world > 1 and int(engine.g_flat.numel()) % self.world != 0:
+        if self.merge == "sharded" and self.multi and int(engine.g_flat.numel()) % self.world != 0:
             self.merge = "allreduce"   # the flat buffers split evenly over 1, 2, 4, 8, 16 ranks; other counts all-reduce
 
     def configure_for_data(self, triples, batch_size):
@@ -170,20 +174,20 @@ class StepLoop:
             self.kernel_hook(0)
         if tiled:
             eng.train_step_tiled(global_batch[lo:hi], self.eta, self.loss_ffi, opt_ffi, self.seed, rng_step,
-                                 reg_e=lam, reg_r=lam_r, row_offset=lo, b_global=bg, grad_only=self.world > 1,
+                                 reg_e=lam, reg_r=lam_r, row_offset=lo, b_global=bg, grad_only=self.multi,
                                  pos_atomic=self.pos_atomic, **({"deterministic": True} if self.deterministic else {}))
         elif hi > lo:
             eng.train_fwdbwd(global_batch[lo:hi], self.eta, self.loss_ffi, self.seed, rng_step,
                              row_offset=lo, b_global=bg)
         if self.kernel_hook is not None:
             self.kernel_hook(1)
-        if self.world > 1 and self.merge == "sharded":
+        if self.multi and self.merge == "sharded":
             self._merge_sharded(opt_ffi, lam, lam_r)
         else:
-            if self.world > 1:
+            if self.multi:
                 for g in eng.grad_tensors():
                     self.dist.all_reduce(g)
-            if not (tiled and self.world == 1):   # the single-GPU owner-computes call is the complete step
+            if not (tiled and not self.multi):   # the single-GPU owner-computes call is the complete step
                 eng.opt_step(opt_ffi, lam, lam_r)
         if self.kernel_hook is not None:
             self.kernel_hook(2)
@@ -232,7 +236,7 @@ class StepLoop:
                 if q != r:
                     ops.append(self.dist.P2POp(self.dist.isend, mine, q))
                     ops.append(self.dist.P2POp(self.dist.irecv, flat[q * chunk:(q + 1) * chunk], q))
-            for req in self.dist.batch_isend_irecv(ops):
+            for req in (self.dist.batch_isend_irecv(ops) if ops else ()):   # (a group of one rank has nobody to send to)
                 req.wait()
         else:
             self.dist.all_gather_into_tensor(flat, mine)
@@ -252,7 +256,7 @@ class StepLoop:
         import torch
 
         self.merge_report = None
-        if self.world == 1 or not hasattr(self.engine, "opt_step_flat") or int(self.engine.g_flat.numel()) % self.world:
+        if not self.multi or not hasattr(self.engine, "opt_step_flat") or int(self.engine.g_flat.numel()) % self.world:
             return 0
         backend = getattr(self.dist, "get_backend", lambda: "")()
         cands = [("allreduce", self.collectives), ("sharded", "alltoall"), ("sharded", "alltoall+allgather")]
@@ -280,7 +284,7 @@ class StepLoop:
                         if q != self.rank:
                             ops.append(self.dist.P2POp(self.dist.isend, b[self.rank * 4:(self.rank + 1) * 4], q))
                             ops.append(self.dist.P2POp(self.dist.irecv, b[q * 4:(q + 1) * 4], q))
-                    for req in self.dist.batch_isend_irecv(ops):
+                    for req in (self.dist.batch_isend_irecv(ops) if ops else ()):
                         req.wait()
             except RuntimeError:
                 return False
@@ -317,7 +321,7 @@ class StepLoop:
     def sync_optimizer_slots(self):
         """Sharded merge: every rank only maintains ITS slice of the optimizer slots.  Before a checkpoint is written
         the slices are exchanged so that any rank holds the complete m / v / accumulator tables."""
-        if self.world == 1 or self.merge != "sharded":
+        if not self.multi or self.merge != "sharded":
             return
         W, r = self.world, self.rank
         for fl in self.engine.slot_flat.values():
@@ -340,11 +344,11 @@ class StepLoop:
             raise RuntimeError("deterministic mode: a tile received more entries than its sort buffer holds (very hot rows); "
                                "this epoch's sums were not all added in canonical order")
         acc = self.engine.loss_acc.clone()
-        if self.world > 1 and self.merge == "sharded":
+        if self.multi and self.merge == "sharded":
             both = acc[0:2].clone()
             self.dist.all_reduce(both)
             acc[0], acc[1] = both[0], both[1]
-        elif self.world > 1:
+        elif self.multi:
             data = acc[0:1].clone()
             self.dist.all_reduce(data)
             acc[0] = data[0]

@@ -40,3 +40,36 @@ def planted_kg(model="ComplEx", n_ents=300, n_rels=6, k_true=6, per_pair=3, n_te
     mask = np.zeros(len(tri), dtype=bool)
     mask[test_idx] = True
     return {"train": tri[~mask], "test": tri[mask], "n_ents": n_ents, "n_rels": n_rels}
+
+
+# ---- the learning-parity schedule of tests/test_gpu_learning.py, replayed by the oracle (CPU) ---------------------------------
+LEARNING = dict(epochs=40, batch=1024, eta=5, k=16, lr=2e-2)
+
+
+def oracle_learning_run(model, loss, seed, epochs=None):
+    """The oracle's replay of test_gpu_learning's schedule on planted_kg(model, seed): Glorot tables drawn as the drop-in
+    class draws them, Adam, `epochs` passes in sequential batches -> (loss history, filtered ranks (n_test, 2), state)."""
+    from oracle import kge_oracle as O
+
+    from ampligraph_amd.latent_features.initializers import initialise
+
+    cfg = LEARNING
+    d = planted_kg(model, seed=seed)
+    train, test = d["train"].astype(str), d["test"].astype(str)
+    ents, rels = O.first_seen_index(train)
+    Xi = O.to_indexes(train, ents, rels)
+    N, R, K = len(ents), len(rels), O.internal_k(model, cfg["k"])
+    rng = np.random.Generator(np.random.PCG64(seed))
+    st = O.TrainState(initialise("glorot_uniform", (N, K), rng), initialise("glorot_uniform", (R, K), rng), "adam", cfg["lr"])
+    steps = (len(Xi) + cfg["batch"] - 1) // cfg["batch"]
+    hist = []
+    for ep in range(cfg["epochs"] if epochs is None else epochs):
+        tot = 0.0
+        for s in range(steps):
+            tot += float(O.train_step(st, model, Xi[s * cfg["batch"]:(s + 1) * cfg["batch"]], cfg["eta"], loss, seed,
+                                      ep * steps + s, max_rel_size=R))
+        hist.append(tot / steps)
+    ti = O.to_indexes(test, ents, rels)
+    fs, fo = O.filter_sets(ti, [Xi, ti])
+    ranks = O.evaluate_ranks(model, st.ent, st.rel, ti, fs, fo, "s,o", "worst", max_rel_size=R)
+    return np.asarray(hist), ranks, st

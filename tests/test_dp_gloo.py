@@ -103,6 +103,52 @@ def test_two_ranks_equal_one_rank(tmp_path, tiled, flat):
     assert (calls[:, 1] == 0).all() and set(calls[:, 2]) == {37, 27} and set(calls[:, 0]) == {18, 13}
 
 
+def _run_forced(rank, port, out, flat, tune):
+    """A process group of ONE rank with AMDKGE_FORCE_DIST=1: the multi-rank form of the step (gradient-only kernels + merge
+    through the collectives) -- what `AMDKGE_BENCH_FORCE_DIST=1 bench.py` runs through RCCL on a one-GPU box."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["AMDKGE_FORCE_DIST"] = "1"
+    from oracle_backend import OracleEngine
+
+    from ampligraph_amd.latent_features import loss_functions, optimizers, regularizers
+    from ampligraph_amd.trainer import StepLoop
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    ent, rel, X, k = _problem()
+    eng = OracleEngine("ComplEx", k, ent, rel, tiled=True, flat=flat)
+    loop = StepLoop(eng, 3, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}),
+                    regularizers.get("LP", {"p": 2, "lambda": 1e-3}), seed=5, dist=dist)
+    assert loop.multi and loop.world == 1 and loop.merge == ("sharded" if flat else "allreduce")
+    Xt = torch.as_tensor(X)
+    bs = 37
+    if tune:   # every schedule, measured: each must carry out the same update
+        used = loop.tune_merge(lambda st: Xt[(st % 3) * bs:(st % 3) * bs + bs], 0, trials=1)
+        assert used == 6 and loop.merge_report is not None and all(v is not None for v in loop.merge_report.values()), loop.merge_report
+    else:
+        loop.reset_loss()
+        step = 0
+        for ep in range(2):
+            for b0 in range(0, X.shape[0], bs):
+                loop.step(Xt[b0:b0 + bs], step)
+                step += 1
+        assert (eng.flat_sweeps > 0) == flat
+        np.savez(out, ent=eng.state.ent, rel=eng.state.rel, loss=loop.mean_batch_loss())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_forced_single_rank_group_equals_plain_run(tmp_path, flat):
+    single, forced = str(tmp_path / "single.npz"), str(tmp_path / "forced.npz")
+    _run(1, 0, 0, single, True)
+    mp.spawn(_run_forced, args=(_free_port(), forced, flat, False), nprocs=1, join=True)
+    a, b = np.load(single), np.load(forced)
+    assert np.abs(a["ent"] - b["ent"]).max() < 5e-6 and np.abs(a["rel"] - b["rel"]).max() < 5e-6
+    assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5 * abs(float(a["loss"]))
+    mp.spawn(_run_forced, args=(_free_port(), forced, True, True), nprocs=1, join=True)   # tune_merge over a group of one
+
+
 def _run_spawn(rank, world, port, out, tiled=False, flat=False, opt=("adam", {})):
     _run(world, rank, port, out, tiled, flat, opt)
 

@@ -26,6 +26,22 @@ def test_oracle_reproduces_golden_bitwise():
         assert np.array_equal(np.asarray(fresh[k]), G[k]), k
 
 
+@pytest.mark.parametrize("model,loss,seed", [("TransE", "nll", 5), ("TransE", "pairwise", 63), ("RotatE", "self_adversarial", 40),
+                                             ("RotatE", "nll", 383)])
+def test_oracle_reproduces_learning_golden(model, loss, seed):
+    """tests/golden/learning_mrr_v1.npz (the oracle's side of test_gpu_learning's many-seed MRR test): a sample re-derived."""
+    import sys
+
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_learning_golden
+
+    L = np.load(os.path.join(HERE, "golden", "learning_mrr_v1.npz"))
+    assert {f"{m}/{ls}": n for m, ls, n in make_learning_golden.CASES} == {k: len(L[k]) for k in L.files}
+    got = make_learning_golden.one((model, loss, seed))
+    assert np.array_equal(np.asarray(got, dtype=np.float64), L[f"{model}/{loss}"][seed]), (got, L[f"{model}/{loss}"][seed])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("model", MODELS)
 def test_hip_path_against_golden(gpu_lib, model):
