@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AMDKGE_LIB") or os.path.join(_HERE, "lib", "libamdkge.so")   # AMDKGE_LIB: development builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enums of include/amdkge.h
 SCORING_TYPES = {"TransE": 0, "DistMult": 1, "ComplEx": 2, "HolE": 3, "RotatE": 4}
@@ -73,6 +73,7 @@ U64 = C.c_uint64
 # name -> (restype, argtypes): every symbol include/amdkge.h declares
 SIGNATURES = {
     "amdkge_abi_version": (C.c_int, []),
+    "amdkge_release_scratch": (C.c_int, []),
     "amdkge_last_error": (C.c_char_p, []),
     "amdkge_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "amdkge_set_device": (C.c_int, [C.c_int]),
@@ -131,6 +132,9 @@ SIGNATURES = {
     "amdkge_session_score": (C.c_int, [P, P, I64, P]),
     "amdkge_session_rank": (C.c_int, [P, P, I64, P, P, P, P, P, I64, I32, I32, P]),
     "amdkge_session_group_create": (C.c_int, [C.POINTER(SessionConfig), P, I32, C.POINTER(C.c_void_p)]),
+    "amdkge_session_group_create_ex": (C.c_int, [C.POINTER(SessionConfig), P, I32, I32, C.POINTER(C.c_void_p)]),
+    "amdkge_session_group_info": (C.c_int, [P, C.POINTER(I32), C.POINTER(I32)]),
+    "amdkge_session_screen_stats": (C.c_int, [P, C.POINTER(I32), C.POINTER(I64), C.POINTER(I32)]),
     "amdkge_session_group_destroy": (None, [P]),
     "amdkge_session_group_size": (I32, [P]),
     "amdkge_session_group_replica": (C.c_int, [P, I32, C.POINTER(C.c_void_p)]),

@@ -39,6 +39,14 @@ extern "C" int amdkge_device_count(int* count) {
     return AMDKGE_OK;
 }
 
+namespace kge { void release_loss_parts(); void release_plan_guard(); }
+
+extern "C" int amdkge_release_scratch(void) {
+    kge::release_loss_parts();
+    kge::release_plan_guard();
+    return AMDKGE_OK;
+}
+
 extern "C" int amdkge_set_device(int device) {
     const hipError_t e = hipSetDevice(device);
     return e == hipSuccess ? AMDKGE_OK : set_error_hip(e, "hipSetDevice");

@@ -1164,7 +1164,11 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     sa.b = b; sa.n = n; sa.m = mcand; sa.U = g.U;
     // per unit: the three dropped limb products (2^23 + 2^14) and the cross term of the two fixed-point roundings (1/4), in units of
     // A B; + 2^25: the fp32 reconstruction of the 40-bit integer sum in the epilogue (inner sum rounds by <= 2^8 in units of 2^16 A B)
-    sa.drop = (float)(((double)g.U * (8388608.0 + 16384.0 + 0.25) + 33554432.0) * (1.0 + 1e-6));
+    // ... + the fp32 rebuild of f = L0 2^16 + L1 2^8 + L2 in the epilogue, in units of f: |L1| <= U 2^15 and |L2| <= 3 U 2^14 exceed
+    // 2^24 for U > 512, so their conversions round too (half an ulp: <= 2 resp. 4 for U <= 2048, the first times 2^8), and the
+    // inner fma rounds at up to 2^34 (half an ulp: 2^10): 2^9 + 4 + 2^10 < 2^11, i.e. 2^27 A B (the screening condition holds
+    // U <= 2048; the outer fma's rounding is relative to |f| and sits in the thresholds)
+    sa.drop = (float)(((double)g.U * (8388608.0 + 16384.0 + 0.25) + 134217728.0) * (1.0 + 1e-6));
     const int64_t qtiles = (n + SCR_Q - 1) / SCR_Q, etiles = (mcand + SCR_ET - 1) / SCR_ET;
     // Each block takes a run of entity tiles of one 128-query block (its query fragments stay in L1 / L2); two workgroups per CU,
     // 256 CUs.  The run length is the one with the shortest schedule: rounds of 512 co-resident blocks x (tiles + ~0.35 of a
@@ -1329,7 +1333,7 @@ static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const flo
         // ---- int8 screening pass + exact recheck (kge_rank_screen.h) when the caller supplied its workspace: same counts, bit
         //      for bit; the exact kernel below then runs only as the fall-back of an overflowing recheck list ----
         const int64_t mcand = ent_hi - ent_lo;
-        if (d_screen && force == 0 && v4 && pipe && g.eplane == 0 && n >= 128 && mcand >= 512 && sgn_scale_positive(mc) &&
+        if (d_screen && force == 0 && v4 && pipe && g.eplane == 0 && g.U <= 2048 && n >= 128 && mcand >= 512 && sgn_scale_positive(mc) &&
             screen_bytes >= (int64_t)screen_fixed_bytes(n, mcand, g.U) + (1 << 16)) {
             if (int rc = run_screen(m, d_ent, d_ent_ids, ent_lo, mcand, n, g, w, mc, d_counts, d_screen, (size_t)screen_bytes, st)) return rc;
             a.guard = carve_screen(d_screen, (size_t)screen_bytes, n, mcand, g.U).counter + 1;

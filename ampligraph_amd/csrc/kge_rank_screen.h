@@ -19,7 +19,7 @@
 //                                                               with W = diag(sqrt(U - j)): half of the classic gamma_U |q| |e|)
 //               + (A_i |e_j|_1 + B_j |q_i|_1) / 2 + U A_i B_j / 4   (rounding of the rows to their fixed-point grids)
 //               + U (2^23 + 2^14) A_i B_j                      (the three dropped limb products)
-//               + 2^25 A_i B_j + 2^-22 |S~|                   (the epilogue's own fp32 roundings; the relative part sits in the
+//               + 2^27 A_i B_j + 2^-22 |S~|                   (the epilogue's own fp32 roundings, U <= 2048; the relative part sits in the
 //                                                               thresholds), the rest inflated by 2^-10;
 //      a pair whose interval [S~ - E, S~ + E] lies on one side of both thresholds (or between them) is DECIDED and counted;
 //   3. the others (a fraction of a per cent: those within ~1e-4 of the positive's quantisation cell) go to a list and are
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel(ScreenArgs 
         const float4 m4 = a.b.qm[okq ? q0 + tid : a.n - 1];
         const float c = 1.f + 0x1p-10f;
         qm_s[tid] = make_float4(m4.x * 65536.f, m4.y * c, m4.x * c, fmaf(a.drop, m4.x, m4.z) * c);
-        // The epilogue's own fp32 roundings.  Rebuilding f = L0 2^16 + L1 2^8 + L2 (an integer below 2^40) in fp32 costs at most
-        // 2^8 in the inner sum (absolute: part of `drop`, see run_screen) and 2^-24 |f| in the outer; the scales are powers of two;
+        // The epilogue's own fp32 roundings.  Rebuilding f = L0 2^16 + L1 2^8 + L2 (an integer below 2^42) in fp32 costs at most
+        // 2^11 absolutely (conversions of L1, L2 beyond 2^24 and the inner sum; part of `drop`, see run_screen) and 2^-24 |f| in the outer; the scales are powers of two;
         // S~ -+ E' rounds by 2^-24 (|S~| + E').  The part relative to |S~| (eps = 2^-23, taken as 2^-22) is moved into the
         // thresholds:  S~ - E' >= T + 2 eps |T|  implies  S~ - E' - eps |S~| >= T  (|S~| <= 2 (|T| + E'): directly, the 2^-10
         // inflation of E' taking the E' part; larger |S~|: its sign decides) -- 2^-20 |T| here, which also covers these sums' own

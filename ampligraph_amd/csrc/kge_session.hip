@@ -352,7 +352,17 @@ extern "C" int amdkge_session_rank(amdkge_session* s, const int32_t* triples, in
         const int64_t* off = (side == AMDKGE_SIDE_S) ? fs_off : fo_off;
         const int32_t* ids = (side == AMDKGE_SIDE_S) ? fs_ids : fo_ids;
         KGE_HIP(hipMemsetAsync(d_counts, 0, (size_t)n * 3 * sizeof(int32_t), s->st), "hipMemsetAsync");
-        KGE_RC(amdkge_rank_counts(m, s->tab[0], s->tab[1], (const int32_t*)d_tri, n, side, d_ent_ids, 0, ent_hi, (int32_t*)d_counts, d_work, s->st));
+        // DistMult / ComplEx / HolE: the int8 screening pass + exact recheck (kge_rank_screen.h) -- the counts of amdkge_rank_counts,
+        // bit for bit, at about twice its rate.  Its workspace is a scratch slot of the session; beyond SCREEN_MAX (huge candidate
+        // ranges), and for TransE / RotatE (screen_need == 0), the call is the plain amdkge_rank_counts.
+        void* d_screen = nullptr;
+        const int64_t screen_need = amdkge_rank_screen_workspace_bytes(m, n, ent_hi);
+        const int64_t SCREEN_MAX = (int64_t)8 << 30;
+        int64_t screen_bytes = 0;
+        if (screen_need > 0 && screen_need <= SCREEN_MAX) { KGE_RC(scratch(s, 7, screen_need, &d_screen)); screen_bytes = screen_need; }
+        KGE_RC(amdkge_rank_counts_screened(m, s->tab[0], s->tab[1], (const int32_t*)d_tri, n, side, d_ent_ids, 0, ent_hi, (int32_t*)d_counts,
+                                           d_work, d_screen, screen_bytes, s->st));
+        s->screen_ran = d_screen != nullptr;
         const int32_t* sub = nullptr;
         if (off) {
             if (off[0] < 0) return set_error(AMDKGE_EINVAL, "session_rank: negative filter offset");
@@ -369,6 +379,10 @@ extern "C" int amdkge_session_rank(amdkge_session* s, const int32_t* triples, in
         KGE_RC(amdkge_rank_compose((const int32_t*)d_counts, sub, n, strategy, (int32_t*)d_ranks + (two_cols ? col : col * n), two_cols ? 2 : 1, s->st));
         ++col;
     }
+    s->screen_stats[0] = s->screen_stats[1] = 0;
+    if (s->screen_ran) {   // (of the LAST side counted: the workspace is reused per side)
+        KGE_HIP(hipMemcpyAsync(s->screen_stats, s->buf[7], sizeof(s->screen_stats), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
+    }
     if (corrupt_side == AMDKGE_CORRUPT_S_PLUS_O) {   // the two 0-based sides are summed, then +1 (:1459-1463,1684)
         std::vector<int32_t> h((size_t)2 * n);
         KGE_HIP(hipMemcpyAsync(h.data(), d_ranks, (size_t)2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
@@ -378,6 +392,14 @@ extern "C" int amdkge_session_rank(amdkge_session* s, const int32_t* triples, in
     }
     KGE_HIP(hipMemcpyAsync(ranks_out, d_ranks, (size_t)n * (two_cols ? 2 : 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
     KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_screen_stats(const amdkge_session* s, int32_t* ran, int64_t* rechecked_pairs, int32_t* fell_back) {
+    if (!s) return set_error(AMDKGE_EINVAL, "session_screen_stats: NULL session");
+    if (ran) *ran = s->screen_ran ? 1 : 0;
+    if (rechecked_pairs) *rechecked_pairs = s->screen_ran ? (int64_t)s->screen_stats[0] : 0;
+    if (fell_back) *fell_back = s->screen_ran ? s->screen_stats[1] : 0;
     return AMDKGE_OK;
 }
 

@@ -38,6 +38,7 @@ struct Rccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    int (*GetVersion)(int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -55,6 +56,7 @@ int load_rccl(Rccl& r) {
 #define KGE_SYM(field, sym) do { *(void**)(&r.field) = dlsym(r.handle, sym); if (!r.field) return set_error(AMDKGE_ERCCL, "session_group: librccl lacks " sym); } while (0)
     KGE_SYM(CommInitAll, "ncclCommInitAll"); KGE_SYM(CommDestroy, "ncclCommDestroy"); KGE_SYM(AllReduce, "ncclAllReduce");
     KGE_SYM(GroupStart, "ncclGroupStart"); KGE_SYM(GroupEnd, "ncclGroupEnd"); KGE_SYM(GetErrorString, "ncclGetErrorString");
+    KGE_SYM(GetVersion, "ncclGetVersion");
 #undef KGE_SYM
     return AMDKGE_OK;
 }
@@ -83,6 +85,7 @@ struct amdkge_session_group {
     std::vector<hipEvent_t> ev;     // per replica: its share of the step is enqueued / done (same-device sum)
     Rccl rccl;
     bool same_device = false;
+    int32_t flags = 0;              // AMDKGE_GROUP_*
 };
 
 extern "C" void amdkge_session_group_destroy(amdkge_session_group* g) {
@@ -97,9 +100,27 @@ extern "C" void amdkge_session_group_destroy(amdkge_session_group* g) {
 }
 
 extern "C" int amdkge_session_group_create(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, amdkge_session_group** out) {
+    return amdkge_session_group_create_ex(cfg, devices, n_gpus, 0, out);
+}
+
+extern "C" int amdkge_session_group_info(const amdkge_session_group* g, int32_t* uses_rccl, int32_t* rccl_version) {
+    if (!g) return set_error(AMDKGE_EINVAL, "session_group_info: NULL group");
+    if (uses_rccl) *uses_rccl = g->comm.empty() ? 0 : 1;
+    if (rccl_version) {
+        int v = 0;
+        if (g->rccl.GetVersion) (void)g->rccl.GetVersion(&v);
+        *rccl_version = v;
+    }
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_group_create_ex(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
+                                              amdkge_session_group** out) {
     if (!cfg || !out || n_gpus < 1 || n_gpus > 16) return set_error(AMDKGE_EINVAL, "session_group_create: bad arguments (1 <= n_gpus <= 16)");
+    if (flags & ~AMDKGE_GROUP_FORCE_RCCL) return set_error(AMDKGE_EINVAL, "session_group_create_ex: unknown flag");
     *out = nullptr;
     amdkge_session_group* g = new amdkge_session_group();
+    g->flags = flags;
     auto fail = [&](int rc) { amdkge_session_group_destroy(g); return rc; };
     bool same = true, distinct = true;
     for (int d = 0; d < n_gpus; ++d) {
@@ -118,7 +139,7 @@ extern "C" int amdkge_session_group_create(const amdkge_session_config* cfg, con
         if (hipError_t e = hipSetDevice(g->rep[d]->cfg.device)) return fail(set_error_hip(e, "hipSetDevice"));
         if (hipError_t e = hipEventCreateWithFlags(&g->ev[d], hipEventDisableTiming)) return fail(set_error_hip(e, "hipEventCreate"));
     }
-    if (n_gpus > 1 && !g->same_device) {
+    if ((n_gpus > 1 && !g->same_device) || (n_gpus == 1 && (flags & AMDKGE_GROUP_FORCE_RCCL))) {
         if (int rc = load_rccl(g->rccl)) return fail(rc);
         std::vector<int> devs;
         for (amdkge_session* s : g->rep) devs.push_back(s->cfg.device);
@@ -146,7 +167,7 @@ extern "C" int amdkge_session_group_set_rows(amdkge_session_group* g, int32_t ta
 // sum `len` floats at `ptr_of(replica)` over the replicas, result on every replica, stream-ordered on each replica's stream
 static int group_sum(amdkge_session_group* g, float* (*ptr_of)(amdkge_session*), int64_t len) {
     const int n = (int)g->rep.size();
-    if (n == 1 || len == 0) return AMDKGE_OK;
+    if ((n == 1 && g->comm.empty()) || len == 0) return AMDKGE_OK;
     if (g->same_device) {
         // replica 0's stream waits for the others' work, sums in place for everybody, and the others wait for the sum
         amdkge_session* s0 = g->rep[0];
@@ -181,14 +202,24 @@ static int group_sum(amdkge_session_group* g, float* (*ptr_of)(amdkge_session*),
 extern "C" int amdkge_session_group_train_step(amdkge_session_group* g, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out) {
     if (!g || B < 0) return set_error(AMDKGE_EINVAL, "session_group_train_step: bad arguments");
     const int n = (int)g->rep.size();
-    if (n == 1) return amdkge_session_train_step(g->rep[0], triples, B, focus_w, loss_out);   // the complete fused step
+    if (n == 1 && g->comm.empty()) return amdkge_session_train_step(g->rep[0], triples, B, focus_w, loss_out);   // the complete fused step
     if (loss_out) *loss_out = 0.0;
     if (B == 0) return AMDKGE_OK;
     if (!triples) return set_error(AMDKGE_EINVAL, "session_group_train_step: NULL triples");
     // ---- 1. every replica: its share of the batch, gradients only ----
     for (int d = 0; d < n; ++d) {
         const int64_t lo = B * d / n, hi = B * (d + 1) / n;
-        KGE_RC(amdkge_session_grad_step(g->rep[d], triples + 3 * lo, hi - lo, focus_w ? focus_w + lo : nullptr, lo, B));
+        if (const int rc = amdkge_session_grad_step(g->rep[d], triples + 3 * lo, hi - lo, focus_w ? focus_w + lo : nullptr, lo, B)) {
+            // replicas 0 .. d-1 already hold this batch's gradients: clear them, or the next call would add to them (their loss
+            // accumulators are reset by every grad_step)
+            for (int q = 0; q < d; ++q) {
+                amdkge_session* s = g->rep[q];
+                (void)hipSetDevice(s->cfg.device);
+                (void)hipMemsetAsync(s->g_ent, 0, (size_t)s->cfg.model.n_ents * s->Ks * sizeof(float), s->st);
+                (void)hipMemsetAsync(s->g_rel, 0, (size_t)s->cfg.model.n_rels * s->Ks * sizeof(float), s->st);
+            }
+            return rc;
+        }
     }
     // ---- 2. gradient sum over the replicas (RCCL all-reduce, or the local sum of same-device replicas) ----
     KGE_RC(group_sum(g, [](amdkge_session* s) { return s->g_ent; }, g->rep[0]->cfg.model.n_ents * (int64_t)g->rep[0]->Ks));
@@ -203,5 +234,21 @@ extern "C" int amdkge_session_group_train_step(amdkge_session_group* g, const in
         if (d == 0) reg = h[1];
     }
     if (loss_out) *loss_out = data + reg;
+    // deterministic mode: a tile beyond its sort buffer fell back to arrival order -- reported like amdkge_session_train_step does
+    if (g->rep[0]->cfg.flags & AMDKGE_TILED_DETERMINISTIC) {
+        bool fell_back = false;
+        for (int d = 0; d < n; ++d) {
+            amdkge_session* s = g->rep[d];
+            const int64_t lo = B * d / n, hi = B * (d + 1) / n;
+            if (hi == lo || !s->twork) continue;
+            KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+            int32_t st_flag = 0;
+            KGE_RC(amdkge_train_tiled_status(&s->cfg.model, hi - lo, s->cfg.eta, s->cfg.flags & (AMDKGE_TILED_POS_ATOMIC | AMDKGE_TILED_DETERMINISTIC),
+                                             s->twork, &st_flag, s->st));
+            fell_back = fell_back || st_flag != 0;
+        }
+        if (fell_back)
+            return set_error(AMDKGE_EUNSUPPORTED, "session_group_train_step: deterministic mode -- a tile received more entries than its sort buffer holds (a very hot row); this step's sums were not all added in canonical order");
+    }
     return AMDKGE_OK;
 }

@@ -21,6 +21,8 @@ struct amdkge_session {
     int64_t iteration = 0;
     std::vector<int32_t> hot_ids;   // AMDKGE_TILED_HOT_ROWS: declared hot rows, (re)applied whenever the workspace is (re)allocated
     bool hot_dirty = false;
+    bool screen_ran = false;        // the last amdkge_session_rank went through the int8 screening pass
+    int32_t screen_stats[2] = {0, 0};   // its {rechecked pairs, fell back to the exact kernel} (last side)
 };
 
 

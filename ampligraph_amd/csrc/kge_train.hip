@@ -47,21 +47,52 @@ __global__ void loss_fold_kernel(double* parts, double* loss_sum) {
 }
 
 // Scratch of the atomic path (it has no workspace argument): LOSS_PARTS partial sums, zero between calls.  One buffer per LOSS
-// ACCUMULATOR (keyed by d_loss_sum): two engines or sessions that train on different streams of one GPU have their own
-// accumulators, hence their own partials -- a buffer shared per device let their kernels and fold launches mix sums
-// (ADVICE r2).  Calls that share an accumulator are ordered by their caller anyway.  Thread-safe; the few hundred bytes per
-// accumulator live until the process ends.
+// ACCUMULATOR -- keyed by (device, d_loss_sum): two engines or sessions that train on different streams of one GPU have their
+// own accumulators, hence their own partials (a buffer shared per device let their kernels and fold launches mix sums, ADVICE
+// r2), and the same address on ANOTHER GPU is another accumulator, whose partials must live on that GPU.  Calls
+// that share an accumulator are ordered by their caller anyway.  Thread-safe.  A buffer is 8 KB; a host that hands over fresh
+// accumulators without end is bounded: beyond LOSS_PARTS_MAX entries, or when amdkge_release_scratch() is called, every device
+// with entries is synchronised and its buffers are freed.
+namespace {
+struct PartsKey {
+    int dev; const void* p;
+    bool operator==(const PartsKey& o) const { return dev == o.dev && p == o.p; }
+};
+struct PartsHash { size_t operator()(const PartsKey& k) const { return std::hash<const void*>()(k.p) ^ ((size_t)k.dev * 0x9E3779B97F4A7C15ull); } };
+constexpr size_t LOSS_PARTS_MAX = 1024;
+std::mutex g_parts_mu;
+std::unordered_map<PartsKey, double*, PartsHash> g_parts;
+
+void release_parts_locked() {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : g_parts) {
+        (void)hipSetDevice(kv.first.dev);
+        (void)hipDeviceSynchronize();   // (a launch that still reads the partials may be in flight)
+        (void)hipFree(kv.second);
+    }
+    g_parts.clear();
+    (void)hipSetDevice(cur);
+}
+}  // namespace
+
+void release_loss_parts() {   // (kge::, called by amdkge_release_scratch)
+    std::lock_guard<std::mutex> lk(g_parts_mu);
+    release_parts_locked();
+}
+
 static double* loss_parts_for(const void* d_loss_sum) {
-    static std::mutex mu;
-    static std::unordered_map<const void*, double*> parts;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = parts.find(d_loss_sum);
-    if (it != parts.end()) return it->second;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_parts_mu);
+    auto it = g_parts.find(PartsKey{dev, d_loss_sum});
+    if (it != g_parts.end()) return it->second;
+    if (g_parts.size() >= LOSS_PARTS_MAX) release_parts_locked();
     double* p = nullptr;
     const size_t bytes = (size_t)LOSS_PARTS * LOSS_PART_STRIDE * sizeof(double);
     if (hipMalloc((void**)&p, bytes) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
-    parts.emplace(d_loss_sum, p);
+    g_parts.emplace(PartsKey{dev, d_loss_sum}, p);
     return p;
 }
 

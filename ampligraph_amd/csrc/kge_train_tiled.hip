@@ -840,16 +840,32 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
 // used the buffer in between.  The library remembers, per workspace address, the geometry of the last step enqueued on it and
 // clears the counter region on the step's stream when it changes (first sight of an address counts as a change; the
 // caller's zero-fill contract covers a buffer that is freed and re-allocated at the same address).
+// The memory is per (device, address) -- the same address on another GPU is another workspace -- and bounded: past
+// PLAN_GUARD_MAX remembered workspaces (or on amdkge_release_scratch()) everything is forgotten, which only costs the next step on
+// each workspace one memset.  The guard is HOST state: a step captured into a hipGraph and replayed does not pass through it, so
+// a graph must not be replayed on a workspace that a step of another geometry has used since the capture (include/amdkge.h).
+namespace {
+constexpr size_t PLAN_GUARD_MAX = 4096;
+std::mutex g_plan_mu;
+std::unordered_map<uint64_t, uint64_t> g_plan_last[16];   // per device ordinal (mod 16): workspace address -> geometry signature
+}
+void release_plan_guard() {   // (kge::, called by amdkge_release_scratch)
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    for (auto& mp : g_plan_last) mp.clear();
+}
 static int plan_guard(const void* d_work, const TiledPlan& p, char* w, hipStream_t st) {
-    static std::mutex mu;
-    static std::unordered_map<const void*, uint64_t> last;
     const uint64_t sig = ((uint64_t)(uint32_t)p.n_tiles << 32) ^ ((uint64_t)p.off_cnt * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(uint32_t)p.cap;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return set_error_hip(e, "hipGetDevice");
     bool changed;
     {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = last.find(d_work);
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        auto& last = g_plan_last[dev & 15];
+        if (last.size() >= PLAN_GUARD_MAX) last.clear();
+        const uint64_t key = (uint64_t)(uintptr_t)d_work ^ ((uint64_t)(dev >> 4) << 56);
+        auto it = last.find(key);
         changed = it == last.end() || it->second != sig;
-        if (changed) last[d_work] = sig;
+        if (changed) last[key] = sig;
     }
     if (changed)
         if (hipError_t e = hipMemsetAsync(w + p.off_cnt, 0, (size_t)(p.n_tiles + 2) * 32 * 4, st)) return set_error_hip(e, "hipMemsetAsync(tile counters)");

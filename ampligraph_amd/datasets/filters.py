@@ -100,13 +100,17 @@ class FilterIndex:
         device = engine.device
         cache = self.__dict__.setdefault("_dev", {})
         if cache.get("device") != str(device):
-            cache.clear()
-            cache["device"] = str(device)
+            # another device than the one the index lives on (or a host-built index): the host copies first -- for a
+            # device-built index they exist only through __getattr__, which reads the very cache replaced here
+            host = {nm: getattr(self, nm) for nm in ("po_keys", "po_start", "sp_keys", "sp_start", "s_ids", "o_ids")}
+            fresh = {"device": str(device)}
             for nm in ("po_keys", "po_start", "sp_keys", "sp_start"):
-                cache[nm] = torch.as_tensor(getattr(self, nm)).to(device)
+                fresh[nm] = torch.as_tensor(host[nm]).to(device)
             for nm in ("s_ids", "o_ids"):
-                a = getattr(self, nm)
-                cache[nm] = torch.as_tensor(a if a.size else np.zeros(1, np.int32)).to(device)
+                fresh[nm] = torch.as_tensor(host[nm] if host[nm].size else np.zeros(1, np.int32)).to(device)
+            cache.clear()
+            cache.update(fresh)
+            self.__dict__["_dev_sizes"] = {"s_ids": int(host["s_ids"].size), "o_ids": int(host["o_ids"].size)}
         keys, start, ids = (cache["po_keys"], cache["po_start"], cache["s_ids"]) if side == "s" else \
             (cache["sp_keys"], cache["sp_start"], cache["o_ids"])
         lo, hi = engine.filter_ranges(keys, start, triples_dev, 1 if side == "s" else 2, self.n_ents, self.n_rels)

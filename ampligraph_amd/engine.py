@@ -241,11 +241,10 @@ class KgeEngine:
             check(self.lib.amdkge_train_tiled_set_hot_rows(C.byref(self.model), _ptr(self._twork), None, 0, _stream()))
 
     def tiled_status(self):
-        """Sticky status of the owner-computes steps since the last query (synchronises): 1 = a DETERMINISTIC step fell back to
-        unsorted accumulation in some tile; 2 = a tile of the row-direct pass (long rows) received more entries than its LDS
-        list holds.  Queried only where one of the two can be set."""
-        long_rows = self.ks > 512   # stored half width beyond 128 quads: kge_tile_direct.h
-        if self._twork is None or not hasattr(self, "_last_tiled") or not ((self._last_tiled[2] & 2) or long_rows):
+        """Sticky status of the owner-computes steps since the last query: 1 = a DETERMINISTIC step fell back to unsorted
+        accumulation in some tile.  Only a deterministic step can set it, so only then is the stream synchronised to read it (the
+        row-direct pass of long rows handles an overflowing LDS list by rescanning the spill: complete sums, no status)."""
+        if self._twork is None or not hasattr(self, "_last_tiled") or not (self._last_tiled[2] & 2):
             return 0
         st = C.c_int32(0)
         B, eta, flags = self._last_tiled

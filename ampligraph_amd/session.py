@@ -127,6 +127,14 @@ class Session:
         return out
 
 
+    def screen_stats(self):
+        """Of the last rank(): None when the count pass ran without the int8 screening pass (TransE / RotatE, tiny problems), else
+        (pairs the exact fp32 chain re-checked on the last side, fell back to the exact kernel?)."""
+        ran, pairs, fb = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+        check(self.lib.amdkge_session_screen_stats(self._h, C.byref(ran), C.byref(pairs), C.byref(fb)))
+        return (int(pairs.value), bool(fb.value)) if ran.value else None
+
+
 class SessionGroup:
     """amdkge_session_group_*: the session layer on several GPUs from ONE process, numpy only -- data-parallel training with the
     library's own RCCL communicators (kge_session_group.hip).  `devices`: distinct ordinals (RCCL all-reduce over xGMI) or the
@@ -134,7 +142,9 @@ class SessionGroup:
     model: replica(i) is an ordinary Session view for get_rows / score / rank."""
 
     def __init__(self, devices, scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer=None, rel_regularizer=None, seed=0,
-                 pos_atomic=False, focus_nonlinearity=None, deterministic=False):
+                 pos_atomic=False, focus_nonlinearity=None, deterministic=False, force_rccl=False):
+        """force_rccl: AMDKGE_GROUP_FORCE_RCCL -- a group of one replica still binds librccl and sums its gradients through a
+        one-rank ncclAllReduce (first contact with RCCL on a one-GPU box)."""
         self.lib = _ffi.lib()
         self._args = (scoring_type, int(k), int(n_ents), int(n_rels), int(eta), loss, optimizer)
         self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], int(k)))
@@ -142,8 +152,14 @@ class SessionGroup:
                       focus_nonlinearity, deterministic)
         dev = _i32(list(devices))
         self._g = C.c_void_p()
-        check(self.lib.amdkge_session_group_create(C.byref(cfg), _p(dev), int(dev.shape[0]), C.byref(self._g)))
+        check(self.lib.amdkge_session_group_create_ex(C.byref(cfg), _p(dev), int(dev.shape[0]), 1 if force_rccl else 0, C.byref(self._g)))
         self.size = int(self.lib.amdkge_session_group_size(self._g))
+
+    def info(self):
+        """(sums through RCCL?, ncclGetVersion code or 0)"""
+        u, v = C.c_int32(0), C.c_int32(0)
+        check(self.lib.amdkge_session_group_info(self._g, C.byref(u), C.byref(v)))
+        return bool(u.value), int(v.value)
 
     def close(self):
         if getattr(self, "_g", None) is not None and self._g.value:

@@ -337,9 +337,6 @@ class StepLoop:
         term is identical on every rank (replicated tables, all-reduce merge: counted once) or split over the
         ranks' slices (sharded merge: summed)."""
         st = self.engine.tiled_status() if hasattr(self.engine, "tiled_status") else 0   # (0 without a sync unless it can be set)
-        if st & 2:
-            raise RuntimeError("owner-computes step, long rows: a tile received more entries than its LDS list holds (a "
-                               "pathologically hot tile); this epoch's gradient sums are incomplete")
         if self.deterministic and st:
             raise RuntimeError("deterministic mode: a tile received more entries than its sort buffer holds (very hot rows); "
                                "this epoch's sums were not all added in canonical order")

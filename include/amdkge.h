@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AMDKGE_ABI_VERSION 3
+#define AMDKGE_ABI_VERSION 4
 
 /* error classes */
 #define AMDKGE_OK 0
@@ -125,6 +125,11 @@ typedef struct amdkge_opt {
 int amdkge_abi_version(void);
 const char* amdkge_last_error(void);
 int amdkge_device_count(int* count);
+/* Library-internal scratch that is keyed by a caller's pointers -- the 8 KB of per-block loss partials amdkge_train_fwdbwd keeps
+ * per (device, d_loss_sum), and the per-(device, workspace) memory of the owner-computes plan guard -- is bounded (1 024 resp.
+ * 4 096 entries, then dropped wholesale) and can be dropped explicitly here, e.g. after freeing the accumulators and workspaces
+ * of a finished job.  Synchronises the devices that hold such scratch.  Safe at any time between calls. */
+int amdkge_release_scratch(void);
 int amdkge_set_device(int device);
 int amdkge_dev_alloc(void** d_ptr, uint64_t bytes);
 int amdkge_dev_free(void* d_ptr);
@@ -226,12 +231,15 @@ int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_s
  * dominate (zipf: the top entity is the s or o of ~10 % of a batch).  Ignored with DETERMINISTIC / POS_ATOMIC.  Hot rows count
  * as touched in the lazy optimizer mode.  Results are identical up to fp32 summation order. */
 #define AMDKGE_TILED_HOT_ROWS 4
+/* hipGraph capture: a workspace remembers (on the HOST, per device and address) the tile geometry of the last step enqueued on it
+ * and re-zeroes its counters when the geometry changes; a captured-and-replayed step bypasses that memory, so a graph may only be
+ * replayed on a workspace no step of another geometry (other B / eta / flags) has used since the capture. */
 int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int32_t eta);
 /* Long rows (stored half width > 512 units, i.e. rows beyond 2 KB: the C5 row width) take the ROW-DIRECT form of the tile pass by
  * default (kge_tile_direct.h: one wave group per tile, its bucket sorted in LDS, every row folded in registers and updated in
  * one go -- x read once, several tiles resident per CU).  0 keeps them on the LDS-accumulator kernel (A/B measurements, tests);
- * process-wide, both forms compute the same step up to fp32 summation order.  amdkge_train_tiled_status reports 2 when a tile's
- * entries outgrew the direct form's LDS list (a pathologically hot tile: that step's sums are incomplete). */
+ * process-wide, both forms compute the same step up to fp32 summation order.  A tile whose entries outgrow the direct form's LDS
+ * list rescans the spill in memory (slower, complete): no status is raised for it. */
 int amdkge_set_tile_direct(int on);
 /* status != 0 after a DETERMINISTIC step: some tile fell back to unsorted accumulation since the last query (flag is cleared).
  * Synchronises the stream. */
@@ -448,6 +456,10 @@ int amdkge_session_rank(amdkge_session* s, const int32_t* triples, int64_t n,
                         const int64_t* fs_off, const int32_t* fs_ids, const int64_t* fo_off, const int32_t* fo_ids,
                         const int32_t* ent_subset, int64_t n_subset, int32_t corrupt_side, int32_t strategy,
                         int32_t* ranks_out);
+/* Of the last amdkge_session_rank call: did the count pass run behind the int8 screening pass (DistMult / ComplEx / HolE, see
+ * amdkge_rank_counts_screened -- the session keeps its workspace), how many pairs the exact fp32 chain re-checked and whether
+ * the recheck list overflowed into the exact kernel (last side counted).  Any pointer may be NULL. */
+int amdkge_session_screen_stats(const amdkge_session* s, int32_t* ran, int64_t* rechecked_pairs, int32_t* fell_back);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Session GROUP: the session layer on several GPUs of one node from ONE process (kge_session_group.hip) -- what a host
@@ -461,11 +473,21 @@ int amdkge_session_rank(amdkge_session* s, const int32_t* triples, int64_t n,
  *             the negatives one GPU would draw for the whole batch (keyed by the global corruption row), the dense gradients of
  *             both tables are summed over the replicas, every replica applies the same dense update: replicas stay
  *             bit-identical, and n replicas compute the step of one GPU up to fp32 summation order.  The reference has no
- *             multi-device path at all.
+ *             multi-device path at all.  With AMDKGE_TILED_DETERMINISTIC a step whose sorted accumulation fell back in some
+ *             tile returns AMDKGE_EUNSUPPORTED after carrying the step out (as amdkge_session_train_step does).  Hot-row
+ *             replicas (amdkge_session_set_hot_rows on a replica) apply to single-session steps only: group steps ignore them.
+ *             If a replica's share fails, the gradients the earlier replicas already formed are cleared before the error returns.
  *   amdkge_session_group_set_rows   : rows of a table on every replica;   amdkge_session_group_replica : replica i, for
  *             amdkge_session_get_rows / _score / _rank (every replica holds the whole model). */
 typedef struct amdkge_session_group amdkge_session_group;
 int amdkge_session_group_create(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, amdkge_session_group** out);
+/* flags: AMDKGE_GROUP_FORCE_RCCL -- a group of ONE replica takes the multi-replica path too (librccl bound, ncclCommInitAll over
+ * the one device, gradient-only kernels, grouped ncclAllReduce of both gradient tables, dense sweeps): every RCCL call of the
+ * group step is exercised on a one-GPU box.  amdkge_session_group_info: whether the group sums through RCCL, and ncclGetVersion. */
+enum { AMDKGE_GROUP_FORCE_RCCL = 1 };
+int amdkge_session_group_create_ex(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
+                                   amdkge_session_group** out);
+int amdkge_session_group_info(const amdkge_session_group* g, int32_t* uses_rccl, int32_t* rccl_version);
 void amdkge_session_group_destroy(amdkge_session_group* g);
 int32_t amdkge_session_group_size(const amdkge_session_group* g);
 int amdkge_session_group_replica(amdkge_session_group* g, int32_t i, amdkge_session** out);

@@ -60,7 +60,7 @@ def loss_desc(name, reduction="sum", **kw):
 
 # -------------------------------------------------------------------------------- wave reduction
 def test_library_loaded(gpu_lib):
-    assert gpu_lib.amdkge_abi_version() == 3
+    assert gpu_lib.amdkge_abi_version() == 4
     c = C.c_int(0)
     assert gpu_lib.amdkge_device_count(C.byref(c)) == 0 and c.value >= 1
 
