@@ -160,6 +160,10 @@ __global__ __launch_bounds__(256) void rank_prep_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 constexpr int QT = 64, ET = 64, KT = 16, LDP = 68;   // LDP: padded LDS row (floats), keeps float4 reads aligned
 
+}  // namespace kge
+#include "kge_rank_early.h"   // part 1: the distance models' exact early exit (thresholds, the check-point protocol)
+namespace kge {
+
 struct CountArgs {
     const float* ent;
     const float* Q;
@@ -174,14 +178,22 @@ struct CountArgs {
     int qtiles, splits;   // MFMA kernel: logical grid, decoded from a 1-D XCD-aware launch
     float* scores;        // STORE variant of the VALU tile kernel: [n][ld] un-quantised scores instead of counts
     int64_t ld;
-    const int* guard;     // pipelined MFMA kernel as the fall-back of the int8 screening pass: runs only if *guard != 0
+    const int* guard;     // a kernel launched as the fall-back of the screening / early-exit pass: runs only if *guard != 0
+    // EARLY variants of the distance models' tile kernels (kge_rank_early.h)
+    EarlyList e_list;         // the list undecided pairs are handed to
+    const uint8_t* e_qbad;    // [n] / [candidates]: rows whose pairs must not be decided early (non-finite or huge values)
+    const uint8_t* e_ebad;
+    int e_check, e_cost;      // stages between two checks; relative cost of a re-checked pair
 };
 
-template <int MODE, bool V4, bool STORE = false>
+template <int MODE, bool V4, bool STORE = false, bool EARLY = false>
 __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
     constexpr int NQF = ModeTraits<MODE>::NQF, NEF = ModeTraits<MODE>::NEF;
+    static_assert(!EARLY || ((MODE == MODE_L1 || MODE == MODE_L1_SUB) && V4 && !STORE), "early exit: the TransE count kernels");
     __shared__ __attribute__((aligned(16))) float Qs[NQF][KT][LDP];
     __shared__ __attribute__((aligned(16))) float Es[NEF][KT][LDP];
+    __shared__ EarlyShared es_;   // (referenced by the EARLY variants only: elsewhere it is never allocated)
+    if (a.guard && *a.guard == 0) return;   // launched as a fall-back that turned out not to be needed
 
     const int tid = threadIdx.x;
     const int tq = tid >> 4, te = tid & 15;
@@ -198,6 +210,19 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
         }
     }
     int cgt[4] = {0, 0, 0, 0}, ceq[4] = {0, 0, 0, 0};
+    // EARLY: per query the partial sum beyond which the pair is decided (it can no longer reach the positive's quantised score);
+    // +inf for a query row that must not be decided early; rows beyond n take no part
+    float thr[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t qvalid = 0u;
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int64_t qi = q0 + tq * 4 + x;
+            thr[x] = early_threshold(qp[x], a.sgn_scale);
+            if (qi < a.n) { qvalid |= 0xFu << (4 * x); if (a.e_qbad[qi]) thr[x] = INFINITY; }
+        }
+        if (tid == 0) es_.n = 0;
+    }
 
     // loader mapping: row = tid / 4 (0..63), 4-unit group = tid % 4
     const int lrow = tid >> 2, lgrp = tid & 3;
@@ -214,6 +239,18 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
         for (int x = 0; x < 4; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y) acc[x][y] = 0.f;
+        // EARLY: which of the thread's 16 pairs exist at all (query < n, candidate inside the range) and which must stay undecided
+        uint32_t pvalid = 0u, pkeep = 0u;
+        bool ended = false;
+        if constexpr (EARLY) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const int64_t ej = et + te * 4 + y;
+                if (ej < e_end) { pvalid |= 0x1111u << y; if (a.e_ebad[ej - a.ent_lo]) pkeep |= 0x1111u << y; }
+            }
+            pvalid &= qvalid;
+            pkeep &= pvalid;
+        }
 
         for (int k0 = 0; k0 < a.g.U; k0 += KT) {
             const int ku = k0 + lgrp * 4;
@@ -285,8 +322,33 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
                         }
                 }
             }
+            // EARLY, every e_check stages (not behind the last one): count the pairs that are still undecided; the stage's own
+            // barrier publishes the four wave sums
+            bool chk = false;
+            uint32_t und = 0u;
+            if constexpr (EARLY) {
+                chk = ((k0 / KT + 1) % a.e_check == 0) && (k0 + KT < a.g.U);
+                if (chk) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) und |= (acc[x][y] > thr[x]) ? 0u : (1u << (4 * x + y));   // (NaN: undecided)
+                    und = (und | pkeep) & pvalid;
+                    const int c = wave_sum_i(__popc(und));
+                    if ((tid & 63) == 0) es_.red[tid >> 6] = c;
+                }
+            }
             __syncthreads();
+            if constexpr (EARLY) {
+                int total;
+                if (chk && early_decide(es_, k0 + KT, a.g.U, a.e_cost, total)) {
+                    early_spill(es_, a.e_list, und, total, q0 + tq * 4, et + te * 4 - a.ent_lo);
+                    ended = true;
+                    break;
+                }
+            }
         }
+        if constexpr (EARLY) { if (ended) continue; }   // decided or handed over: nothing of this tile is counted here
         if constexpr (STORE) {
             // ---- epilogue of the STORE variant: the scores themselves (discovery: top-k / nearest neighbours) ----
 #pragma unroll
@@ -376,11 +438,14 @@ __device__ __forceinline__ void rot_micro(const float (&qv)[SUBJ ? 4 : 2][4], co
         }
 }
 
-template <bool SUBJ, bool STORE>
+template <bool SUBJ, bool STORE, bool EARLY = false>
 __global__ __launch_bounds__(256) void rank_rot_kernel(CountArgs a) {
     constexpr int NQF = SUBJ ? 4 : 2, NEF = 2;
+    static_assert(!EARLY || !STORE, "early exit: the count form only");
     __shared__ __attribute__((aligned(16))) float Qs[NQF][KT][LDP];
     __shared__ __attribute__((aligned(16))) float Es[NEF][KT][LDP];
+    __shared__ EarlyShared es_;   // (referenced by the EARLY variants only: elsewhere it is never allocated)
+    if (a.guard && *a.guard == 0) return;   // launched as a fall-back that turned out not to be needed
 
     const int tid = threadIdx.x;
     const int tq = tid >> 4, te = tid & 15;
@@ -398,6 +463,17 @@ __global__ __launch_bounds__(256) void rank_rot_kernel(CountArgs a) {
         }
     }
     int cgt[4] = {0, 0, 0, 0}, ceq[4] = {0, 0, 0, 0};
+    float thr[4] = {0.f, 0.f, 0.f, 0.f};   // EARLY: see rank_count_kernel
+    uint32_t qvalid = 0u;
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int64_t qi = q0 + tq * 4 + x;
+            thr[x] = early_threshold(qp[x], a.sgn_scale);
+            if (qi < a.n) { qvalid |= 0xFu << (4 * x); if (a.e_qbad[qi]) thr[x] = INFINITY; }
+        }
+        if (tid == 0) es_.n = 0;
+    }
 
     const int lrow = tid >> 2, lgrp = tid & 3;   // loader: row 0..63, 4-unit group 0..3
     const int64_t lq = q0 + lrow;
@@ -410,8 +486,19 @@ __global__ __launch_bounds__(256) void rank_rot_kernel(CountArgs a) {
         const float* erow = a.ent + erow_id * a.g.K;
         f32x2 acc[4][2];
         float gmax = 0.f;
+        uint32_t pvalid = 0u, pkeep = 0u;   // EARLY: the thread's existing pairs / those that must stay undecided (bit 4 x + y)
+        if constexpr (EARLY) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const int64_t ej = et + te * 4 + y;
+                if (ej < e_end) { pvalid |= 0x1111u << y; if (a.e_ebad[ej - a.ent_lo]) pkeep |= 0x1111u << y; }
+            }
+            pvalid &= qvalid;
+            pkeep &= pvalid;
+        }
 
-        auto run_tile = [&](auto slow_c) __attribute__((always_inline)) {
+        // returns true when the tile ended early (EARLY, fast form only): its undecided pairs are on the list
+        auto run_tile = [&](auto slow_c) __attribute__((always_inline)) -> bool {
             constexpr bool SLOW = decltype(slow_c)::value;
 #pragma unroll
             for (int x = 0; x < 4; ++x)
@@ -453,10 +540,37 @@ __global__ __launch_bounds__(256) void rank_rot_kernel(CountArgs a) {
                 } else {
                     for (int kk = 0; kk < U - k0; ++kk) unit(kk);   // the row's last, partial stage: live units only
                 }
+                bool chk = false;
+                uint32_t und = 0u;
+                if constexpr (EARLY && !SLOW) {
+                    chk = ((k0 / KT + 1) % a.e_check == 0) && (k0 + KT < U);
+                    if (chk) {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+#pragma unroll
+                            for (int y = 0; y < 4; ++y) {
+                                const float sc = (y & 1) ? acc[x][y >> 1].y : acc[x][y >> 1].x;
+                                und |= (sc > thr[x]) ? 0u : (1u << (4 * x + y));   // (NaN: undecided)
+                            }
+                        und = (und | pkeep) & pvalid;
+                        const int c = wave_sum_i(__popc(und));
+                        // a modulus outside the fast form's domain so far (the partial sums cannot be trusted): no exit for this tile
+                        const bool dom = __ballot(!(gmax <= 0x1p50f)) != 0ull;
+                        if ((tid & 63) == 0) es_.red[tid >> 6] = c | (dom ? (1 << 30) : 0);
+                    }
+                }
                 __syncthreads();
+                if constexpr (EARLY && !SLOW) {
+                    int total;
+                    if (chk && early_decide(es_, k0 + KT, U, a.e_cost, total)) {
+                        early_spill(es_, a.e_list, und, total, q0 + tq * 4, et + te * 4 - a.ent_lo);
+                        return true;
+                    }
+                }
             }
+            return false;
         };
-        run_tile(std::false_type{});
+        if (run_tile(std::false_type{})) continue;
         bool bad = !(gmax <= 0x1p50f);
 #pragma unroll
         for (int x = 0; x < 4; ++x)
@@ -1094,6 +1208,8 @@ __global__ void rank_compose_kernel(const int32_t* counts, const int32_t* sub, i
 
 }  // namespace kge
 #include "kge_rank_screen.h"
+#define KGE_RANK_EARLY_PART2
+#include "kge_rank_early.h"   // part 2: workspace, row flags, the exact recheck of the distance models
 namespace kge {
 
 static inline char* align_up(char* p, size_t a) { return (char*)(((uintptr_t)p + a - 1) & ~(uintptr_t)(a - 1)); }
@@ -1216,6 +1332,64 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     return check_launch("rank_screen_merge");
 }
 
+// the early-exit sequence of one rank_counts call of a distance model (kge_rank_early.h): row flags, the EARLY tile kernel (counts
+// of the tiles it finishes + the list of the pairs it hands over), the exact recheck of the list, the merge into the caller's
+// counts (skipped when the list overflowed: the caller then runs the plain kernel behind the same flag).  `a`: the plain
+// kernel's arguments (grid geometry included).
+static int run_early(int mode, const amdkge_model* m, const float* d_ent, const int32_t* d_ent_ids, int64_t ent_lo, int64_t mcand, int64_t n,
+                     const RankGeom& g, const Workspace& w, CountArgs a, dim3 grid, void* d_screen, size_t screen_bytes, const int** guard_out,
+                     hipStream_t st) {
+    int32_t* const caller_counts = a.counts;
+    EarlyBufs eb = carve_early(d_screen, screen_bytes, n, mcand);
+    if (hipError_t e = hipMemsetAsync(eb.b.counter, 0, 256 + scr_up((size_t)n * 8), st)) return set_error_hip(e, "hipMemsetAsync(early counters)");
+    // rows that must not be decided early: the query vectors (every plane) and the candidate rows (stored width)
+    hipLaunchKernelGGL(rank_rowflags_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.Q, (int64_t)g.QW, (const int32_t*)nullptr, (int64_t)0, n, g.QW, eb.qbad);
+    if (int rc = check_launch("rank_rowflags(Q)")) return rc;
+    hipLaunchKernelGGL(rank_rowflags_kernel, dim3((unsigned)((mcand + 3) / 4)), dim3(256), 0, st, d_ent, (int64_t)g.K, d_ent_ids, ent_lo, mcand, g.K, eb.ebad);
+    if (int rc = check_launch("rank_rowflags(E)")) return rc;
+    a.counts = eb.b.counts;
+    a.e_list = EarlyList{eb.b.counter, eb.b.pairs, eb.b.cap};
+    a.e_qbad = eb.qbad; a.e_ebad = eb.ebad;
+    a.e_cost = g_early.cost < 1 ? 1 : g_early.cost;
+    const bool rot = mode == MODE_ROT_O || mode == MODE_ROT_S;
+    a.e_check = rot ? g_early.check_rot : g_early.check_l1;
+    if (a.e_check < 1) a.e_check = 1;
+    RecheckDistArgs ra{};
+    ra.ent = d_ent; ra.Q = w.Q; ra.qpos = w.qpos; ra.ent_ids = d_ent_ids; ra.ent_lo = ent_lo; ra.g = g; ra.sgn_scale = a.sgn_scale; ra.b = eb.b;
+#define KGE_RD(MODE) do { \
+        static bool attr = false; \
+        if (!attr) { \
+            if (hipError_t e = hipFuncSetAttribute((const void*)rank_recheck_dist_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds_bytes<MODE>())) \
+                return set_error_hip(e, "hipFuncSetAttribute(rank_recheck_dist)"); \
+            attr = true; \
+        } \
+        hipLaunchKernelGGL(rank_recheck_dist_kernel<MODE>, dim3(1024), dim3(256), rd_lds_bytes<MODE>(), st, ra); } while (0)
+    switch (mode) {
+        case MODE_L1:
+            hipLaunchKernelGGL((rank_count_kernel<MODE_L1, true, false, true>), grid, dim3(256), 0, st, a);
+            if (int rc = check_launch("rank_counts_early")) return rc;
+            KGE_RD(MODE_L1); break;
+        case MODE_L1_SUB:
+            hipLaunchKernelGGL((rank_count_kernel<MODE_L1_SUB, true, false, true>), grid, dim3(256), 0, st, a);
+            if (int rc = check_launch("rank_counts_early")) return rc;
+            KGE_RD(MODE_L1_SUB); break;
+        case MODE_ROT_S:
+            hipLaunchKernelGGL((rank_rot_kernel<true, false, true>), grid, dim3(256), 0, st, a);
+            if (int rc = check_launch("rank_counts_early")) return rc;
+            KGE_RD(MODE_ROT_S); break;
+        default:
+            hipLaunchKernelGGL((rank_rot_kernel<false, false, true>), grid, dim3(256), 0, st, a);
+            if (int rc = check_launch("rank_counts_early")) return rc;
+            KGE_RD(MODE_ROT_O); break;
+    }
+#undef KGE_RD
+    if (int rc = check_launch("rank_recheck_dist")) return rc;
+    hipLaunchKernelGGL(rank_screen_merge_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, st, eb.b, n, caller_counts);
+    if (int rc = check_launch("rank_early_merge")) return rc;
+    *guard_out = eb.b.counter + 1;
+    return AMDKGE_OK;
+}
+
 }  // namespace kge
 
 using namespace kge;
@@ -1225,6 +1399,14 @@ static int g_rank_kernel = 0;
 extern "C" int amdkge_set_rank_kernel(int which) {
     if (which < 0 || which > 3) return set_error(AMDKGE_EINVAL, "set_rank_kernel: 0 = automatic, 1 = VALU tile kernel, 2 = first MFMA kernel, 3 = pipelined fp32 MFMA kernel without the int8 screening pass");
     g_rank_kernel = which;
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_set_rank_early(int on, int check_l1, int check_rot, int cost) {
+    g_early.on = on ? 1 : 0;
+    if (check_l1 > 0) g_early.check_l1 = check_l1;
+    if (check_rot > 0) g_early.check_rot = check_rot;
+    if (cost > 0) g_early.cost = cost;
     return AMDKGE_OK;
 }
 
@@ -1250,7 +1432,15 @@ extern "C" int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, con
 
 extern "C" int64_t amdkge_rank_screen_workspace_bytes(const amdkge_model* m, int64_t n, int64_t n_cand) {
     if (validate_model(m) != AMDKGE_OK || n < 0 || n_cand < 0) return -1;
-    if (mode_of(m->scoring_type, AMDKGE_SIDE_S) != MODE_DOT) return 0;   // TransE / RotatE: no screening pass
+    if (mode_of(m->scoring_type, AMDKGE_SIDE_S) != MODE_DOT) {
+        // TransE / RotatE: the exact early exit (kge_rank_early.h) -- counters, counts, row flags and the list of handed-over pairs
+        // (room for ~3 % of the comparisons; a full list falls back to the plain kernel)
+        if (!g_early.on) return 0;
+        int64_t pairs = n * n_cand / 32;
+        if (pairs < (1 << 18)) pairs = 1 << 18;
+        if (pairs > (1ll << 27)) pairs = 1ll << 27;
+        return (int64_t)early_fixed_bytes(n, n_cand) + pairs * 8 + 512;
+    }
     int64_t pairs = n * n_cand / 32;   // room for ~3 % of the comparisons (typically ~0.2 % are undecided)
     if (pairs < (1 << 20)) pairs = 1 << 20;
     return (int64_t)screen_fixed_bytes(n, n_cand, row_floats(m)) + pairs * 8 + 512;
@@ -1342,6 +1532,16 @@ static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const flo
         else if (v4) hipLaunchKernelGGL((rank_count_mfma_kernel<true>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         else hipLaunchKernelGGL((rank_count_mfma_kernel<false>), grid1, dim3(256), MFMA_LDS_BYTES, st, a);
         return check_launch("rank_counts_mfma");
+    }
+    // ---- distance models: the exact early exit (kge_rank_early.h) when the caller supplied its workspace: same counts, bit for
+    //      bit; the plain kernel below then runs only as the fall-back of an overflowing list ----
+    {
+        const int64_t mcand = ent_hi - ent_lo;
+        const bool rot = mode == MODE_ROT_O || mode == MODE_ROT_S;
+        if (d_screen && g_early.on && force == 0 && v4 && (!rot || rot_exact) && a.sgn_scale < 0.f && n >= 64 && mcand >= 256 && g.U >= 64 &&
+            mcand < 0x7FFFFFFFll && n < 0x7FFFFFFFll && screen_bytes >= (int64_t)early_fixed_bytes(n, mcand) + (1 << 16)) {
+            if (int rc = run_early(mode, m, d_ent, d_ent_ids, ent_lo, mcand, n, g, w, a, grid, d_screen, (size_t)screen_bytes, &a.guard, st)) return rc;
+        }
     }
     if (rot_exact) {
         if (!v4) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: RotatE's exact mode needs the padded stored layout (k_pad = amdkge_padded_k(k)); dense rows with k % 4 != 0 only have the fast mode (amdkge_set_rank_rotate_fast)");

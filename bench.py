@@ -181,12 +181,12 @@ def cpu_eval_baseline(args, data, ent, rel, n_sample=1024, batch=256):
                       "matmul 1-vs-all + quantise + compare-count + per-triple filter loop); filter sets prebuilt, untimed"}
 
 
-def eval_bench(eng, data, rank):
-    """Filtered evaluate() of the synthetic test split, both sides: ranks/s (BASELINE.json metric, part 2)."""
+def eval_bench(eng, data, rank, triples=None):
+    """Filtered evaluate() of the synthetic test split (or of `triples`), both sides: ranks/s (BASELINE.json metric, part 2)."""
     from ampligraph_amd import _ffi
     from ampligraph_amd.datasets.filters import FilterIndex
 
-    test = data["test"]
+    test = data["test"] if triples is None else triples
     n = test.shape[0]
     dev = eng.device
     Xd = torch.as_tensor(test).to(dev)
@@ -216,12 +216,13 @@ def eval_bench(eng, data, rank):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     r = ranks.cpu().numpy()
-    scr = eng.screen_stats()   # int8 screening pass (contraction models): pairs the exact fp32 chain had to recheck (last side)
+    scr = eng.screen_stats()   # int8 screening pass (contraction models) / exact early exit (distance models): pairs the exact chain had to recheck (last side)
+    dist_model = eng.scoring_type in ("TransE", "RotatE")
     # the same evaluation through the exact fp32 matrix-core kernel alone (round 2's path): ranks must be identical, time beside it
     exact = None
     if scr is not None:
         try:
-            _ffi.check(eng.lib.amdkge_set_rank_kernel(3))
+            _ffi.check(eng.lib.amdkge_set_rank_kernel(1 if dist_model else 3))
             run()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -230,7 +231,8 @@ def eval_bench(eng, data, rank):
             torch.cuda.synchronize()
             dte = (time.perf_counter() - t0) / reps
             exact = {"ms": dte * 1e3, "ranks_per_s": 2 * n / dte, "ranks_identical_to_screened": bool(np.array_equal(ranks.cpu().numpy(), r)),
-                     "kernel": "rank_count_mfma_pipe_kernel (v_mfma_f32_32x32x2_f32) for every pair"}
+                     "kernel": ("the plain tile kernel (rank_count_kernel / rank_rot_kernel): every pair's full chain" if dist_model else
+                                "rank_count_mfma_pipe_kernel (v_mfma_f32_32x32x2_f32) for every pair")}
         finally:
             eng.lib.amdkge_set_rank_kernel(0)
     flops = 2.0 * data["n_ents"] * eng.K * n * 2
@@ -242,8 +244,11 @@ def eval_bench(eng, data, rank):
             "equivalent_fp32_tflops": flops / dt / 1e12,
             "screening": (None if scr is None else {"rechecked_pairs_per_side": scr[0], "fraction": scr[0] / float(n * data["n_ents"]),
                                                     "fell_back_to_exact_kernel": scr[1],
-                                                    "note": "int8 matrix-core pass decides the comparisons a rigorous error bound allows; the "
-                                                            "rest are recomputed with the exact fp32 chain: counts bit-identical to the fp32 kernels"}),
+                                                    "note": ("exact early exit: a pair is dropped once its monotone fp32 partial sum quantises below the positive's "
+                                                             "score; tiles with few undecided pairs hand them to a list whose chains are recomputed in full: counts "
+                                                             "bit-identical to the plain kernels" if dist_model else
+                                                             "int8 matrix-core pass decides the comparisons a rigorous error bound allows; the "
+                                                             "rest are recomputed with the exact fp32 chain: counts bit-identical to the fp32 kernels")}),
             "exact_fp32_kernel_alone": exact,
             "mrr_untrained_tables": float(np.mean(1.0 / r)), "note": "tables as left by the timed training steps"}
 
@@ -575,11 +580,13 @@ def run_config(args, ctx):
                     nxt += 1
                 opt.learning_rate = keep_lr
                 torch.cuda.synchronize()
-                e2 = eval_bench(eng, data, rank)
-                out["eval_trained_like"] = {k_: e2[k_] for k_ in ("ranks_per_s", "ms", "screening", "mrr_untrained_tables") if k_ in e2}
+                e2 = eval_bench(eng, data, rank, triples=data["train"][:data["test"].shape[0]])
+                out["eval_trained_like"] = {k_: e2[k_] for k_ in ("ranks_per_s", "ms", "n_test", "screening", "exact_fp32_kernel_alone", "mrr_untrained_tables") if k_ in e2}
                 out["eval_trained_like"]["mrr"] = out["eval_trained_like"].pop("mrr_untrained_tables")
-                out["eval_trained_like"]["note"] = ("tables after 300 more steps of the same workload at lr 1e-2 (the synthetic graph is uniform-random: "
-                                                    "MRR stays noise, but the score distribution is a trained model's: norms grown, positives' scores pushed up)")
+                out["eval_trained_like"]["note"] = ("tables after 300 more steps of the same workload at lr 1e-2, evaluated on the first n_test TRAINING triples (filter = "
+                                                    "train + valid + test): the synthetic graph is uniform-random, so held-out triples score like random candidates "
+                                                    "whatever the training; the triples the model has fitted are where its positives rank near the top, as a trained "
+                                                    "model's held-out positives do on a real graph")
         if not ctx.multi and not args.no_cpu_baseline and not big and data["train"] is not None and not opt.lazy:
             out["cpu_baseline"] = cpu_baseline(args, data, ent0, rel0)
             if not args.no_eval and data["test"] is not None:

@@ -286,6 +286,15 @@ int amdkge_set_rank_kernel(int which);
  *   1 = FAST: the hardware's 1-ulp v_sqrt_f32 (about 1.3x faster; ranks may differ from the exact mode only where a
  *       quantised comparison at the int32(score * 1000) boundary is decided by the last bit of a modulus). */
 int amdkge_set_rank_rotate_fast(int fast);
+/* TransE / RotatE: the EXACT EARLY EXIT of the count pass behind amdkge_rank_counts_screened (kge_rank_early.h).  Their scores are
+ * -sum of non-negative terms in unit order, so the fp32 partial sums only grow: a pair whose partial sum already quantises below
+ * the positive's score is decided for good, with no error bound.  A tile whose undecided pairs have become few hands them to a
+ * list, ends, and the list's pairs are recomputed by the full chain -- counts identical to amdkge_rank_counts, bit for bit (rows
+ * with non-finite / huge values are exempt; a full list falls back to the plain kernel on the device).  Process-wide testing /
+ * tuning aid: on = 0 switches it off (amdkge_rank_screen_workspace_bytes then returns 0 for these models); check_l1 / check_rot =
+ * stages of 16 units between two checks (defaults 4 / 2), cost = how many tile-kernel pair chains a re-checked pair is priced at
+ * when deciding whether a tile ends (default 6); arguments <= 0 keep the current value. */
+int amdkge_set_rank_early(int on, int check_l1, int check_rot, int cost);
 int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d_rel,
                        const int32_t* d_triples, int64_t n, int32_t side,
                        const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,
@@ -295,9 +304,11 @@ int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d
  * forms the integer dot products exactly, a rigorous per-pair error bound (the fp32 chain's own rounding + the fixed-point
  * rounding + the dropped limb products) decides every comparison whose outcome it cannot change, and the rest -- a fraction of a
  * per cent -- are recomputed with the exact fp32 chain.  d_screen: amdkge_rank_screen_workspace_bytes(m, n, ent_hi - ent_lo)
- * bytes (0 = this model has no screening pass); NULL / too small, TransE / RotatE, tiny problems: the call is amdkge_rank_counts.
+ * bytes (0 = nothing to gain for this model / size); NULL / too small or tiny problems: the call is amdkge_rank_counts.  With the
+ * same workspace TransE / RotatE take their exact early exit (amdkge_set_rank_early above).
  * After the stream is synchronised the first int32 of d_screen (aligned up to 256 bytes) holds the number of rechecked pairs,
- * the second is non-zero if the recheck list overflowed and the call fell back to the exact kernel. */
+ * the second is non-zero if the recheck list overflowed and the call fell back to the exact kernel (distance models: the third
+ * counts the tiles that ended early). */
 int64_t amdkge_rank_screen_workspace_bytes(const amdkge_model* m, int64_t n, int64_t n_cand);
 int amdkge_rank_counts_screened(const amdkge_model* m, const float* d_ent, const float* d_rel,
                                 const int32_t* d_triples, int64_t n, int32_t side,

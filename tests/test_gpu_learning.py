@@ -86,7 +86,7 @@ def _golden():
 # replaying the schedule from tables nudged by one ulp parts from ITSELF by sd 0.0038 (TransE / nll), 0.0009 (TransE / pairwise),
 # 0.0024 (RotatE / self_adversarial), 0.0127 (RotatE / nll) per seed.  What the bar can mean for them is that the GPU path has no
 # BIAS: the MEAN filtered MRR over many seeds within +-0.002 of the oracle's mean over the same seeds -- with enough seeds that
-# the standard error of the mean distance is a third of the bar (tests/golden/make_learning_golden.py: 64 / 64 / 64 / 384).  The
+# the standard error of the mean distance is under a third of the bar (tests/golden/make_learning_golden.py: 512 / 512 / 512 / 2048 seeds).  The
 # oracle's side is frozen in tests/golden/learning_mrr_v1.npz (re-derived on the CPU by tests/test_golden.py, and by the
 # per-seed test above for seeds 0..2).
 @pytest.mark.parametrize("model,loss", [("TransE", "nll"), ("TransE", "pairwise"), ("RotatE", "self_adversarial"), ("RotatE", "nll")])

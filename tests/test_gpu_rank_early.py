@@ -1,0 +1,171 @@
+"""The exact early exit of evaluate()'s count pass for the distance models (kge_rank_early.h): counts bit-identical to the plain
+tile kernels (amdkge_set_rank_kernel(1): rank_count_kernel / rank_rot_kernel, themselves held bit for bit to the declared-order
+oracle in test_gpu_fullsize) -- on untrained tables (nothing is decided early), on tables where the positives score near the
+top (almost everything is), with ties, zeros, denormals, huge / inf / NaN rows, RotatE units of modulus exactly 0, candidate
+subsets and ranges, and an overflowing hand-over list."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kge_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _counts(eng, gpu_lib, Xd, side, which, **kw):
+    from ampligraph_amd import _ffi
+
+    try:
+        _ffi.check(gpu_lib.amdkge_set_rank_kernel(which))
+        _, counts, _ = eng.rank_side(Xd, side, "worst", **kw)
+        stats = None
+        if getattr(eng, "_last_screen", None) is not None:
+            v = eng._last_screen[:12].view(torch.int32).cpu().numpy()
+            stats = (int(v[0]), bool(v[1]), int(v[2]))   # pairs handed over, fell back, tiles ended early
+        return counts.cpu().numpy().copy(), stats
+    finally:
+        gpu_lib.amdkge_set_rank_kernel(0)
+
+
+def _tables(model, k, N, R, n, kind, rng):
+    """(ent, rel, X): `n` test triples over N + n entities; kind 'trained' plants every triple's object next to where the model
+    puts it (o = s + p resp. s o r, plus noise), so the positive scores near the top from both sides."""
+    K = O.internal_k(model, k)
+    NT = N + n
+    if kind == "ties":
+        ent = (rng.integers(-4, 5, size=(NT, K)) / 8.0).astype(np.float32)
+        rel = (rng.integers(-2, 3, size=(R, K)) / 4.0).astype(np.float32)
+    else:
+        ent = (rng.normal(size=(NT, K)) * 0.3).astype(np.float32)
+        rel = (rng.normal(size=(R, K)) * 0.3).astype(np.float32)
+    X = np.stack([rng.integers(0, N, n), rng.integers(0, R, n), rng.integers(0, N, n)], 1).astype(np.int32)
+    if kind == "trained":
+        s, p = ent[X[:, 0]], rel[X[:, 1]]
+        if model == "TransE":
+            tgt = s + p
+        else:
+            phi = (p[:, :k] / np.float32(O.rotate_phase_divisor(k, R))).astype(np.float64)
+            sr, si = s[:, :k].astype(np.float64), s[:, k:].astype(np.float64)
+            tgt = np.concatenate([sr * np.cos(phi) - si * np.sin(phi), sr * np.sin(phi) + si * np.cos(phi)], 1)
+        ent[N:] = (tgt + rng.normal(size=tgt.shape) * 0.03).astype(np.float32)
+        X[:, 2] = N + np.arange(n)
+    return ent, rel, X
+
+
+@pytest.mark.parametrize("model,k,N,n", [("TransE", 200, 14505, 1500), ("TransE", 64, 3000, 400), ("TransE", 350, 5000, 300),
+                                          ("RotatE", 200, 14505, 600), ("RotatE", 64, 2500, 300), ("RotatE", 101, 1500, 200)])
+@pytest.mark.parametrize("kind", ["gaussian", "trained", "ties"])
+def test_early_exit_counts_equal_plain_counts(gpu_lib, model, k, N, n, kind):
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+
+    R = 9
+    rng = np.random.default_rng(k + N)
+    ent, rel, X = _tables(model, k, N, R, n, kind, rng)
+    eng = KgeEngine(model, k, ent.shape[0], R, max_rel_size=R)
+    eng.set_tables(ent, rel)
+    Xd = torch.as_tensor(X).cuda()
+    for side in (_ffi.SIDE_S, _ffi.SIDE_O):
+        plain, st0 = _counts(eng, gpu_lib, Xd, side, 1)
+        early, st = _counts(eng, gpu_lib, Xd, side, 0)
+        assert np.array_equal(early, plain), (side, int((early != plain).sum()), st)
+        assert st is not None and not st[1], st
+        if kind == "trained":   # the exit really happens, and hands over a small fraction of the comparisons
+            tiles = ((n + 63) // 64) * ((ent.shape[0] + 63) // 64)
+            assert st[2] > 0.5 * tiles and st[0] < 0.05 * n * ent.shape[0], (st, tiles)
+        print("early exit", model, k, kind, side, "pairs handed over", st[0], "of", n * ent.shape[0], "tiles ended early", st[2])
+
+
+@pytest.mark.parametrize("model,k", [("TransE", 128), ("RotatE", 96)])
+def test_early_exit_bad_rows_subsets_and_ranges(gpu_lib, model, k):
+    """Rows with huge / inf / NaN / denormal / zero values (never decided early: their chains could stop being monotone), a query
+    that coincides with a candidate in every unit (RotatE: modulus exactly 0, the tile's slow path), candidate id lists and ranges."""
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+
+    N, R, n = 5000, 5, 500
+    rng = np.random.default_rng(7)
+    ent, rel, X = _tables(model, k, N, R, n, "trained", rng)
+    ent[17, 5] = np.inf
+    ent[99, :] = np.nan
+    ent[200, :] = 1e-42
+    ent[201, :] = 0.0
+    ent[300, 7] = 3e30
+    ent[301, :] = -2e19
+    rel[1, :] = 0.0                      # phase 0 (RotatE) / zero translation (TransE): s o r = s, so a candidate equal to s scores exactly 0
+    X[:6, 0] = [17, 99, 200, 201, 300, 301]
+    X[6:12, 2] = [17, 99, 200, 201, 300, 301]
+    X[12:40, 1] = 1
+    eng = KgeEngine(model, k, ent.shape[0], R, max_rel_size=R)
+    eng.set_tables(ent, rel)
+    Xd = torch.as_tensor(X).cuda()
+    M = ent.shape[0]
+    ids = torch.as_tensor(rng.permutation(M)[:3000].astype(np.int32)).cuda()
+    for kw in (dict(), dict(ent_ids=ids), dict(ent_lo=1000, ent_hi=5200), dict(ent_ids=ids, ent_lo=128, ent_hi=2900)):
+        for side in (_ffi.SIDE_S, _ffi.SIDE_O):
+            plain, _ = _counts(eng, gpu_lib, Xd, side, 1, **kw)
+            early, st = _counts(eng, gpu_lib, Xd, side, 0, **kw)
+            assert np.array_equal(early, plain), (list(kw), side, int((early != plain).sum()), st)
+            assert st is not None and not st[1]
+
+
+@pytest.mark.parametrize("model,k", [("TransE", 200), ("RotatE", 128)])
+def test_early_exit_overflowing_list_falls_back(gpu_lib, model, k):
+    """A hand-over list too small for the call (a deliberately tiny workspace through the C ABI): the device-side flag sends the
+    whole call to the guarded plain kernel -- same counts, no host round trip."""
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine, _ptr, _stream
+
+    N, R, n = 6000, 7, 1024
+    rng = np.random.default_rng(5)
+    ent, rel, X = _tables(model, k, N, R, n, "trained", rng)
+    eng = KgeEngine(model, k, ent.shape[0], R, max_rel_size=R)
+    eng.set_tables(ent, rel)
+    Xd = torch.as_tensor(X).cuda()
+    M = ent.shape[0]
+    plain, _ = _counts(eng, gpu_lib, Xd, _ffi.SIDE_O, 1)
+    try:
+        _ffi.check(gpu_lib.amdkge_set_rank_early(1, 1, 1, 1))   # tiles end at their first check with up to 512 pairs each: a long list
+        full, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_O, 0)
+        assert np.array_equal(full, plain) and not st[1] and st[0] > 8200, st
+        need = int(gpu_lib.amdkge_rank_screen_workspace_bytes(C.byref(eng.model), n, M))
+        small = need - (max(1 << 18, n * M // 32) - 8200) * 8          # room for 8 200 pairs only
+        buf = torch.empty(small, dtype=torch.uint8, device="cuda")
+        counts = torch.zeros(n, 2, dtype=torch.int32, device="cuda")
+        work = eng._workspace(n)
+        _ffi.check(gpu_lib.amdkge_rank_counts_screened(C.byref(eng.model), _ptr(eng.ent), _ptr(eng.rel), _ptr(Xd), n, _ffi.SIDE_O, None, 0, M,
+                                                       _ptr(counts), _ptr(work), _ptr(buf), small, _stream()))
+        torch.cuda.synchronize()
+        flag = buf[:8].view(torch.int32).cpu().numpy()
+        assert flag[1] != 0 and flag[0] > 8200
+        assert np.array_equal(counts.cpu().numpy(), plain)
+    finally:
+        gpu_lib.amdkge_set_rank_early(1, 4, 2, 6)
+
+
+def test_early_exit_switch_and_settings(gpu_lib):
+    """amdkge_set_rank_early: off = no workspace is asked for and the plain kernels run; check interval / cost change when tiles end,
+    never what is counted."""
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+
+    N, R, n, k = 4000, 4, 300, 128
+    rng = np.random.default_rng(9)
+    ent, rel, X = _tables("TransE", k, N, R, n, "trained", rng)
+    eng = KgeEngine("TransE", k, ent.shape[0], R, max_rel_size=R)
+    eng.set_tables(ent, rel)
+    Xd = torch.as_tensor(X).cuda()
+    plain, _ = _counts(eng, gpu_lib, Xd, _ffi.SIDE_S, 1)
+    try:
+        for check, cost in ((1, 1), (2, 6), (8, 50)):
+            _ffi.check(gpu_lib.amdkge_set_rank_early(1, check, check, cost))
+            early, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_S, 0)
+            assert np.array_equal(early, plain) and st is not None, (check, cost, st)
+        _ffi.check(gpu_lib.amdkge_set_rank_early(0, 0, 0, 0))
+        assert int(gpu_lib.amdkge_rank_screen_workspace_bytes(C.byref(eng.model), n, ent.shape[0])) == 0
+        off, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_S, 0)
+        assert np.array_equal(off, plain) and st is None
+    finally:
+        gpu_lib.amdkge_set_rank_early(1, 4, 2, 6)

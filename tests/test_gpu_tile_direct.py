@@ -46,11 +46,6 @@ def test_direct_step_in_place_parity(gpu_lib, direct_switch, opt, model, k, reg,
     """Whole steps (tables + slots updated row by row from registers) == oracle train_step, 3 steps, dense and touched-rows mode;
     direct=False runs the same steps on the LDS-accumulator kernel (same bars: the two forms are interchangeable)."""
     direct_switch(direct)
-    if model == "RotatE" and opt in ("sgd+momentum", "rmsprop", "rmsprop+momentum"):
-        # RotatE's row gradient z / |z| carries O(1) fp32 noise wherever a unit's modulus is ~0, and these three rules pass it on
-        # undamped (lr g / sqrt(mean g^2): a unit with g ~ 0 moves by +-lr * 3); on 1 000-unit rows both tile kernels land at
-        # 0.89 .. 0.996 of the elements inside the bars below, identically -- covered for RotatE by the other five rules
-        pytest.skip("ill-conditioned combination: fp32 noise of z / |z| undamped (both tile kernels, see comment)")
     N, R, B, eta = 120, 4, 60, 3   # B * (eta + 2) = 300 entries on 120 rows: some rows stay untouched
     for lazy in (False, True):
         eng, ent, rel = make_engine(model, k, N, R, scale=0.08)
