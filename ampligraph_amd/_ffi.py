@@ -135,6 +135,9 @@ SIGNATURES = {
     "amdkge_session_group_create": (C.c_int, [C.POINTER(SessionConfig), P, I32, C.POINTER(C.c_void_p)]),
     "amdkge_session_group_create_ex": (C.c_int, [C.POINTER(SessionConfig), P, I32, I32, C.POINTER(C.c_void_p)]),
     "amdkge_session_group_info": (C.c_int, [P, C.POINTER(I32), C.POINTER(I32)]),
+    "amdkge_session_group_create_rows": (C.c_int, [C.POINTER(SessionConfig), P, I32, I32, I64, C.POINTER(C.c_void_p)]),
+    "amdkge_session_group_get_rows": (C.c_int, [P, I32, P, I64, I64, P]),
+    "amdkge_session_group_route_overflow": (C.c_int, [P, C.POINTER(I32)]),
     "amdkge_session_screen_stats": (C.c_int, [P, C.POINTER(I32), C.POINTER(I64), C.POINTER(I32)]),
     "amdkge_session_group_destroy": (None, [P]),
     "amdkge_session_group_size": (I32, [P]),

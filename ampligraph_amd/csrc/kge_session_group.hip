@@ -30,12 +30,14 @@ namespace {
 
 // the slice of rccl.h this file needs (ABI of RCCL 2.x: ncclResult_t / ncclDataType_t / ncclRedOp_t are plain enums)
 typedef void* ncclComm_t;
-enum { kNcclSuccess = 0, kNcclFloat = 7, kNcclSum = 0 };
+enum { kNcclSuccess = 0, kNcclInt32 = 2, kNcclFloat = 7, kNcclSum = 0 };
 struct Rccl {
     void* handle = nullptr;
     int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*GetVersion)(int*) = nullptr;
@@ -56,7 +58,7 @@ int load_rccl(Rccl& r) {
 #define KGE_SYM(field, sym) do { *(void**)(&r.field) = dlsym(r.handle, sym); if (!r.field) return set_error(AMDKGE_ERCCL, "session_group: librccl lacks " sym); } while (0)
     KGE_SYM(CommInitAll, "ncclCommInitAll"); KGE_SYM(CommDestroy, "ncclCommDestroy"); KGE_SYM(AllReduce, "ncclAllReduce");
     KGE_SYM(GroupStart, "ncclGroupStart"); KGE_SYM(GroupEnd, "ncclGroupEnd"); KGE_SYM(GetErrorString, "ncclGetErrorString");
-    KGE_SYM(GetVersion, "ncclGetVersion");
+    KGE_SYM(GetVersion, "ncclGetVersion"); KGE_SYM(Send, "ncclSend"); KGE_SYM(Recv, "ncclRecv");
 #undef KGE_SYM
     return AMDKGE_OK;
 }
@@ -86,10 +88,31 @@ struct amdkge_session_group {
     Rccl rccl;
     bool same_device = false;
     int32_t flags = 0;              // AMDKGE_GROUP_*
+    // ---- AMDKGE_GROUP_ROWS: the entity table row-sharded over the replicas (see the ROWS section below) ----
+    bool rows = false;
+    int64_t N = 0, rows_per = 0, cap = 0, max_share = 0;   // global entity count, rows per shard, request slots per peer, positives per replica and step at most
+    uint64_t step = 0;
+    int64_t iteration = 0;
+    struct Shard {
+        int64_t lo = 0, n_local = 0;
+        int32_t *tri = nullptr, *negs = nullptr, *xl = nullptr, *nl = nullptr, *send = nullptr, *recv = nullptr, *counts = nullptr;
+        void* route_work = nullptr;
+        float *rows_out = nullptr, *back = nullptr;
+        double* acc3 = nullptr;     // [data loss, entity-shard regulariser, relation regulariser]
+    };
+    std::vector<Shard> sh;
 };
 
 extern "C" void amdkge_session_group_destroy(amdkge_session_group* g) {
     if (!g) return;
+    for (size_t d = 0; d < g->sh.size() && d < g->rep.size(); ++d) {
+        (void)hipSetDevice(g->rep[d]->cfg.device);
+        if (g->rep[d]->st) (void)hipStreamSynchronize(g->rep[d]->st);
+        amdkge_session_group::Shard& h = g->sh[d];
+        for (void* p : {(void*)h.tri, (void*)h.negs, (void*)h.xl, (void*)h.nl, (void*)h.send, (void*)h.recv, (void*)h.counts, h.route_work,
+                        (void*)h.rows_out, (void*)h.back, (void*)h.acc3})
+            if (p) (void)hipFree(p);
+    }
     for (size_t d = 0; d < g->comm.size(); ++d)
         if (g->comm[d] && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(g->comm[d]);
     for (size_t d = 0; d < g->ev.size(); ++d)
@@ -114,11 +137,10 @@ extern "C" int amdkge_session_group_info(const amdkge_session_group* g, int32_t*
     return AMDKGE_OK;
 }
 
-extern "C" int amdkge_session_group_create_ex(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
-                                              amdkge_session_group** out) {
-    if (!cfg || !out || n_gpus < 1 || n_gpus > 16) return set_error(AMDKGE_EINVAL, "session_group_create: bad arguments (1 <= n_gpus <= 16)");
-    if (flags & ~AMDKGE_GROUP_FORCE_RCCL) return set_error(AMDKGE_EINVAL, "session_group_create_ex: unknown flag");
-    *out = nullptr;
+// replicas (one session per entry of `devices`, each with `n_ents_alloc` entity rows), events, and the RCCL communicators when the
+// replicas sit on distinct devices (or one replica is forced through RCCL)
+static int group_create(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags, int64_t n_ents_alloc,
+                        amdkge_session_group** out) {
     amdkge_session_group* g = new amdkge_session_group();
     g->flags = flags;
     auto fail = [&](int rc) { amdkge_session_group_destroy(g); return rc; };
@@ -126,6 +148,7 @@ extern "C" int amdkge_session_group_create_ex(const amdkge_session_config* cfg, 
     for (int d = 0; d < n_gpus; ++d) {
         amdkge_session_config c = *cfg;
         c.device = devices ? devices[d] : d;
+        c.model.n_ents = n_ents_alloc;
         if (d > 0 && c.device != g->rep[0]->cfg.device) same = false;
         for (int q = 0; q < d; ++q) if (g->rep[q]->cfg.device == c.device) distinct = false;
         amdkge_session* s = nullptr;
@@ -150,6 +173,14 @@ extern "C" int amdkge_session_group_create_ex(const amdkge_session_config* cfg, 
     return AMDKGE_OK;
 }
 
+extern "C" int amdkge_session_group_create_ex(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
+                                              amdkge_session_group** out) {
+    if (!cfg || !out || n_gpus < 1 || n_gpus > 16) return set_error(AMDKGE_EINVAL, "session_group_create: bad arguments (1 <= n_gpus <= 16)");
+    if (flags & ~AMDKGE_GROUP_FORCE_RCCL) return set_error(AMDKGE_EINVAL, "session_group_create_ex: unknown flag (row sharding: amdkge_session_group_create_rows)");
+    *out = nullptr;
+    return group_create(cfg, devices, n_gpus, flags, cfg->model.n_ents, out);
+}
+
 extern "C" int32_t amdkge_session_group_size(const amdkge_session_group* g) { return g ? (int32_t)g->rep.size() : 0; }
 
 extern "C" int amdkge_session_group_replica(amdkge_session_group* g, int32_t i, amdkge_session** out) {
@@ -158,8 +189,12 @@ extern "C" int amdkge_session_group_replica(amdkge_session_group* g, int32_t i, 
     return AMDKGE_OK;
 }
 
+static int rows_set_rows(amdkge_session_group* g, int32_t table, int64_t row0, int64_t nrows, const float* host);
+static int rows_train_step(amdkge_session_group* g, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out);
+
 extern "C" int amdkge_session_group_set_rows(amdkge_session_group* g, int32_t table, int64_t row0, int64_t nrows, const float* host) {
     if (!g) return set_error(AMDKGE_EINVAL, "session_group_set_rows: NULL group");
+    if (g->rows) return rows_set_rows(g, table, row0, nrows, host);
     for (amdkge_session* s : g->rep) KGE_RC(amdkge_session_set_rows(s, table, row0, nrows, host));
     return AMDKGE_OK;
 }
@@ -201,6 +236,7 @@ static int group_sum(amdkge_session_group* g, float* (*ptr_of)(amdkge_session*),
 
 extern "C" int amdkge_session_group_train_step(amdkge_session_group* g, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out) {
     if (!g || B < 0) return set_error(AMDKGE_EINVAL, "session_group_train_step: bad arguments");
+    if (g->rows) return rows_train_step(g, triples, B, focus_w, loss_out);
     const int n = (int)g->rep.size();
     if (n == 1 && g->comm.empty()) return amdkge_session_train_step(g->rep[0], triples, B, focus_w, loss_out);   // the complete fused step
     if (loss_out) *loss_out = 0.0;
@@ -250,5 +286,321 @@ extern "C" int amdkge_session_group_train_step(amdkge_session_group* g, const in
         if (fell_back)
             return set_error(AMDKGE_EUNSUPPORTED, "session_group_train_step: deterministic mode -- a tile received more entries than its sort buffer holds (a very hot row); this step's sums were not all added in canonical order");
     }
+    return AMDKGE_OK;
+}
+
+// =====================================================================================================================================
+// AMDKGE_GROUP_ROWS -- the entity table ROW-SHARDED over the replicas of a group (BASELINE.json configs[3], configs[4]; the C-ABI
+// form of ampligraph_amd/sharded.py ShardedStepLoop, for a host without torch).  Replica d owns the contiguous id range
+// [d * rows_per, min(N, (d + 1) * rows_per)), rows_per = ceil(N / W) -- the reference's own bucket rule, owner(e) = e // ceil(N / G)
+// (datasets/graph_partitioner.py:339-344) -- with the optimizer state of those rows; the relation table is replicated.  What a
+// step replaces is the reference's partition loop (ScoringBasedEmbeddingModel.py:227,259-261 for training), with the partitions
+// living on different GPUs:
+//   1. replica d takes the share [B d / W, B (d + 1) / W) of the global batch; amdkge_shard_route classifies every s / o id of the
+//      share (and, with global negatives, of its corruptions) by owner ON THE DEVICE, de-duplicates remote ids and gives each a
+//      request slot at its owner (cap slots per peer: equal, host-known splits -- nothing is copied to the host);
+//   2. the request lists are exchanged (grouped ncclSend / ncclRecv, one slice per peer: every xGMI link carries one slice at once),
+//      owners gather the rows (amdkge_gather_rows), the rows travel back and land BEHIND the shard in the same allocation, where
+//      the re-indexed batch finds them: the fused train kernels run unchanged on "a table of n_local + W cap rows";
+//   3. the kernels run in their gradient-only form; gradient rows of the fetched copies go home by the reverse route and are added
+//      at the owner (amdkge_scatter_add_rows); the relation gradient is all-reduced (ncclAllReduce);
+//   4. every replica sweeps ITS rows and the replicated relation table.
+// Negatives: shard-local by default (replacement ids from the replica's own range -- what the reference's partitioned training
+// does; only <= 2 remote rows per positive move); AMDKGE_GROUP_GLOBAL_NEGATIVES reproduces one GPU's corruptions exactly (the same
+// Philox rows over all N ids), which is what the parity test compares with a single session.  Replicas on ONE device exchange by
+// device-to-device copies ordered with events -- everything but the RCCL calls, for the one-GPU box.
+namespace {
+
+typedef amdkge_session_group::Shard Shard;
+
+int64_t table_rows_global(const amdkge_session_group* g, int t) {
+    return (t == AMDKGE_TABLE_ENT || t == AMDKGE_TABLE_ENT_SLOT0 || t == AMDKGE_TABLE_ENT_SLOT1) ? g->N : g->rep[0]->cfg.model.n_rels;
+}
+bool is_entity_table(int t) { return t == AMDKGE_TABLE_ENT || t == AMDKGE_TABLE_ENT_SLOT0 || t == AMDKGE_TABLE_ENT_SLOT1; }
+
+// all_to_all with equal splits: slice q of `send(d)` (elems elements of `bytes_per` bytes) -> slice d of `recv(q)`, stream-ordered on
+// every replica's stream.  The self slice is a device-to-device copy; the others go through RCCL or, for same-device replicas, copies
+// on the RECEIVER's stream behind an event of the sender's stream.
+template <class FS, class FR>
+int exchange(amdkge_session_group* g, FS send, FR recv, int64_t elems, int bytes_per, int nccl_type) {
+    const int W = (int)g->rep.size();
+    const size_t slice = (size_t)elems * bytes_per;
+    if (slice == 0) return AMDKGE_OK;
+    for (int d = 0; d < W; ++d) {
+        KGE_HIP(hipSetDevice(g->rep[d]->cfg.device), "hipSetDevice");
+        KGE_HIP(hipMemcpyAsync((char*)recv(d) + (size_t)d * slice, (const char*)send(d) + (size_t)d * slice, slice, hipMemcpyDeviceToDevice, g->rep[d]->st),
+                "hipMemcpyAsync(self slice)");
+    }
+    if (W == 1) return AMDKGE_OK;
+    if (g->same_device) {
+        for (int d = 0; d < W; ++d) KGE_HIP(hipEventRecord(g->ev[d], g->rep[d]->st), "hipEventRecord");
+        for (int q = 0; q < W; ++q)
+            for (int d = 0; d < W; ++d) {
+                if (d == q) continue;
+                KGE_HIP(hipStreamWaitEvent(g->rep[q]->st, g->ev[d], 0), "hipStreamWaitEvent");
+                KGE_HIP(hipMemcpyAsync((char*)recv(q) + (size_t)d * slice, (const char*)send(d) + (size_t)q * slice, slice, hipMemcpyDeviceToDevice, g->rep[q]->st),
+                        "hipMemcpyAsync(peer slice)");
+            }
+        // a sender must not reuse its buffer before the receivers have read it: the receivers' copies are joined back
+        for (int q = 0; q < W; ++q) KGE_HIP(hipEventRecord(g->ev[q], g->rep[q]->st), "hipEventRecord");
+        for (int d = 0; d < W; ++d)
+            for (int q = 0; q < W; ++q)
+                if (q != d) KGE_HIP(hipStreamWaitEvent(g->rep[d]->st, g->ev[q], 0), "hipStreamWaitEvent");
+        return AMDKGE_OK;
+    }
+    if (int rc = g->rccl.GroupStart()) return rccl_error(g->rccl, rc, "ncclGroupStart");
+    for (int d = 0; d < W; ++d)
+        for (int q = 0; q < W; ++q) {
+            if (q == d) continue;
+            int rc = g->rccl.Send((const char*)send(d) + (size_t)q * slice, (size_t)elems, nccl_type, q, g->comm[(size_t)d], g->rep[d]->st);
+            if (!rc) rc = g->rccl.Recv((char*)recv(d) + (size_t)q * slice, (size_t)elems, nccl_type, q, g->comm[(size_t)d], g->rep[d]->st);
+            if (rc) { (void)g->rccl.GroupEnd(); return rccl_error(g->rccl, rc, "ncclSend/ncclRecv"); }
+        }
+    if (int rc = g->rccl.GroupEnd()) return rccl_error(g->rccl, rc, "ncclGroupEnd");
+    return AMDKGE_OK;
+}
+
+}  // namespace
+
+extern "C" int amdkge_session_group_create_rows(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
+                                                int64_t max_batch, amdkge_session_group** out) {
+    if (!cfg || !out || n_gpus < 1 || n_gpus > 16) return set_error(AMDKGE_EINVAL, "session_group_create_rows: bad arguments (1 <= n_gpus <= 16)");
+    if (flags & ~(AMDKGE_GROUP_FORCE_RCCL | AMDKGE_GROUP_ROWS | AMDKGE_GROUP_GLOBAL_NEGATIVES)) return set_error(AMDKGE_EINVAL, "session_group_create_rows: unknown flag");
+    if (max_batch < 1) return set_error(AMDKGE_EINVAL, "session_group_create_rows: max_batch must be >= 1");
+    if (cfg->model.n_ents < n_gpus) return set_error(AMDKGE_EINVAL, "session_group_create_rows: fewer entities than replicas");
+    if (cfg->flags & AMDKGE_TILED_DETERMINISTIC) return set_error(AMDKGE_EUNSUPPORTED, "session_group_create_rows: deterministic mode is not offered for row-sharded groups");
+    *out = nullptr;
+    const int W = n_gpus;
+    const int64_t N = cfg->model.n_ents, rows_per = (N + W - 1) / W;
+    if ((int64_t)(W - 1) * rows_per >= N) return set_error(AMDKGE_EINVAL, "session_group_create_rows: the last replica would own no rows (use fewer replicas)");
+    const bool global = (flags & AMDKGE_GROUP_GLOBAL_NEGATIVES) != 0;
+    const int64_t share = (max_batch + W - 1) / W;
+    // request slots per peer: the worst case -- every id of a replica's share remote, distinct and owned by ONE peer (ordinary for
+    // first-seen ids in sequential batches), bounded by the rows a peer owns
+    int64_t cap = share * (2 + (global ? cfg->eta : 0));
+    if (cap > rows_per) cap = rows_per;
+    if (cap < 1) cap = 1;
+    if (cap > 0x7FFFFFFFll / (W > 1 ? W : 1)) return set_error(AMDKGE_EUNSUPPORTED, "session_group_create_rows: request lists too long (max_batch x eta)");
+    amdkge_session_group* g = nullptr;
+    if (int rc = group_create(cfg, devices, n_gpus, flags & AMDKGE_GROUP_FORCE_RCCL, rows_per + (int64_t)W * cap, &g)) return rc;
+    g->flags = flags | AMDKGE_GROUP_ROWS;
+    g->rows = true; g->N = N; g->rows_per = rows_per; g->cap = cap; g->max_share = share;
+    g->sh.assign((size_t)W, Shard());
+    auto fail = [&](int rc) { amdkge_session_group_destroy(g); return rc; };
+    const int64_t nneg = global ? share * cfg->eta : 0;
+    const int64_t rw = amdkge_shard_route_workspace_bytes(share, nneg);
+    if (rw < 0) return fail(set_error(AMDKGE_EUNSUPPORTED, "session_group_create_rows: max_batch too large for one route call"));
+    for (int d = 0; d < W; ++d) {
+        amdkge_session* s = g->rep[d];
+        Shard& h = g->sh[(size_t)d];
+        h.lo = (int64_t)d * rows_per < N ? (int64_t)d * rows_per : N;
+        const int64_t hi = (int64_t)(d + 1) * rows_per < N ? (int64_t)(d + 1) * rows_per : N;
+        h.n_local = hi - h.lo;
+        if (hipError_t e = hipSetDevice(s->cfg.device)) return fail(set_error_hip(e, "hipSetDevice"));
+        auto alloc = [&](void** p, size_t bytes) -> int { const hipError_t e = hipMalloc(p, bytes ? bytes : 16); return e == hipSuccess ? AMDKGE_OK : set_error_hip(e, "hipMalloc(row-shard scratch)"); };
+        int rc = alloc((void**)&h.tri, (size_t)share * 12);
+        if (!rc) rc = alloc((void**)&h.negs, (size_t)nneg * 12);
+        if (!rc) rc = alloc((void**)&h.xl, (size_t)share * 12);
+        if (!rc) rc = alloc((void**)&h.nl, (size_t)nneg * 12);
+        if (!rc) rc = alloc((void**)&h.send, (size_t)W * cap * 4);
+        if (!rc) rc = alloc((void**)&h.recv, (size_t)W * cap * 4);
+        if (!rc) rc = alloc((void**)&h.counts, (size_t)(W + 1) * 4);
+        if (!rc) rc = alloc(&h.route_work, (size_t)rw);
+        if (!rc) rc = alloc((void**)&h.rows_out, (size_t)W * cap * s->Ks * 4);
+        if (!rc) rc = alloc((void**)&h.back, (size_t)W * cap * s->Ks * 4);
+        if (!rc) rc = alloc((void**)&h.acc3, 3 * sizeof(double));
+        if (rc) return fail(rc);
+        if (hipError_t e = hipMemsetAsync(h.counts, 0, (size_t)(W + 1) * 4, s->st)) return fail(set_error_hip(e, "hipMemsetAsync"));
+        if (hipError_t e = hipStreamSynchronize(s->st)) return fail(set_error_hip(e, "hipStreamSynchronize"));
+    }
+    *out = g;
+    return AMDKGE_OK;
+}
+
+// rows [row0, row0 + nrows) of a table in GLOBAL numbering: entity tables go to their owners, relation tables to every replica
+static int rows_set_rows(amdkge_session_group* g, int32_t table, int64_t row0, int64_t nrows, const float* host) {
+    if (table < 0 || table > 5) return set_error(AMDKGE_EINVAL, "session_group_set_rows: no such table");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > table_rows_global(g, table)) return set_error(AMDKGE_EINVAL, "session_group_set_rows: rows outside the table");
+    if (nrows == 0) return AMDKGE_OK;
+    if (!host) return set_error(AMDKGE_EINVAL, "session_group_set_rows: NULL host buffer");
+    if (!is_entity_table(table)) {
+        for (amdkge_session* s : g->rep) KGE_RC(amdkge_session_set_rows(s, table, row0, nrows, host));
+        return AMDKGE_OK;
+    }
+    const int K = g->rep[0]->K;
+    for (size_t d = 0; d < g->rep.size(); ++d) {
+        const Shard& h = g->sh[d];
+        const int64_t a = row0 > h.lo ? row0 : h.lo, b = (row0 + nrows) < (h.lo + h.n_local) ? (row0 + nrows) : (h.lo + h.n_local);
+        if (b > a) KGE_RC(amdkge_session_set_rows(g->rep[d], table, a - h.lo, b - a, host + (a - row0) * (int64_t)K));
+    }
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_group_get_rows(amdkge_session_group* g, int32_t table, const int32_t* ids, int64_t row0, int64_t nrows, float* host) {
+    if (!g || table < 0 || table > 5) return set_error(AMDKGE_EINVAL, "session_group_get_rows: bad arguments");
+    if (nrows < 0) return set_error(AMDKGE_EINVAL, "session_group_get_rows: nrows must be >= 0");
+    if (nrows == 0) return AMDKGE_OK;
+    if (!host) return set_error(AMDKGE_EINVAL, "session_group_get_rows: NULL host buffer");
+    if (!g->rows || !is_entity_table(table)) return amdkge_session_get_rows(g->rep[0], table, ids, row0, nrows, host);   // every replica holds it whole
+    const int K = g->rep[0]->K;
+    const int64_t rows = g->N;
+    if (!ids && (row0 < 0 || row0 + nrows > rows)) return set_error(AMDKGE_EINVAL, "session_group_get_rows: rows outside the table");
+    // group the wanted rows by owner, fetch each owner's list, scatter into the caller's order
+    std::vector<std::vector<int32_t>> local(g->rep.size());
+    std::vector<std::vector<int64_t>> where(g->rep.size());
+    for (int64_t i = 0; i < nrows; ++i) {
+        const int64_t id = ids ? (int64_t)ids[i] : row0 + i;
+        if (id < 0 || id >= rows) return set_error(AMDKGE_EINVAL, "session_group_get_rows: row id outside the table");
+        const size_t d = (size_t)(id / g->rows_per);
+        local[d].push_back((int32_t)(id - g->sh[d].lo));
+        where[d].push_back(i);
+    }
+    std::vector<float> tmp;
+    for (size_t d = 0; d < g->rep.size(); ++d) {
+        if (local[d].empty()) continue;
+        tmp.resize(local[d].size() * (size_t)K);
+        KGE_RC(amdkge_session_get_rows(g->rep[d], table, local[d].data(), 0, (int64_t)local[d].size(), tmp.data()));
+        for (size_t j = 0; j < local[d].size(); ++j) memcpy(host + where[d][j] * (int64_t)K, tmp.data() + j * (size_t)K, (size_t)K * sizeof(float));
+    }
+    return AMDKGE_OK;
+}
+
+extern "C" int amdkge_session_group_route_overflow(amdkge_session_group* g, int32_t* overflowed) {
+    if (!g || !overflowed) return set_error(AMDKGE_EINVAL, "session_group_route_overflow: bad arguments");
+    *overflowed = 0;
+    if (!g->rows) return AMDKGE_OK;
+    const int W = (int)g->rep.size();
+    for (int d = 0; d < W; ++d) {
+        int32_t f = 0;
+        KGE_HIP(hipSetDevice(g->rep[d]->cfg.device), "hipSetDevice");
+        KGE_HIP(hipMemcpyAsync(&f, g->sh[(size_t)d].counts + W, sizeof(f), hipMemcpyDeviceToHost, g->rep[d]->st), "hipMemcpyAsync(D2H)");
+        KGE_HIP(hipStreamSynchronize(g->rep[d]->st), "hipStreamSynchronize");
+        if (f) {
+            *overflowed = 1;
+            KGE_HIP(hipMemsetAsync(g->sh[(size_t)d].counts + W, 0, sizeof(int32_t), g->rep[d]->st), "hipMemsetAsync");   // reported once
+        }
+    }
+    return AMDKGE_OK;
+}
+
+static int rows_train_step(amdkge_session_group* g, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out) {
+    const int W = (int)g->rep.size();
+    if (loss_out) *loss_out = 0.0;
+    if (B == 0) return AMDKGE_OK;
+    if (!triples) return set_error(AMDKGE_EINVAL, "session_group_train_step: NULL triples");
+    if ((B + W - 1) / W > g->max_share) return set_error(AMDKGE_EINVAL, "session_group_train_step: batch larger than the max_batch the row-sharded group was created for");
+    const amdkge_session_config& c0 = g->rep[0]->cfg;
+    if (focus_w && !c0.loss.focus_nonlinearity) return set_error(AMDKGE_EINVAL, "session_group_train_step: FocusE weights given but the group's loss has focus_nonlinearity == 0");
+    for (int64_t i = 0; i < B; ++i)
+        if (triples[3 * i] < 0 || triples[3 * i] >= g->N || triples[3 * i + 2] < 0 || triples[3 * i + 2] >= g->N || triples[3 * i + 1] < 0 ||
+            triples[3 * i + 1] >= c0.model.n_rels)
+            return set_error(AMDKGE_EINVAL, "session_group_train_step: a triple has an entity / relation id outside the tables");
+    const bool global = (g->flags & AMDKGE_GROUP_GLOBAL_NEGATIVES) != 0;
+    const int eta = c0.eta;
+    const int64_t cap = g->cap, Wcap = (int64_t)W * cap;
+    // ---- 1. route: local index space + request lists, per replica ----
+    for (int d = 0; d < W; ++d) {
+        amdkge_session* s = g->rep[d];
+        Shard& h = g->sh[(size_t)d];
+        const int64_t lo = B * d / W, hi = B * (d + 1) / W, b = hi - lo;
+        KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+        KGE_HIP(hipMemsetAsync(h.acc3, 0, 3 * sizeof(double), s->st), "hipMemsetAsync");
+        if (b > 0) KGE_HIP(hipMemcpyAsync(h.tri, triples + 3 * lo, (size_t)b * 12, hipMemcpyHostToDevice, s->st), "hipMemcpyAsync(H2D)");
+        const int64_t nneg = global ? b * eta : 0;
+        if (global && b > 0)   // the very corruptions one GPU would draw: global Philox rows, ids over all N entities
+            KGE_RC(amdkge_sample_corruptions(h.tri, b, eta, 0, g->N, c0.seed, g->step, lo, B, h.negs, s->st));
+        KGE_RC(amdkge_shard_route(g->N, W, d, h.tri, b, global ? h.negs : nullptr, nneg, (int32_t)cap, h.xl, global ? h.nl : nullptr, h.send, h.counts,
+                                  h.route_work, s->st));
+    }
+    // ---- 2. request ids to the owners, rows back behind the shards ----
+    KGE_RC(exchange(g, [&](int d) { return (void*)g->sh[(size_t)d].send; }, [&](int d) { return (void*)g->sh[(size_t)d].recv; }, cap, 4, kNcclInt32));
+    for (int d = 0; d < W; ++d) {
+        amdkge_session* s = g->rep[d];
+        KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+        KGE_RC(amdkge_gather_rows(s->tab[AMDKGE_TABLE_ENT], s->Ks, g->sh[(size_t)d].recv, Wcap, g->sh[(size_t)d].rows_out, s->st));
+    }
+    KGE_RC(exchange(g, [&](int d) { return (void*)g->sh[(size_t)d].rows_out; },
+                    [&](int d) { return (void*)(g->rep[d]->tab[AMDKGE_TABLE_ENT] + g->sh[(size_t)d].n_local * (int64_t)g->rep[d]->Ks); },
+                    cap * (int64_t)g->rep[0]->Ks, 4, kNcclFloat));
+    // ---- 3. the fused kernels, gradient only, on the local index space ----
+    for (int d = 0; d < W; ++d) {
+        amdkge_session* s = g->rep[d];
+        Shard& h = g->sh[(size_t)d];
+        const int64_t lo = B * d / W, hi = B * (d + 1) / W, b = hi - lo;
+        if (b == 0) continue;
+        KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+        amdkge_model m = s->cfg.model;
+        m.n_ents = h.n_local + Wcap;
+        amdkge_loss loss = s->cfg.loss;
+        if (focus_w) {   // (FocusE weights of the share ride in the session's scratch slot 1)
+            if (s->buf_bytes[1] < b * (int64_t)sizeof(float)) {
+                if (s->buf[1]) KGE_HIP(hipFree(s->buf[1]), "hipFree(scratch)");
+                s->buf[1] = nullptr; s->buf_bytes[1] = 0;
+                KGE_HIP(hipMalloc(&s->buf[1], (size_t)b * sizeof(float)), "hipMalloc(scratch)");
+                s->buf_bytes[1] = b * (int64_t)sizeof(float);
+            }
+            KGE_HIP(hipMemcpyAsync(s->buf[1], focus_w + lo, (size_t)b * sizeof(float), hipMemcpyHostToDevice, s->st), "hipMemcpyAsync(H2D)");
+            loss.d_focus_w = (const float*)s->buf[1];
+        } else { loss.focus_nonlinearity = AMDKGE_FOCUS_OFF; loss.d_focus_w = nullptr; }
+        amdkge_opt opt = s->cfg.opt;
+        opt.iteration = g->iteration + 1;
+        const int64_t srange = global ? m.n_ents : h.n_local;   // shard-local negatives: replacement rows are local rows [0, n_local)
+        const int32_t* nov = global ? h.nl : nullptr;
+        const int64_t need = amdkge_train_tiled_workspace_bytes(&m, b, eta);
+        if (need > 0) {
+            if (need > s->twork_bytes) {
+                if (s->twork) KGE_HIP(hipFree(s->twork), "hipFree(twork)");
+                s->twork = nullptr; s->twork_bytes = 0;
+                KGE_HIP(hipMalloc(&s->twork, (size_t)need), "hipMalloc(twork)");
+                KGE_HIP(hipMemsetAsync(s->twork, 0, (size_t)need, s->st), "hipMemsetAsync(twork)");
+                s->twork_bytes = need;
+            }
+            const int rc = amdkge_train_step_tiled(&m, &loss, &opt, s->tab[0], s->tab[1], nullptr, nullptr, nullptr, nullptr, 0.f, h.xl, b, eta, 0, srange,
+                                                   c0.seed, g->step, lo, B, nov, s->g_ent, s->g_rel, 0, s->cfg.flags & AMDKGE_TILED_POS_ATOMIC, h.acc3,
+                                                   h.acc3 + 1, nullptr, nullptr, s->twork, s->st);
+            if (rc != AMDKGE_OK) { (void)hipFree(s->twork); s->twork = nullptr; s->twork_bytes = 0; return rc; }
+        } else {
+            KGE_RC(amdkge_train_fwdbwd(&m, &loss, s->tab[0], s->tab[1], h.xl, b, eta, 0, srange, c0.seed, g->step, lo, B, nov, s->g_ent, s->g_rel, h.acc3,
+                                       nullptr, nullptr, s->st));
+        }
+    }
+    // ---- 4. gradients of the fetched copies go home; the relation gradient is summed over the replicas ----
+    KGE_RC(exchange(g, [&](int d) { return (void*)(g->rep[d]->g_ent + g->sh[(size_t)d].n_local * (int64_t)g->rep[d]->Ks); },
+                    [&](int d) { return (void*)g->sh[(size_t)d].back; }, cap * (int64_t)g->rep[0]->Ks, 4, kNcclFloat));
+    for (int d = 0; d < W; ++d) {
+        amdkge_session* s = g->rep[d];
+        Shard& h = g->sh[(size_t)d];
+        KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+        KGE_RC(amdkge_scatter_add_rows(s->g_ent, s->Ks, h.recv, Wcap, h.back, s->st));
+        KGE_HIP(hipMemsetAsync(s->g_ent + h.n_local * (int64_t)s->Ks, 0, (size_t)Wcap * s->Ks * sizeof(float), s->st), "hipMemsetAsync(scratch gradients)");
+    }
+    KGE_RC(group_sum(g, [](amdkge_session* s) { return s->g_rel; }, c0.model.n_rels * (int64_t)g->rep[0]->Ks));
+    // ---- 5. every replica sweeps its rows and the replicated relation table ----
+    double data = 0.0, reg = 0.0;
+    for (int d = 0; d < W; ++d) {
+        amdkge_session* s = g->rep[d];
+        Shard& h = g->sh[(size_t)d];
+        KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+        amdkge_opt opt = s->cfg.opt;
+        opt.iteration = g->iteration + 1;
+        if (h.n_local > 0) KGE_RC(amdkge_opt_step(&opt, s->tab[0], s->g_ent, s->tab[2], s->tab[3], h.n_local * (int64_t)s->Ks, h.acc3 + 1, s->st));
+        amdkge_opt orel = opt;
+        orel.reg_lambda = s->cfg.rel_reg_lambda;
+        if (opt.rel_reg_p > 0) orel.reg_p = opt.rel_reg_p;
+        orel.reg2_p = opt.rel_reg2_p; orel.reg2_lambda = opt.rel_reg2_lambda;
+        KGE_RC(amdkge_opt_step(&orel, s->tab[1], s->g_rel, s->tab[4], s->tab[5], c0.model.n_rels * (int64_t)s->Ks, h.acc3 + 2, s->st));
+    }
+    for (int d = 0; d < W; ++d) {
+        amdkge_session* s = g->rep[d];
+        double hst[3] = {0.0, 0.0, 0.0};
+        KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
+        KGE_HIP(hipMemcpyAsync(hst, g->sh[(size_t)d].acc3, sizeof(hst), hipMemcpyDeviceToHost, s->st), "hipMemcpyAsync(D2H)");
+        KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");
+        data += hst[0];
+        reg += hst[1] + (d == 0 ? hst[2] : 0.0);   // entity shards: summed; the relation table's term is the same on every replica
+    }
+    g->step += 1;
+    g->iteration += 1;
+    if (loss_out) *loss_out = data + reg;
     return AMDKGE_OK;
 }

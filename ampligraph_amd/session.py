@@ -142,9 +142,13 @@ class SessionGroup:
     model: replica(i) is an ordinary Session view for get_rows / score / rank."""
 
     def __init__(self, devices, scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer=None, rel_regularizer=None, seed=0,
-                 pos_atomic=False, focus_nonlinearity=None, deterministic=False, force_rccl=False):
+                 pos_atomic=False, focus_nonlinearity=None, deterministic=False, force_rccl=False, rows=False, max_batch=None,
+                 global_negatives=False):
         """force_rccl: AMDKGE_GROUP_FORCE_RCCL -- a group of one replica still binds librccl and sums its gradients through a
-        one-rank ncclAllReduce (first contact with RCCL on a one-GPU box)."""
+        one-rank ncclAllReduce (first contact with RCCL on a one-GPU box).  rows=True: the entity table ROW-SHARDED over the
+        replicas (amdkge_session_group_create_rows; n_ents is the global count, max_batch the largest batch of a step,
+        global_negatives reproduces one GPU's corruptions instead of drawing shard-local ones); set_rows / get_rows then speak
+        global row numbers."""
         self.lib = _ffi.lib()
         self._args = (scoring_type, int(k), int(n_ents), int(n_rels), int(eta), loss, optimizer)
         self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], int(k)))
@@ -152,7 +156,14 @@ class SessionGroup:
                       focus_nonlinearity, deterministic)
         dev = _i32(list(devices))
         self._g = C.c_void_p()
-        check(self.lib.amdkge_session_group_create_ex(C.byref(cfg), _p(dev), int(dev.shape[0]), 1 if force_rccl else 0, C.byref(self._g)))
+        self.rows, self.n_ents, self.n_rels = bool(rows), int(n_ents), int(n_rels)
+        if rows:
+            if max_batch is None:
+                raise ValueError("rows=True needs max_batch (the largest batch a step will be given)")
+            check(self.lib.amdkge_session_group_create_rows(C.byref(cfg), _p(dev), int(dev.shape[0]), (1 if force_rccl else 0) | (4 if global_negatives else 0),
+                                                            int(max_batch), C.byref(self._g)))
+        else:
+            check(self.lib.amdkge_session_group_create_ex(C.byref(cfg), _p(dev), int(dev.shape[0]), 1 if force_rccl else 0, C.byref(self._g)))
         self.size = int(self.lib.amdkge_session_group_size(self._g))
 
     def info(self):
@@ -183,6 +194,24 @@ class SessionGroup:
         if v.ndim != 2 or v.shape[1] != self.K:
             raise ValueError(f"rows must have {self.K} floats")
         check(self.lib.amdkge_session_group_set_rows(self._g, _ffi.TABLES[table], int(row0), int(v.shape[0]), _p(v)))
+
+    def get_rows(self, table, ids=None, row0=0, nrows=None):
+        """Rows of a table in GLOBAL numbering (a row-sharded group gathers entity rows from their owners)."""
+        if ids is not None:
+            ids = _i32(ids)
+            out = np.empty((ids.shape[0], self.K), dtype=np.float32)
+            check(self.lib.amdkge_session_group_get_rows(self._g, _ffi.TABLES[table], _p(ids), 0, int(ids.shape[0]), _p(out)))
+            return out
+        if nrows is None:
+            nrows = (self.n_ents if table.startswith("ent") else self.n_rels) - int(row0)
+        out = np.empty((int(nrows), self.K), dtype=np.float32)
+        check(self.lib.amdkge_session_group_get_rows(self._g, _ffi.TABLES[table], None, int(row0), int(nrows), _p(out)))
+        return out
+
+    def route_overflow(self):
+        f = C.c_int32(0)
+        check(self.lib.amdkge_session_group_route_overflow(self._g, C.byref(f)))
+        return bool(f.value)
 
     def train_step(self, triples, focus_w=None):
         t = _i32(triples)

@@ -356,6 +356,10 @@ def run_config(args, ctx):
     from ampligraph_amd.latent_features import loss_functions, optimizers
     from ampligraph_amd.trainer import StepLoop
 
+    if os.environ.get("AMDKGE_RANK_EARLY"):   # development: "on,check_l1,check_rot,cost" of the distance models' early exit (amdkge_set_rank_early)
+        from ampligraph_amd import _ffi as _f
+
+        _f.check(_f.lib().amdkge_set_rank_early(*[int(v) for v in os.environ["AMDKGE_RANK_EARLY"].split(",")]))
     if os.environ.get("AMDKGE_TILE_DIRECT", "1") == "0":   # development A/B: long rows on the LDS-accumulator tile kernel
         from ampligraph_amd import _ffi as _f
 

@@ -495,10 +495,33 @@ int amdkge_session_group_create(const amdkge_session_config* cfg, const int32_t*
 /* flags: AMDKGE_GROUP_FORCE_RCCL -- a group of ONE replica takes the multi-replica path too (librccl bound, ncclCommInitAll over
  * the one device, gradient-only kernels, grouped ncclAllReduce of both gradient tables, dense sweeps): every RCCL call of the
  * group step is exercised on a one-GPU box.  amdkge_session_group_info: whether the group sums through RCCL, and ncclGetVersion. */
-enum { AMDKGE_GROUP_FORCE_RCCL = 1 };
+enum { AMDKGE_GROUP_FORCE_RCCL = 1, AMDKGE_GROUP_ROWS = 2 /* set by amdkge_session_group_create_rows */, AMDKGE_GROUP_GLOBAL_NEGATIVES = 4 };
 int amdkge_session_group_create_ex(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
                                    amdkge_session_group** out);
 int amdkge_session_group_info(const amdkge_session_group* g, int32_t* uses_rccl, int32_t* rccl_version);
+/* ROW-SHARDED group (BASELINE configs[3] / [4]: tables that do not fit, or should not be replicated on, every GPU).  cfg->model.n_ents
+ * is the GLOBAL entity count N; replica d owns rows [d * rows_per, min(N, (d + 1) * rows_per)), rows_per = ceil(N / n_gpus) -- the
+ * reference's bucket rule owner(e) = e // ceil(N / G) (datasets/graph_partitioner.py:339-344) -- with their optimizer state, the
+ * relation table is replicated.  amdkge_session_group_train_step then is the partitioned step of
+ * ScoringBasedEmbeddingModel.py:227,259-261 with the partitions on different GPUs: ids routed to their owners on the device
+ * (amdkge_shard_route), request ids / rows / returning gradient rows exchanged as equal-split grouped ncclSend / ncclRecv (device
+ * copies between replicas that share one device), the fused kernels in their gradient-only form on the local index space, the
+ * relation gradient all-reduced, every replica sweeping its own rows.  max_batch: the largest B a step will be given (sizes the
+ * request lists at their worst case).  flags: AMDKGE_GROUP_GLOBAL_NEGATIVES = corruptions drawn over all N ids exactly as on one
+ * GPU (same Philox rows: n replicas compute one GPU's step up to fp32 summation order; fabric-bound) instead of the default,
+ * shard-local negatives (replacement ids from the replica's own rows: what the reference's partitioned training does);
+ * AMDKGE_GROUP_FORCE_RCCL as above.  In such a group
+ *   amdkge_session_group_set_rows / _get_rows speak GLOBAL row numbers (entity tables and their slots are scattered to / gathered
+ *     from the owners; _get_rows also serves replicated groups, from replica 0);
+ *   amdkge_session_group_route_overflow reports (and clears) whether a request list overflowed since the last query (cannot happen
+ *     with B <= max_batch; kept as the device-side guard it is in the torch host);
+ *   amdkge_session_group_replica hands out a replica's LOCAL view (its shard + scratch rows): score / rank through it see only
+ *     that shard -- gather the rows into one amdkge_session for evaluation, or evaluate through the torch host (sharded.py).
+ * AMDKGE_TILED_DETERMINISTIC is not offered for row-sharded groups (AMDKGE_EUNSUPPORTED). */
+int amdkge_session_group_create_rows(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
+                                     int64_t max_batch, amdkge_session_group** out);
+int amdkge_session_group_get_rows(amdkge_session_group* g, int32_t table, const int32_t* ids, int64_t row0, int64_t nrows, float* host);
+int amdkge_session_group_route_overflow(amdkge_session_group* g, int32_t* overflowed);
 void amdkge_session_group_destroy(amdkge_session_group* g);
 int32_t amdkge_session_group_size(const amdkge_session_group* g);
 int amdkge_session_group_replica(amdkge_session_group* g, int32_t i, amdkge_session** out);

@@ -169,3 +169,43 @@ def test_transe_drift_is_sensitivity_to_one_ulp(gpu_lib, loss):
         import warnings
 
         warnings.warn("TransE nll: this run did not amplify the one-ulp nudge (%.3g, %.3g)" % (dist(a, b), dist(a, o)))
+
+
+# VERDICT r3 #1b: the rigorous half.  oracle/train_ordered.py restates the TransE / pairwise / Adam step in the kernels' DECLARED
+# fp32 order (the unit order of a lane, the wave64 tree of a score, the fp32 hinge, opt_elem's Adam).  With the pairwise loss every
+# gradient entry is an integer, so the row sums do not depend on the order of their additions and BOTH train paths (the default
+# one with its arrival-order buckets / atomics, and the deterministic mode) must reproduce the ordered replay BIT FOR BIT: same
+# hinge terms active, same signs flipped, same tables after 160 Adam steps -- hence the same ranks and the same MRR, per seed.
+@pytest.mark.parametrize("deterministic", [False, True])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_transe_pairwise_fit_equals_ordered_oracle_bit_for_bit(gpu_lib, seed, deterministic):
+    from planted import LEARNING, planted_kg
+
+    from oracle import rank_ordered as RO
+    from oracle import train_ordered as TO
+
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers
+    from ampligraph_amd.latent_features.initializers import initialise
+
+    d = planted_kg("TransE", seed=seed)
+    train, test = d["train"].astype(str), d["test"].astype(str)
+    m = ScoringBasedEmbeddingModel(eta=ETA, k=K, scoring_type="TransE", seed=seed)
+    m.compile(optimizer=optimizers.get("adam", {"learning_rate": LR}), loss="pairwise", deterministic=deterministic)
+    got = np.asarray(m.fit(train, batch_size=BATCH, epochs=EPOCHS, verbose=False).history["loss"])
+    hist, st, Xi, ti = TO.replay_learning("TransE", "pairwise", seed, LEARNING, planted_kg, initialise)
+    ents, rels = O.first_seen_index(train)
+    names_e = np.array(sorted(ents, key=ents.get))
+    names_r = np.array(sorted(rels, key=rels.get))
+    E = m.get_embeddings(names_e, embedding_type="e")
+    Rm = m.get_embeddings(names_r, embedding_type="r")
+    diff_e, diff_r = int((E != st.ent).sum()), int((Rm != st.rel).sum())
+    report = dict(seed=seed, deterministic=deterministic, loss_history_max_rel=float(np.max(np.abs(got - hist) / np.abs(hist))),
+                  entity_elements_differing=diff_e, relation_elements_differing=diff_r,
+                  max_abs_diff=float(max(np.abs(E - st.ent).max(), np.abs(Rm - st.rel).max())))
+    print("TransE pairwise vs ordered oracle", report)
+    assert diff_e == 0 and diff_r == 0, report                       # the tables after 160 Adam steps: the same bits
+    assert report["loss_history_max_rel"] <= 1e-12, report          # (fp64 sum of the same fp32 per-positive losses: order only)
+    ranks = m.evaluate(test, use_filter={"train": train, "test": test}, corrupt_side="s,o", verbose=False)
+    fs, fo = O.filter_sets(ti, [Xi, ti])
+    ref = RO.evaluate_ranks("TransE", st.ent, st.rel, ti, fs, fo, corrupt_side="s,o", ranking_strategy="worst")
+    assert np.array_equal(ranks, ref) and O.mrr_score(ranks) == O.mrr_score(ref)

@@ -224,3 +224,119 @@ def test_session_rank_takes_the_screening_pass(gpu_lib, model, k):
         else:
             assert stats is not None and not stats[1] and 0 <= stats[0] < n * N // 20, stats   # ran; a few per cent rechecked at most
     s.close()
+
+
+def _rows_reference(model, ent, rel, batches, eta, seed, W, negatives, opt, lr, reg):
+    """The oracle on ONE process with the whole table following a row-sharded group's schedule: replica r takes the share
+    [B r / W, B (r + 1) / W) of every batch; corruptions from the global Philox rows over all N ids ("global") or over the
+    replica's own row range ("local": the same Philox rows, range n_local, + lo); gradients summed; one dense step."""
+    N, R = ent.shape[0], rel.shape[0]
+    st = O.TrainState(ent, rel, opt, lr)
+    rows_per = -(-N // W)
+    losses = []
+    for step, xb in enumerate(batches):
+        bg = xb.shape[0]
+        Ge, Gr, tot = np.zeros(ent.shape, np.float64), np.zeros(rel.shape, np.float64), 0.0
+        for r in range(W):
+            lo, hi = bg * r // W, bg * (r + 1) // W
+            xr = xb[lo:hi]
+            if len(xr) == 0:
+                continue
+            if negatives == "global":
+                ng = O.generate_corruptions(xr, N, eta, seed, step, lo, bg)
+            else:
+                slo, n_local = r * rows_per, min(N, (r + 1) * rows_per) - r * rows_per
+                B = xr.shape[0]
+                j = np.repeat(np.arange(eta, dtype=np.uint64), B)
+                i = np.tile(np.arange(B, dtype=np.uint64), eta)
+                keep, repl = O.sample_corruption_draws(j * np.uint64(bg) + np.uint64(lo) + i, step, seed, n_local)
+                data = np.tile(xr, (eta, 1))
+                repl = repl.astype(np.int64) + slo
+                ng = np.stack([np.where(keep == 1, data[:, 0], repl), data[:, 1], np.where(keep == 1, repl, data[:, 2])], 1).astype(np.int32)
+            loss, ge, gr, _ = O.dense_gradients(model, st.ent, st.rel, xr, ng, eta, "self_adversarial", None, "sum", R)
+            Ge += ge
+            Gr += gr
+            tot += float(loss)
+        for x, G in ((st.ent, Ge), (st.rel, Gr)):
+            xx = x.astype(np.float64)
+            tot += reg[1] * float((np.abs(xx) ** reg[0]).sum())
+            G += reg[1] * reg[0] * np.abs(xx) ** (reg[0] - 1) * np.sign(xx)
+        O.apply_optimizer(st, Ge, Gr)
+        losses.append(tot)
+    return st, losses
+
+
+@pytest.mark.parametrize("model,k,opt,W,negatives", [("ComplEx", 8, "adam", 2, "global"), ("ComplEx", 200, "adam", 3, "global"),
+                                                     ("DistMult", 64, "adagrad", 2, "local"), ("TransE", 12, "sgd", 4, "local"),
+                                                     ("RotatE", 100, "adam", 2, "global"), ("ComplEx", 200, "adam", 1, "local")])
+def test_session_group_rows_matches_single_session(gpu_lib, model, k, opt, W, negatives):
+    """amdkge_session_group_create_rows: the entity table row-sharded over W replicas through the C ABI, numpy only.
+    Here all replicas on device 0 -- device copies ordered by events instead of grouped ncclSend / ncclRecv, everything else
+    of the multi-GPU path: device-side routing, request / row / gradient exchanges, gradient-only kernels on the local index
+    space, relation all-reduce, per-shard sweeps.  global negatives: == a single session on the whole batch (same corruptions
+    by construction) == the oracle; local negatives: == the oracle following the sharded schedule.  N is not a multiple of W
+    (ragged last shard), B not a multiple of W (ragged shares), ids repeat (de-duplicated requests), s == o triples."""
+    from ampligraph_amd.latent_features import loss_functions, optimizers, regularizers
+    from ampligraph_amd.session import Session, SessionGroup
+
+    rng = np.random.default_rng(13)
+    N, R, B, eta, seed, lr = 131, 4, 203, 3, 7, 1e-2
+    K = O.internal_k(model, k)
+    sc = 0.3 if k < 100 else 0.08
+    ent = (rng.normal(size=(N, K)) * sc).astype(np.float32)
+    rel = (rng.normal(size=(R, K)) * sc).astype(np.float32)
+    X = np.stack([rng.integers(0, N, 3 * B), rng.integers(0, R, 3 * B), rng.integers(0, N, 3 * B)], 1).astype(np.int32)
+    X[:9, 2] = X[:9, 0]
+    batches = [X[t * B:(t + 1) * B] for t in range(3)]
+    reg = regularizers.get("LP", {"p": 2, "lambda": 1e-3})
+    mk = lambda: (loss_functions.get("self_adversarial"), optimizers.get(opt, {"learning_rate": lr}))   # noqa: E731
+    group = SessionGroup([0] * W, model, k, N, R, eta, *mk(), reg, seed=seed, rows=True, max_batch=B, global_negatives=negatives == "global")
+    group.set_rows("ent", ent)
+    group.set_rows("rel", rel)
+    assert np.array_equal(group.get_rows("ent"), ent) and np.array_equal(group.get_rows("ent", ids=[130, 0, 77, 77, 66]), ent[[130, 0, 77, 77, 66]])
+    st, ref_losses = _rows_reference(model, ent, rel, batches, eta, seed, W, negatives, opt, lr, (2, 1e-3))
+    single = None
+    if negatives == "global":
+        single = Session(model, k, N, R, eta, *mk(), reg, seed=seed)
+        single.set_rows("ent", ent)
+        single.set_rows("rel", rel)
+    for t, xb in enumerate(batches):
+        lg = group.train_step(xb)
+        assert abs(lg - ref_losses[t]) <= 3e-5 * abs(ref_losses[t]), (t, lg, ref_losses[t])
+        if single is not None:
+            l1 = single.train_step(xb)
+            assert abs(lg - l1) <= 3e-5 * abs(l1), (t, lg, l1)
+    assert not group.route_overflow()
+    eg, rg = group.get_rows("ent"), group.get_rows("rel")
+    assert np.mean(np.abs(eg - st.ent) <= 1e-5 + 1e-3 * np.abs(st.ent)) > 0.99 and np.abs(eg - st.ent).max() < 2.5e-2
+    assert np.mean(np.abs(rg - st.rel) <= 1e-5 + 1e-3 * np.abs(st.rel)) > 0.99
+    if single is not None:
+        es = single.get_rows("ent")
+        assert np.mean(np.abs(eg - es) <= 1e-5 + 1e-3 * np.abs(es)) > 0.99 and np.abs(eg - es).max() < 2.5e-2
+        single.close()
+    if opt == "adam":   # the optimizer state lives with the rows: m of the entity table, gathered from the owners
+        mg = group.get_rows("ent_slot0")
+        assert np.mean(np.abs(mg - st.slots["m_e"]) <= 1e-6 + 2e-3 * np.abs(st.slots["m_e"])) > 0.99
+    group.close()
+
+
+def test_session_group_rows_argument_checks(gpu_lib):
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.latent_features import loss_functions, optimizers
+    from ampligraph_amd.session import SessionGroup
+
+    mk = lambda: (loss_functions.get("nll"), optimizers.get("adam"))   # noqa: E731
+    with pytest.raises(_ffi.AmdKgeError):   # the last replica would own no rows
+        SessionGroup([0] * 4, "DistMult", 8, 5, 2, 2, *mk(), rows=True, max_batch=16)
+    with pytest.raises(ValueError):
+        SessionGroup([0] * 2, "DistMult", 8, 50, 2, 2, *mk(), rows=True)
+    g = SessionGroup([0] * 2, "DistMult", 8, 50, 2, 2, *mk(), rows=True, max_batch=16)
+    X = np.stack([np.arange(32) % 50, np.zeros(32, int), (np.arange(32) * 7) % 50], 1).astype(np.int32)
+    with pytest.raises(_ffi.AmdKgeError):   # more than max_batch
+        g.train_step(X)
+    bad = X[:8].copy()
+    bad[3, 2] = 50
+    with pytest.raises(_ffi.AmdKgeError):   # id outside the GLOBAL table
+        g.train_step(bad)
+    g.train_step(X[:16])
+    g.close()

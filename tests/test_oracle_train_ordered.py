@@ -1,0 +1,76 @@
+"""oracle/train_ordered.py (the train step of TransE / pairwise / Adam in the kernels' declared fp32 order) pinned on the CPU
+against oracle/kge_oracle.py: where every fp32 operation is exact (dyadic tables) the two must agree bit for bit; on real-valued
+tables they may differ only where a hinge term or a sign sits within rounding of its boundary; its Adam against the fp64-formed
+rule of the main oracle."""
+import numpy as np
+import pytest
+
+from oracle import kge_oracle as O
+from oracle import train_ordered as TO
+
+
+def _problem(rng, N=40, R=3, K=16, B=120, dyadic=False):
+    if dyadic:
+        ent = (rng.integers(-8, 9, size=(N, K)) / 8.0).astype(np.float32)
+        rel = (rng.integers(-8, 9, size=(R, K)) / 8.0).astype(np.float32)
+    else:
+        ent = (rng.normal(size=(N, K)) * 0.4).astype(np.float32)
+        rel = (rng.normal(size=(R, K)) * 0.4).astype(np.float32)
+    X = np.stack([rng.integers(0, N, B), rng.integers(0, R, B), rng.integers(0, N, B)], 1).astype(np.int32)
+    return ent, rel, X
+
+
+@pytest.mark.parametrize("K,eta", [(16, 5), (52, 3), (200, 7), (256, 70)])
+def test_ordered_step_equals_oracle_on_dyadic_tables(K, eta):
+    rng = np.random.default_rng(K)
+    ent, rel, X = _problem(rng, K=K, dyadic=True)
+    st = TO.AdamState(ent, rel, 1e-2)
+    loss, Ge, Gr = TO.transe_pairwise_step(st, X, eta, 11, 3, margin=1.0, return_grads=True)
+    negs = O.generate_corruptions(X, ent.shape[0], eta, 11, 3)
+    tot, Re, Rr, _ = O.dense_gradients("TransE", ent, rel, X, negs, eta, "pairwise", None, "sum", rel.shape[0])
+    assert np.array_equal(Ge, Re) and np.array_equal(Gr, Rr)
+    assert loss == float(tot) or abs(loss - float(tot)) <= 1e-6 * abs(float(tot))   # (the oracle rounds its total to fp32)
+
+
+def test_ordered_step_differs_from_fp64_oracle_only_at_decision_boundaries():
+    rng = np.random.default_rng(1)
+    ent, rel, X = _problem(rng, N=300, K=64, B=2000)
+    st = TO.AdamState(ent, rel, 1e-2)
+    loss, Ge, Gr = TO.transe_pairwise_step(st, X, 5, 7, 0, return_grads=True)
+    negs = O.generate_corruptions(X, ent.shape[0], 5, 7, 0)
+    tot, Re, Rr, _ = O.dense_gradients("TransE", ent, rel, X, negs, 5, "pairwise", None, "sum", rel.shape[0])
+    assert abs(loss - float(tot)) <= 2e-6 * abs(float(tot))
+    # a flipped hinge term moves K entries of three rows by one: a handful among 300 x 64, never more than a few units
+    assert np.mean(Ge != Re) < 0.02 and np.abs(Ge - Re).max() <= 3 and np.abs(Gr - Rr).max() <= 3 * 64
+
+
+def test_ordered_adam_is_the_oracles_rule():
+    rng = np.random.default_rng(2)
+    ent, rel, _ = _problem(rng)
+    a = TO.AdamState(ent, rel, 2e-2)
+    b = O.TrainState(ent, rel, "adam", 2e-2)
+    for t in range(5):
+        Ge = rng.integers(-3, 4, size=ent.shape).astype(np.float64)
+        Gr = rng.integers(-3, 4, size=rel.shape).astype(np.float64)
+        a.apply(Ge, Gr)
+        O.apply_optimizer(b, Ge, Gr)
+        # the slots are the same bits; the main oracle forms lr_t from the python-float betas, the kernels (and this module) from
+        # the fp32 ones (1 - 0.999f differs from 1 - 0.999 by 1.3e-5 relative): lr x 6.4e-6 per step on x
+        assert np.array_equal(a.m[0], b.slots["m_e"]) and np.array_equal(a.v[0], b.slots["v_e"])
+        assert np.abs(a.ent - b.ent).max() <= (t + 1) * 2e-2 * 1e-5 + 2e-7
+
+
+def test_replay_learning_runs_and_learns():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from planted import LEARNING, planted_kg
+
+    from ampligraph_amd.latent_features.initializers import initialise
+
+    hist, st, Xi, ti = TO.replay_learning("TransE", "pairwise", 0, LEARNING, planted_kg, initialise, epochs=6)
+    assert hist[-1] < 0.8 * hist[0]
+    # the fp64 oracle on the same schedule: the early epochs agree closely (before the trajectories can part)
+    from planted import oracle_learning_run
+
+    h64, _, _ = oracle_learning_run("TransE", "pairwise", 0, epochs=6)
+    assert abs(hist[0] - h64[0]) <= 1e-5 * abs(h64[0]) and np.max(np.abs(hist - h64) / np.abs(h64)) < 5e-3
