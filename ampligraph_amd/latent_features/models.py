@@ -476,10 +476,10 @@ class ScoringBasedEmbeddingModel:
         return torch.cat(outs) if outs else torch.zeros(0, dtype=torch.float32, device=Xd.device)
 
     # ------------------------------------------------------------------------------------ evaluate
-    def evaluate(self, x=None, batch_size=32, verbose=True, use_filter=False, corrupt_side="s,o",
+    def evaluate(self, x=None, batch_size=10, verbose=True, use_filter=False, corrupt_side="s,o",
                  entities_subset=None, ranking_strategy="worst", callbacks=None, dataset_type="test"):
-        """:1516-1692: int32 ranks (n, 1|2), 1-based, reference tie/filter semantics.  `batch_size` only
-        chunked the TF graph in the reference; results do not depend on it and it is ignored here."""
+        """:1516-1692: int32 ranks (n, 1|2), 1-based, reference tie/filter semantics.  `batch_size` (the reference's default, 10,
+        :1519) only chunked the TF graph in the reference; results do not depend on it and it is ignored here."""
         import torch
 
         assert corrupt_side in ["s", "o", "s,o", "s+o"], "Invalid value for corrupt_side"

@@ -19,6 +19,13 @@ for m in TransE RotatE; do
 done
 timeout 300 python bench.py --model TransE --k 50 --eta 5 --loss pairwise --no-cpu-baseline --trained-eval --steps 50 --warmup 5 >> $O/dist_models.jsonl 2>> $O/dist_models.err
 timeout 300 python bench.py --model RotatE --k 350 --no-cpu-baseline --trained-eval --steps 20 --warmup 5 >> $O/dist_models.jsonl 2>> $O/dist_models.err
+# narrow rows: does a row that is a whole number of 128-byte lines (k = 64) beat k = 50 (208-byte rows) on the atomic path?
+for kk in 48 50 64; do timeout 200 python bench.py --model TransE --k $kk --eta 5 --loss pairwise --no-cpu-baseline --no-eval --steps 200 --warmup 20 >> $O/narrow.jsonl 2>> $O/dist_models.err; done
+python - <<PY2
+import json
+for line in open("$O/narrow.jsonl"):
+    d = json.loads(line); print("narrow", d["config"]["workload"][26:60], "ms/step", round(d["ms_per_step"], 4), "frac", round(d["roofline"]["frac"], 3))
+PY2
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$O/dist_models*.jsonl")):
