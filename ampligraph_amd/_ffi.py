@@ -74,7 +74,7 @@ U64 = C.c_uint64
 SIGNATURES = {
     "amdkge_abi_version": (C.c_int, []),
     "amdkge_release_scratch": (C.c_int, []),
-    "amdkge_set_rank_early": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "amdkge_set_rank_early": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "amdkge_last_error": (C.c_char_p, []),
     "amdkge_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "amdkge_set_device": (C.c_int, [C.c_int]),

@@ -178,7 +178,10 @@ struct CountArgs {
     int qtiles, splits;   // MFMA kernel: logical grid, decoded from a 1-D XCD-aware launch
     float* scores;        // STORE variant of the VALU tile kernel: [n][ld] un-quantised scores instead of counts
     int64_t ld;
-    const int* guard;     // a kernel launched as the fall-back of the screening / early-exit pass: runs only if *guard != 0
+    const int* guard;     // a kernel launched as the fall-back of the screening / early-exit pass: runs only if *guard != 0 (guard_mode
+                          // refines this for the early-exit path: see guard_says_run in kge_rank_early.h)
+    int guard_mode;       // GUARD_* ; 0 with guard != NULL means GUARD_FLAG
+    const int* e_probe;   // the early-exit probe's {decided, sampled}
     // EARLY variants of the distance models' tile kernels (kge_rank_early.h)
     EarlyList e_list;         // the list undecided pairs are handed to
     const uint8_t* e_qbad;    // [n] / [candidates]: rows whose pairs must not be decided early (non-finite or huge values)
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void rank_count_kernel(CountArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[NQF][KT][LDP];
     __shared__ __attribute__((aligned(16))) float Es[NEF][KT][LDP];
     __shared__ EarlyShared es_;   // (referenced by the EARLY variants only: elsewhere it is never allocated)
-    if (a.guard && *a.guard == 0) return;   // launched as a fall-back that turned out not to be needed
+    if (a.guard_mode ? !guard_says_run(a.guard_mode, a.guard, a.e_probe) : (a.guard && *a.guard == 0)) return;   // a launch that turned out not to be needed
 
     const int tid = threadIdx.x;
     const int tq = tid >> 4, te = tid & 15;
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256) void rank_rot_kernel(CountArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[NQF][KT][LDP];
     __shared__ __attribute__((aligned(16))) float Es[NEF][KT][LDP];
     __shared__ EarlyShared es_;   // (referenced by the EARLY variants only: elsewhere it is never allocated)
-    if (a.guard && *a.guard == 0) return;   // launched as a fall-back that turned out not to be needed
+    if (a.guard_mode ? !guard_says_run(a.guard_mode, a.guard, a.e_probe) : (a.guard && *a.guard == 0)) return;   // a launch that turned out not to be needed
 
     const int tid = threadIdx.x;
     const int tq = tid >> 4, te = tid & 15;
@@ -1347,12 +1350,30 @@ static int run_early(int mode, const amdkge_model* m, const float* d_ent, const 
     if (int rc = check_launch("rank_rowflags(Q)")) return rc;
     hipLaunchKernelGGL(rank_rowflags_kernel, dim3((unsigned)((mcand + 3) / 4)), dim3(256), 0, st, d_ent, (int64_t)g.K, d_ent_ids, ent_lo, mcand, g.K, eb.ebad);
     if (int rc = check_launch("rank_rowflags(E)")) return rc;
+    // the probe: which of the call's two kernels does the work (decided on the device)
+    if (!g_early.probe) {   // (tests: the early-exit kernel always)
+        if (hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(eb.b.counter + 4), 1, 2, st)) return set_error_hip(e, "hipMemsetD32Async(probe)");
+    } else {
+        ProbeArgs pa{};
+        pa.ent = d_ent; pa.Q = w.Q; pa.qpos = w.qpos; pa.ent_ids = d_ent_ids; pa.ent_lo = ent_lo; pa.m = mcand; pa.n = n; pa.g = g; pa.sgn_scale = a.sgn_scale;
+        pa.probe = eb.b.counter + 4;
+        switch (mode) {
+            case MODE_L1: hipLaunchKernelGGL(rank_early_probe_kernel<MODE_L1>, dim3(16), dim3(256), 0, st, pa); break;
+            case MODE_L1_SUB: hipLaunchKernelGGL(rank_early_probe_kernel<MODE_L1_SUB>, dim3(16), dim3(256), 0, st, pa); break;
+            case MODE_ROT_S: hipLaunchKernelGGL(rank_early_probe_kernel<MODE_ROT_S>, dim3(16), dim3(256), 0, st, pa); break;
+            default: hipLaunchKernelGGL(rank_early_probe_kernel<MODE_ROT_O>, dim3(16), dim3(256), 0, st, pa); break;
+        }
+        if (int rc = check_launch("rank_early_probe")) return rc;
+    }
     a.counts = eb.b.counts;
+    a.guard = nullptr; a.guard_mode = g_early.probe ? GUARD_EARLY : GUARD_NONE; a.e_probe = eb.b.counter + 4;
     a.e_list = EarlyList{eb.b.counter, eb.b.pairs, eb.b.cap};
     a.e_qbad = eb.qbad; a.e_ebad = eb.ebad;
     a.e_cost = g_early.cost < 1 ? 1 : g_early.cost;
     const bool rot = mode == MODE_ROT_O || mode == MODE_ROT_S;
     a.e_check = rot ? g_early.check_rot : g_early.check_l1;
+    const int nstages = (g.U + KT - 1) / KT;   // short rows: at least three checks per row
+    if (a.e_check > nstages / 4) a.e_check = nstages / 4;
     if (a.e_check < 1) a.e_check = 1;
     RecheckDistArgs ra{};
     ra.ent = d_ent; ra.Q = w.Q; ra.qpos = w.qpos; ra.ent_ids = d_ent_ids; ra.ent_lo = ent_lo; ra.g = g; ra.sgn_scale = a.sgn_scale; ra.b = eb.b;
@@ -1384,7 +1405,7 @@ static int run_early(int mode, const amdkge_model* m, const float* d_ent, const 
     }
 #undef KGE_RD
     if (int rc = check_launch("rank_recheck_dist")) return rc;
-    hipLaunchKernelGGL(rank_screen_merge_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, st, eb.b, n, caller_counts);
+    hipLaunchKernelGGL(rank_early_merge_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, st, eb.b, n, caller_counts);
     if (int rc = check_launch("rank_early_merge")) return rc;
     *guard_out = eb.b.counter + 1;
     return AMDKGE_OK;
@@ -1402,8 +1423,9 @@ extern "C" int amdkge_set_rank_kernel(int which) {
     return AMDKGE_OK;
 }
 
-extern "C" int amdkge_set_rank_early(int on, int check_l1, int check_rot, int cost) {
+extern "C" int amdkge_set_rank_early(int on, int check_l1, int check_rot, int cost, int probe) {
     g_early.on = on ? 1 : 0;
+    if (probe >= 0) g_early.probe = probe ? 1 : 0;
     if (check_l1 > 0) g_early.check_l1 = check_l1;
     if (check_rot > 0) g_early.check_rot = check_rot;
     if (cost > 0) g_early.cost = cost;
@@ -1541,6 +1563,7 @@ static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const flo
         if (d_screen && g_early.on && force == 0 && v4 && (!rot || rot_exact) && a.sgn_scale < 0.f && n >= 64 && mcand >= 256 && g.U >= 64 &&
             mcand < 0x7FFFFFFFll && n < 0x7FFFFFFFll && screen_bytes >= (int64_t)early_fixed_bytes(n, mcand) + (1 << 16)) {
             if (int rc = run_early(mode, m, d_ent, d_ent_ids, ent_lo, mcand, n, g, w, a, grid, d_screen, (size_t)screen_bytes, &a.guard, st)) return rc;
+            a.guard_mode = GUARD_EARLY_FALLBACK; a.e_probe = a.guard + 3;   // the plain kernel below: only if the probe chose it or the list overflowed
         }
     }
     if (rot_exact) {

@@ -293,8 +293,11 @@ int amdkge_set_rank_rotate_fast(int fast);
  * with non-finite / huge values are exempt; a full list falls back to the plain kernel on the device).  Process-wide testing /
  * tuning aid: on = 0 switches it off (amdkge_rank_screen_workspace_bytes then returns 0 for these models); check_l1 / check_rot =
  * stages of 16 units between two checks (defaults 4 / 2), cost = how many tile-kernel pair chains a re-checked pair is priced at
- * when deciding whether a tile ends (default 6); arguments <= 0 keep the current value. */
-int amdkge_set_rank_early(int on, int check_l1, int check_rot, int cost);
+ * when deciding whether a tile ends (default 6); arguments <= 0 keep the current value.  probe: 1 (default) = a sample of 4 096
+ * pairs decides ON THE DEVICE whether the call is worth the early-exit kernel (are at least half of them decided at half their
+ * units?) or runs the plain kernel (tables whose positives do not stand out: an untrained model); 0 = always the early-exit
+ * kernel (tests); < 0 keeps the current value. */
+int amdkge_set_rank_early(int on, int check_l1, int check_rot, int cost, int probe);
 int amdkge_rank_counts(const amdkge_model* m, const float* d_ent, const float* d_rel,
                        const int32_t* d_triples, int64_t n, int32_t side,
                        const int32_t* d_ent_ids, int64_t ent_lo, int64_t ent_hi,

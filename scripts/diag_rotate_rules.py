@@ -19,11 +19,14 @@ lib = _ffi.lib()
 model, k, reg = "RotatE", 1000, (3, 1e-2)
 N, R, B, eta = 120, 4, 60, 3
 out = []
-for opt in ["sgd", "sgd+momentum", "rmsprop", "rmsprop+momentum", "adam"]:
-    for direct in (True, False):
+LAZY = len(sys.argv) > 1 and sys.argv[1] == "lazy"
+for opt in (["rmsprop", "rmsprop+momentum", "sgd+momentum", "adam"] if LAZY else ["sgd", "sgd+momentum", "rmsprop", "rmsprop+momentum", "adam"]):
+    for direct in ((True,) if LAZY else (True, False)):
         lib.amdkge_set_tile_direct(1 if direct else 0)
         eng, ent, rel = make_engine(model, k, N, R, scale=0.08)
         w, mk = make_optimizer(opt.split("+")[0], {"momentum": 0.7} if "+" in opt else {})
+        w.lazy = LAZY
+        hist = np.zeros((3, N), dtype=bool)
         eng.prepare_training(w.name)
         st = mk(ent, rel)
         rng = np.random.default_rng(6)
@@ -34,7 +37,7 @@ for opt in ["sgd", "sgd+momentum", "rmsprop", "rmsprop+momentum", "adam"]:
             _, Ge, Gr, _ = O.dense_gradients(model, st.ent, st.rel, X, negs, eta, "self_adversarial", None, "sum", R, oreg)
             eng.loss_acc.zero_()
             eng.train_step_tiled(dev(X), eta, loss_desc("self_adversarial"), w.to_ffi(t, reg[0]), 77, t, reg_e=reg[1], reg_r=reg[1])
-            O.train_step(st, model, X, eta, "self_adversarial", 77, t, max_rel_size=R, reg=oreg)
+            O.train_step(st, model, X, eta, "self_adversarial", 77, t, max_rel_size=R, reg=oreg, lazy=LAZY)
             torch.cuda.synchronize()
             e, r = eng.get_tables()
             err = np.abs(e - st.ent)
@@ -42,7 +45,12 @@ for opt in ["sgd", "sgd+momentum", "rmsprop", "rmsprop+momentum", "adam"]:
             touched = np.zeros(N, dtype=bool)
             touched[np.concatenate([X[:, 0], X[:, 2], negs[:, 0], negs[:, 2]])] = True
             gabs = np.abs(Ge)
-            rec = dict(opt=opt, direct=direct, t=t, frac_inside=float(1 - bad.mean()), max_err=float(err.max()),
+            hist[t - 1] = touched
+            bad_rows = bad.mean(1)
+            rec = dict(lazy=LAZY, rows_with_bad=int((bad_rows > 0).sum()), bad_rows_top=[(int(i), float(bad_rows[i]), [bool(h) for h in hist[:t, i]]) for i in np.argsort(-bad_rows)[:6]],
+                       bad_by_history={str(tuple(int(v) for v in key)): float(bad[np.all(hist[:t].T == np.array(key, dtype=bool), axis=1)].mean()) if np.any(np.all(hist[:t].T == np.array(key, dtype=bool), axis=1)) else None
+                                       for key in ([(1, 1, 1), (0, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0)] if t == 3 else [])},
+                       opt=opt, direct=direct, t=t, frac_inside=float(1 - bad.mean()), max_err=float(err.max()),
                        bad_in_touched_rows=float(bad[touched].mean()), bad_in_untouched_rows=float(bad[~touched].mean()) if (~touched).any() else None,
                        err_q=[float(np.quantile(err, q)) for q in (0.5, 0.9, 0.99, 0.999)],
                        g_abs_q_at_bad=[float(np.quantile(gabs[bad], q)) for q in (0.1, 0.5, 0.9)] if bad.any() else None,

@@ -20,7 +20,7 @@ EPOCHS, BATCH, ETA, K, LR = 40, 1024, 5, 16, 2e-2
 # in the loss, 0.002..0.008 in MRR, both runs equally good).  The reference has the same property between its own CPU and GPU
 # kernels.  The bars below are the measured drift with headroom, and the early epochs are held tight.
 CASES = [("ComplEx", "multiclass_nll", 1e-4, 1e-4, 2e-3, 0.15), ("DistMult", "self_adversarial", 1e-4, 1e-4, 2e-3, 0.05),
-         ("TransE", "nll", 2e-3, 5e-5, 1.5e-2, 0.15), ("TransE", "pairwise", 2e-2, 2e-3, 1.5e-2, 0.15),
+         ("TransE", "nll", 2e-3, 5e-5, 2.5e-2, 0.15), ("TransE", "pairwise", 2e-2, 2e-3, 2.5e-2, 0.15),
          # round 3: the two remaining models.  HolE = ComplEx's score scaled by 2/k: same bars (measured 1e-5 / 4e-4 MRR).  RotatE's
          # gradient z / |z| is ill-conditioned where a unit's modulus is ~0 (no epsilon, RotatE.py:102-104), so two fp32 / fp64
          # evaluations of the same schedule part slowly, like TransE's: measured on MI355X vs the fp64-accumulating oracle, first 5
@@ -28,7 +28,12 @@ CASES = [("ComplEx", "multiclass_nll", 1e-4, 1e-4, 2e-3, 0.15), ("DistMult", "se
          # loss and 8e-4 .. 2.1e-3 in MRR -- at the north_star's +-0.002, bar = measured x 2.  With nll this graph trains into a
          # regime where MRR itself is chaotic: loss within 0.15 .. 0.32 %, but MRR 0.22 .. 0.30 across the ORACLE's own three seeds
          # and 0.01 .. 0.05 between the two runs of one seed; there the test holds the loss and "both learn", not an MRR distance.
-         ("HolE", "self_adversarial", 1e-4, 1e-4, 2e-3, 0.05), ("RotatE", "self_adversarial", 1e-3, 1e-5, 4e-3, 0.05),
+         # Round 4: the per-seed MRR bars of the distance models are what ONE seed can be held to -- measured over 512 seeds on MI355X
+         # (test_mean_mrr_over_seeds_matches_oracle, profiles/r04b_pytest_gpu.log): per-seed |MRR(GPU) - MRR(oracle)| sd 0.0064 / 0.0055 /
+         # 0.0023, max 0.0225 / 0.0214 / 0.0205 (TransE nll / TransE pairwise / RotatE self_adversarial; heavy-tailed: a trajectory
+         # that parts early parts far), and the default mode is not bitwise reproducible, so a bar at twice a 3-seed maximum (round 3:
+         # 0.004 for RotatE) fails one run in a dozen.  The north_star's +-0.002 is asserted on the MEAN over the seeds, below.
+         ("HolE", "self_adversarial", 1e-4, 1e-4, 2e-3, 0.05), ("RotatE", "self_adversarial", 1e-3, 1e-5, 2.5e-2, 0.05),
          ("RotatE", "nll", 1e-2, 1e-5, None, 0.05)]
 
 
@@ -113,7 +118,7 @@ def test_mean_mrr_over_seeds_matches_oracle(gpu_lib, model, loss):
                   first_epoch_loss_max_rel=float(np.max(np.abs(got[:, 2] - gold[:, 2]) / np.abs(gold[:, 2]))),
                   last_epoch_loss_mean_rel=float(np.mean((got[:, 3] - gold[:, 3]) / np.abs(gold[:, 3]))))
     print("mean MRR over seeds", model, loss, report)
-    assert report["first_epoch_loss_max_rel"] <= {"nll": 1e-5, "pairwise": 4e-4, "self_adversarial": 1e-5}[loss], report   # before any drift: every seed
+    assert report["first_epoch_loss_max_rel"] <= {"nll": 5e-5, "pairwise": 4e-4, "self_adversarial": 1e-5}[loss], report   # before any drift: every seed (measured max over 512 / 2 048 seeds: 1.3e-5 / 2.2e-5 / 1.9e-7)
     assert abs(report["mean_distance"]) <= 2e-3, report                       # the north_star's bar, on the mean
     assert abs(report["hits10_mean_distance"]) <= 4e-3, report
     # no bias in the loss either (per seed the pairwise hinge parts by 0.5 .. 0.8 %, the others by <= 0.3 %: CASES above)
@@ -204,7 +209,9 @@ def test_transe_pairwise_fit_equals_ordered_oracle_bit_for_bit(gpu_lib, seed, de
                   max_abs_diff=float(max(np.abs(E - st.ent).max(), np.abs(Rm - st.rel).max())))
     print("TransE pairwise vs ordered oracle", report)
     assert diff_e == 0 and diff_r == 0, report                       # the tables after 160 Adam steps: the same bits
-    assert report["loss_history_max_rel"] <= 1e-12, report          # (fp64 sum of the same fp32 per-positive losses: order only)
+    # the loss history: the same fp32 per-positive losses summed in fp64 -- exactly the replay's in deterministic mode (measured
+    # 0.0); the default path (k = 16: the atomic-scatter kernels) reports it 1.2e-8 .. 1.4e-8 off with the tables bit-identical
+    assert report["loss_history_max_rel"] <= (1e-12 if deterministic else 1e-7), report
     ranks = m.evaluate(test, use_filter={"train": train, "test": test}, corrupt_side="s,o", verbose=False)
     fs, fo = O.filter_sets(ti, [Xi, ti])
     ref = RO.evaluate_ranks("TransE", st.ent, st.rel, ti, fs, fo, corrupt_side="s,o", ranking_strategy="worst")

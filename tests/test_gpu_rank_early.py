@@ -14,6 +14,15 @@ from oracle import kge_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _always_the_early_kernel(gpu_lib):
+    """The device-side probe would send untrained-looking tables to the plain kernel: here the early-exit kernel itself is under
+    test, so it always does the work (test_probe_* below check the probe)."""
+    gpu_lib.amdkge_set_rank_early(1, 4, 2, 6, 0)
+    yield
+    gpu_lib.amdkge_set_rank_early(1, 4, 2, 6, 1)
+
+
 def _counts(eng, gpu_lib, Xd, side, which, **kw):
     from ampligraph_amd import _ffi
 
@@ -29,7 +38,7 @@ def _counts(eng, gpu_lib, Xd, side, which, **kw):
         gpu_lib.amdkge_set_rank_kernel(0)
 
 
-def _tables(model, k, N, R, n, kind, rng):
+def _tables(model, k, N, R, n, kind, rng, noise=0.03):
     """(ent, rel, X): `n` test triples over N + n entities; kind 'trained' plants every triple's object next to where the model
     puts it (o = s + p resp. s o r, plus noise), so the positive scores near the top from both sides."""
     K = O.internal_k(model, k)
@@ -49,7 +58,7 @@ def _tables(model, k, N, R, n, kind, rng):
             phi = (p[:, :k] / np.float32(O.rotate_phase_divisor(k, R))).astype(np.float64)
             sr, si = s[:, :k].astype(np.float64), s[:, k:].astype(np.float64)
             tgt = np.concatenate([sr * np.cos(phi) - si * np.sin(phi), sr * np.sin(phi) + si * np.cos(phi)], 1)
-        ent[N:] = (tgt + rng.normal(size=tgt.shape) * 0.03).astype(np.float32)
+        ent[N:] = (tgt + rng.normal(size=tgt.shape) * noise).astype(np.float32)
         X[:, 2] = N + np.arange(n)
     return ent, rel, X
 
@@ -119,17 +128,21 @@ def test_early_exit_overflowing_list_falls_back(gpu_lib, model, k):
     from ampligraph_amd.engine import KgeEngine, _ptr, _stream
 
     N, R, n = 6000, 7, 1024
-    rng = np.random.default_rng(5)
-    ent, rel, X = _tables(model, k, N, R, n, "trained", rng)
-    eng = KgeEngine(model, k, ent.shape[0], R, max_rel_size=R)
-    eng.set_tables(ent, rel)
-    Xd = torch.as_tensor(X).cuda()
-    M = ent.shape[0]
-    plain, _ = _counts(eng, gpu_lib, Xd, _ffi.SIDE_O, 1)
+    M = N + n
     try:
-        _ffi.check(gpu_lib.amdkge_set_rank_early(1, 1, 1, 1))   # tiles end at their first check with up to 512 pairs each: a long list
-        full, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_O, 0)
-        assert np.array_equal(full, plain) and not st[1] and st[0] > 8200, st
+        _ffi.check(gpu_lib.amdkge_set_rank_early(1, 1, 1, 1, 0))   # tiles end at their first check with up to 512 pairs each: a long list
+        for noise in (0.03, 0.1, 0.2, 0.3, 0.45):   # the less the positives stand out, the more pairs are still undecided at the first check
+            rng = np.random.default_rng(5)
+            ent, rel, X = _tables(model, k, N, R, n, "trained", rng, noise=noise)
+            eng = KgeEngine(model, k, M, R, max_rel_size=R)
+            eng.set_tables(ent, rel)
+            Xd = torch.as_tensor(X).cuda()
+            plain, _ = _counts(eng, gpu_lib, Xd, _ffi.SIDE_O, 1)
+            full, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_O, 0)
+            assert np.array_equal(full, plain), st   # (whether or not the product-sized list overflowed)
+            if st[0] > 9000:
+                break
+        assert st[0] > 9000, st
         need = int(gpu_lib.amdkge_rank_screen_workspace_bytes(C.byref(eng.model), n, M))
         small = need - (max(1 << 18, n * M // 32) - 8200) * 8          # room for 8 200 pairs only
         buf = torch.empty(small, dtype=torch.uint8, device="cuda")
@@ -142,7 +155,7 @@ def test_early_exit_overflowing_list_falls_back(gpu_lib, model, k):
         assert flag[1] != 0 and flag[0] > 8200
         assert np.array_equal(counts.cpu().numpy(), plain)
     finally:
-        gpu_lib.amdkge_set_rank_early(1, 4, 2, 6)
+        gpu_lib.amdkge_set_rank_early(1, 4, 2, 6, 1)
 
 
 def test_early_exit_switch_and_settings(gpu_lib):
@@ -160,12 +173,41 @@ def test_early_exit_switch_and_settings(gpu_lib):
     plain, _ = _counts(eng, gpu_lib, Xd, _ffi.SIDE_S, 1)
     try:
         for check, cost in ((1, 1), (2, 6), (8, 50)):
-            _ffi.check(gpu_lib.amdkge_set_rank_early(1, check, check, cost))
+            _ffi.check(gpu_lib.amdkge_set_rank_early(1, check, check, cost, 0))
             early, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_S, 0)
             assert np.array_equal(early, plain) and st is not None, (check, cost, st)
-        _ffi.check(gpu_lib.amdkge_set_rank_early(0, 0, 0, 0))
+        _ffi.check(gpu_lib.amdkge_set_rank_early(0, 0, 0, 0, -1))
         assert int(gpu_lib.amdkge_rank_screen_workspace_bytes(C.byref(eng.model), n, ent.shape[0])) == 0
         off, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_S, 0)
         assert np.array_equal(off, plain) and st is None
     finally:
-        gpu_lib.amdkge_set_rank_early(1, 4, 2, 6)
+        gpu_lib.amdkge_set_rank_early(1, 4, 2, 6, 1)
+
+
+@pytest.mark.parametrize("model,k", [("TransE", 200), ("RotatE", 100)])
+def test_probe_picks_the_kernel_on_the_device(gpu_lib, model, k):
+    """With the probe on (the product's setting): tables whose positives do not stand out go through the plain kernel (no tile ends
+    early, nothing is handed over), tables of a fitted model through the early-exit kernel -- same counts either way."""
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+
+    N, R, n = 5000, 5, 512
+    gpu_lib.amdkge_set_rank_early(1, 4, 2, 6, 1)
+    for kind in ("gaussian", "trained"):
+        rng = np.random.default_rng(21)
+        ent, rel, X = _tables(model, k, N, R, n, kind, rng)
+        eng = KgeEngine(model, k, ent.shape[0], R, max_rel_size=R)
+        eng.set_tables(ent, rel)
+        Xd = torch.as_tensor(X).cuda()
+        for side in (_ffi.SIDE_S, _ffi.SIDE_O):
+            plain, _ = _counts(eng, gpu_lib, Xd, side, 1)
+            got, st = _counts(eng, gpu_lib, Xd, side, 0)
+            v = eng._last_screen[:24].view(torch.int32).cpu().numpy()
+            print("probe", model, kind, side, "decided", int(v[4]), "of", int(v[5]), "sampled; tiles ended early", st[2])
+            assert np.array_equal(got, plain) and not st[1]
+            assert v[5] == 4096
+            if kind == "gaussian":
+                assert v[4] * 2 < v[5] and st[2] == 0 and st[0] == 0, (v[:6], st)
+            else:
+                assert v[4] * 2 >= v[5] and st[2] > 0, (v[:6], st)
+
