@@ -1524,6 +1524,13 @@ static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const flo
         if (!mfma) break;
     }
     if (best_cost < 0) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: entity range too large for one launch; split [ent_lo, ent_hi)");
+    // distance models with the early-exit workspace: TWO tile kernels are launched per call and one of them returns at once (the
+    // probe's choice, kge_rank_early.h) -- with one tile per block that is ~70 000 workgroups dispatched for nothing (measured
+    // 0.25 ms per side at C2); runs of >= 8 tiles keep the blocks few (and amortise the early-exit kernel's per-block thresholds)
+    if (!mfma && d_screen && g_early.on && tiles_per < 8) {
+        tiles_per = etiles < 8 ? etiles : 8;
+        while (tiles_per < etiles && qtiles * ((etiles + tiles_per - 1) / tiles_per) > 16 * slots) ++tiles_per;
+    }
     int64_t splits;
     a.ent_per_block = (int)(tiles_per * et_);
     splits = (etiles + tiles_per - 1) / tiles_per;

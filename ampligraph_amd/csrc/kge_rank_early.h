@@ -32,8 +32,9 @@ constexpr int EARLY_STAGE_PAIRS = 512;   // undecided pairs a tile may hand over
 
 struct EarlyCfg {
     int on = 1;
-    int check_l1 = 4, check_rot = 2;   // stages (of KT = 16 units) between two checks
-    int cost = 6;                      // a re-checked pair's chain costs about this many tile-kernel pair chains
+    int check_l1 = 2, check_rot = 1;   // stages (of KT = 16 units) between two checks (a check is ~6 % of a TransE stage, ~1 % of a RotatE stage)
+    int cost = 12;                     // a re-checked pair's chain costs about this many tile-kernel pair chains (measured ~10: one lane
+                                       // per pair against a 4 x 4 register tile)
     int probe = 1;                     // 0: the early-exit kernel always does the work (tests)
 };
 static EarlyCfg g_early;

@@ -608,64 +608,10 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     auto flush = [&](auto kind_c) KGE_TILE_INLINE {
     constexpr int KIND = decltype(kind_c)::value;
     constexpr int NS = opt_nslots(KIND);
-#ifndef KGE_FLUSH_SERIAL
-    // The ordinary case (optimizer applied here, no hot-row replicas, no atomic positives), SOFTWARE-PIPELINED over the rows a
-    // wave owns: x and the slots of the NEXT row are requested before the current row is updated and stored.  Row after row --
-    // load x, m, v / update / store, each round trip exposed -- a wave's 3 - 4 rows cost ~12 us of a tile's ~49 us at C4 (8.4
-    // rounds of tiles per CU: nothing else hides them); two register sets, named so that no array is indexed at run time.
-    // (two quads per lane AND two planes would need 24 float4 of row state per lane: spills at the 128 registers a 1024-thread
-    // workgroup leaves -- those shapes keep the row-by-row form)
-    if (CH * NC <= 2 && a.apply_update && !a.hot_map && !a.pos_atomic && !KGE_DBG(a, 1024)) {
-        auto want = [&](int r) KGE_TILE_INLINE -> bool { return row_ok(r) && !(a.lazy && !tflag[r * gw + wg]); };
-        auto next_row = [&](int r) KGE_TILE_INLINE -> int { while (r < nrow && !want(r)) r += G; return r; };
-        auto ld = [&](int r, float4 (&X)[CH][NC], float4 (&M)[CH][NC], float4 (&V)[CH][NC]) KGE_TILE_INLINE {
-            const int64_t base = row_of(r) * a.K;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int h = 0; h < NC; ++h) {
-                    const int64_t off = base + qoff[c] + h * a.k;   // (lanes beyond the row re-read its first quad: nothing is stored for them)
-                    X[c][h] = KGE_LD4(a.x + off);
-                    if constexpr (NS >= 1) M[c][h] = KGE_LD4(a.s0 + off);
-                    if constexpr (NS == 2) V[c][h] = KGE_LD4(a.s1 + off);
-                }
-        };
-        auto upd = [&](int r, float4 (&X)[CH][NC], float4 (&M)[CH][NC], float4 (&V)[CH][NC]) KGE_TILE_INLINE {
-            const float* arow = acc + (size_t)r * a.K;
-            const int64_t base = row_of(r) * a.K;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                if (!qok[c]) continue;
-#pragma unroll
-                for (int h = 0; h < NC; ++h) {
-                    const float4 g = *reinterpret_cast<const float4*>(arow + qoff[c] + h * a.k);
-                    const int64_t off = base + qoff[c] + h * a.k;
-                    float4 x = X[c][h], m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
-                    if constexpr (NS >= 1) m = M[c][h];
-                    if constexpr (NS == 2) v = V[c][h];
-                    opt_elem<KIND>(a.opt, x.x, g.x, m.x, v.x, reg_acc); opt_elem<KIND>(a.opt, x.y, g.y, m.y, v.y, reg_acc);
-                    opt_elem<KIND>(a.opt, x.z, g.z, m.z, v.z, reg_acc); opt_elem<KIND>(a.opt, x.w, g.w, m.w, v.w, reg_acc);
-                    if constexpr (NS >= 1) *reinterpret_cast<float4*>(a.s0 + off) = m;
-                    if constexpr (NS == 2) *reinterpret_cast<float4*>(a.s1 + off) = v;
-                    *reinterpret_cast<float4*>(a.x + off) = x;
-                }
-            }
-        };
-        float4 X0[CH][NC], M0[CH][NC], V0[CH][NC], X1[CH][NC], M1[CH][NC], V1[CH][NC];
-        int r0 = next_row(grp);
-        if (r0 < nrow) ld(r0, X0, M0, V0);
-        while (r0 < nrow) {
-            const int r1 = next_row(r0 + G);
-            if (r1 < nrow) ld(r1, X1, M1, V1);
-            upd(r0, X0, M0, V0);
-            if (r1 >= nrow) break;
-            r0 = next_row(r1 + G);
-            if (r0 < nrow) ld(r0, X0, M0, V0);
-            upd(r1, X1, M1, V1);
-        }
-        return;
-    }
-#endif
+    // (Round 4, measured and dropped: software-pipelining this loop -- the next row's x / m / v requested before the current row
+    // is updated and stored, two named register sets -- changed nothing at C2 (0.1416 vs 0.1411 ms/step), cost 3 % at C4 and 7 % at
+    // the C5 row width, gained 2 % at C3 (profiles/r04c_flush_ab.jsonl): with 16 waves per CU in the flush the round trips of one
+    // wave are already covered by the others; the flush is bandwidth, not latency.)
     for (int r = grp; r < (KGE_DBG(a, 1024) ? 0 : nrow); r += G) {
         const float* arow = acc + (size_t)r * a.K;
         if (!row_ok(r)) continue;
