@@ -607,7 +607,6 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
     float reg_acc = 0.f;
     auto flush = [&](auto kind_c) KGE_TILE_INLINE {
     constexpr int KIND = decltype(kind_c)::value;
-    constexpr int NS = opt_nslots(KIND);
     // (Round 4, measured and dropped: software-pipelining this loop -- the next row's x / m / v requested before the current row
     // is updated and stored, two named register sets -- changed nothing at C2 (0.1416 vs 0.1411 ms/step), cost 3 % at C4 and 7 % at
     // the C5 row width, gained 2 % at C3 (profiles/r04c_flush_ab.jsonl): with 16 waves per CU in the flush the round trips of one

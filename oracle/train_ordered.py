@@ -10,8 +10,9 @@ the ranks (oracle/rank_ordered.py) ONE order has to be fixed for "identical" to 
 
   * d = fl(fl(s + p) - o) per unit (TransE.py:51-53), for a corruption fl(fl(s + p) - e) (object replaced) or
     fl(fl(e + p) - o) (subject replaced), rounded where the reference rounds;
-  * a score = -(sum of |d|): lane l of a wave holds units 4 l .. 4 l + 3 and adds them in that order, the 64 lane sums are
-    combined by the wave64 DPP tree (rank_ordered.wave_sum); rows of up to 256 units (one quad per lane);
+  * a score = -(sum of |d|): a lane of the wave adds the units it holds in order (which units: the kernel's row layout, see
+    _lane_sums -- quads per lane in the owner-computes pair, single units per lane in the atomic-scatter path's narrow-row
+    geometry), the 64 lane sums are combined by the wave64 DPP tree (rank_ordered.wave_sum); rows of up to 512 units;
   * the pairwise hinge in fp32: h_j = fl(fl(margin - P) + n_j), active iff h_j >= 0 (tf.maximum passes the gradient to its
     first argument on ties), per-positive loss = the wave64 tree over the lanes' max(h_j, 0) (lane j % 64 adds its terms in
     increasing j), reduction "sum";
@@ -37,53 +38,126 @@ from .rank_ordered import wave_sum
 F32 = np.float32
 
 
-def _lane_sums(absd):
-    """[n, K] per-unit |d| -> [n, 64]: lane l adds its units 4 l .. 4 l + 3 in order (from 0); K <= 256, K % 4 == 0."""
+def _lane_sums(absd, layout="quad"):
+    """[n, K] per-unit |d| -> [n, 64] lane sums of one wave, as the forward kernels lay a row out over the lanes:
+      "quad": lane l holds the QUADS l, l + 64 (units 4 q .. 4 q + 3 each) -- the 16-byte geometry of the owner-computes pair (any
+              k, stored halves are whole float4s) and of the atomic-scatter path for rows of 129 .. 512 units; a quad's units are
+              added in order from 0, the lane's quads one after the other;
+      "unit": lane l holds the UNITS l, l + 64, ... -- the one-unit-per-lane geometry the atomic-scatter path takes for rows of up
+              to 128 stored units (kge_train.hip launch_train_m).
+    K <= 512 (one wave per positive)."""
     n, K = absd.shape
-    assert K % 4 == 0 and K <= 256, "ordered TransE step: rows of up to 256 units (one quad per lane)"
+    assert K <= 512, "ordered TransE step: rows of up to 512 units (one wave per positive)"
+    lanes = np.zeros((n, 64), dtype=F32)
+    if layout == "unit":
+        for c0 in range(0, K, 64):
+            blk = absd[:, c0:c0 + 64]
+            lanes[:, :blk.shape[1]] = (lanes[:, :blk.shape[1]] + blk).astype(F32)   # (first chunk: 0 + |d|, exact)
+        return lanes
+    assert layout == "quad" and K % 4 == 0
     q = absd.reshape(n, K // 4, 4)
     acc = np.zeros((n, K // 4), dtype=F32)
     for u in range(4):
         acc = (acc + q[:, :, u]).astype(F32)
-    lanes = np.zeros((n, 64), dtype=F32)
-    lanes[:, :K // 4] = acc
+    for c0 in range(0, K // 4, 64):
+        blk = acc[:, c0:c0 + 64]
+        lanes[:, :blk.shape[1]] = (lanes[:, :blk.shape[1]] + blk).astype(F32)
     return lanes
 
 
-def transe_scores(s, p, o):
+def transe_scores(s, p, o, layout="quad"):
     """-(sum |fl(fl(s + p) - o)|) in the declared order; s, p, o fp32 [n, K]."""
     d = ((s + p).astype(F32) - o).astype(F32)
-    return (F32(-1.0) * wave_sum(_lane_sums(np.abs(d)))).astype(F32), d
+    return (F32(-1.0) * wave_sum(_lane_sums(np.abs(d), layout))).astype(F32), d
 
 
-class AdamState:
-    """Both tables with their Adam slots, fp32; lr, b1, b2, eps are the fp32 hyper-parameters the descriptor carries."""
+class OptState:
+    """Both tables with their optimizer state tensors, fp32, updated by kge_opt.h's opt_elem rule for rule `kind` -- every rule is
+    element-wise IEEE arithmetic (+, *, /, sqrt, max) in a fixed operation order, so numpy float32 reproduces it bit for bit.
+    Hyper-parameters are the fp32 values the descriptor carries (OptimizerWrapper.to_ffi): lr, beta1 / beta2 (or the rule's rho /
+    momentum in their place, as include/amdkge.h documents), epsilon."""
 
-    def __init__(self, ent, rel, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+    def __init__(self, ent, rel, kind="adam", lr=1e-3, beta1=None, beta2=None, eps=1e-7):
         self.ent, self.rel = np.array(ent, dtype=F32), np.array(rel, dtype=F32)
-        self.m = [np.zeros_like(self.ent), np.zeros_like(self.rel)]
-        self.v = [np.zeros_like(self.ent), np.zeros_like(self.rel)]
-        self.lr, self.b1, self.b2, self.eps = F32(lr), F32(beta1), F32(beta2), F32(eps)
+        self.kind = kind
+        d1 = {"adam": 0.9, "adamax": 0.9, "momentum": 0.0, "rmsprop": 0.9, "rmsprop_mom": 0.9, "adadelta": 0.95}.get(kind, 0.9)
+        d2 = {"adam": 0.999, "adamax": 0.999}.get(kind, 0.0)
+        self.lr, self.b1, self.b2, self.eps = F32(lr), F32(d1 if beta1 is None else beta1), F32(d2 if beta2 is None else beta2), F32(eps)
+        ns = {"sgd": 0, "adagrad": 1, "momentum": 1, "rmsprop": 1}.get(kind, 2)
+        fill = F32(0.1) if kind == "adagrad" else F32(0.0)   # Keras legacy Adagrad: initial_accumulator_value = 0.1
+        self.s0 = [np.full_like(self.ent, fill), np.full_like(self.rel, fill)] if ns >= 1 else [None, None]
+        self.s1 = [np.zeros_like(self.ent), np.zeros_like(self.rel)] if ns == 2 else [None, None]
         self.iterations = 0
 
+    # (Adam's slots under the names the tests of the Adam-only first version use)
+    @property
+    def m(self):
+        return self.s0
+
+    @property
+    def v(self):
+        return self.s1
+
     def apply(self, Ge, Gr):
-        """kge_opt.h: fill_opt_args (lr_t, 1 - beta in fp64 from the fp32 values, rounded once) + opt_elem<ADAM>."""
+        """kge_opt.h: fill_opt_args (lr_t and 1 - beta formed in fp64 from the fp32 values, rounded once) + opt_elem<KIND>."""
         self.iterations += 1
         t = float(self.iterations)
-        b1, b2, lr = float(self.b1), float(self.b2), float(self.lr)
-        lr_t = F32(lr * math.sqrt(1.0 - math.pow(b2, t)) / (1.0 - math.pow(b1, t)))
-        omb1, omb2 = F32(1.0 - b1), F32(1.0 - b2)
-        for x, g, m, v in ((self.ent, Ge, self.m[0], self.v[0]), (self.rel, Gr, self.m[1], self.v[1])):
-            g = g.astype(F32)
-            m[...] = ((m * self.b1).astype(F32) + (g * omb1).astype(F32)).astype(F32)
-            v[...] = ((v * self.b2).astype(F32) + ((g * g).astype(F32) * omb2).astype(F32)).astype(F32)
-            x[...] = (x - ((lr_t * m).astype(F32) / (np.sqrt(v).astype(F32) + self.eps).astype(F32)).astype(F32)).astype(F32)
+        b1d, b2d, lrd = float(self.b1), float(self.b2), float(self.lr)
+        omb1, omb2 = F32(1.0 - b1d), F32(1.0 - b2d)
+        if self.kind == "adamax":
+            lr_t = F32(lrd / (1.0 - math.pow(b1d, t)))
+        else:
+            lr_t = F32(lrd * math.sqrt(1.0 - math.pow(b2d, t)) / (1.0 - math.pow(b1d, t))) if self.kind == "adam" else F32(0)
+        lr, b1, b2, eps = self.lr, self.b1, self.b2, self.eps
+        f = lambda a: a.astype(F32)   # noqa: E731  (every operation rounds to fp32 once, as the kernel's does)
+        for i, (x, g) in enumerate(((self.ent, Ge), (self.rel, Gr))):
+            g = np.asarray(g).astype(F32)
+            s0, s1 = self.s0[i], self.s1[i]
+            k = self.kind
+            if k == "adam":
+                s0[...] = f(f(s0 * b1) + f(g * omb1))
+                s1[...] = f(f(s1 * b2) + f(f(g * g) * omb2))
+                x[...] = f(x - f(f(lr_t * s0) / f(f(np.sqrt(s1)) + eps)))
+            elif k == "adagrad":
+                s0[...] = f(s0 + f(g * g))
+                x[...] = f(x - f(f(lr * g) / f(f(np.sqrt(s0)) + eps)))
+            elif k == "momentum":     # beta1 = momentum, beta2 != 0: nesterov
+                s0[...] = f(f(s0 * b1) - f(lr * g))
+                x[...] = f(x + (f(f(s0 * b1) - f(lr * g)) if b2 != 0 else s0))
+            elif k == "rmsprop":      # beta1 = rho
+                s0[...] = f(s0 + f(f(f(g * g) - s0) * omb1))
+                x[...] = f(x - f(f(lr * g) / f(f(np.sqrt(s0)) + eps)))
+            elif k == "rmsprop_mom":  # beta1 = rho, beta2 = momentum
+                s0[...] = f(s0 + f(f(f(g * g) - s0) * omb1))
+                s1[...] = f(f(s1 * b2) + f(f(lr * g) / f(np.sqrt(f(s0 + eps)))))
+                x[...] = f(x - s1)
+            elif k == "adadelta":     # beta1 = rho
+                s0[...] = f(f(s0 * b1) + f(f(g * g) * omb1))
+                u = f(f(f(np.sqrt(f(s1 + eps))) * f(F32(1.0) / f(np.sqrt(f(s0 + eps))))) * g)
+                x[...] = f(x - f(u * lr))
+                s1[...] = f(f(s1 * b1) + f(f(u * u) * omb1))
+            elif k == "adamax":
+                s0[...] = f(s0 + f(f(g - s0) * omb1))
+                s1[...] = np.maximum(f(b2 * s1), np.abs(g)).astype(F32)
+                x[...] = f(x - f(f(lr_t * s0) / f(s1 + eps)))
+            elif k == "sgd":
+                x[...] = f(x - f(lr * g))
+            else:
+                raise ValueError(k)
 
 
-def transe_pairwise_step(state, pos, eta, seed, step, margin=1.0, n_ents=None, row_offset=0, b_global=None, return_grads=False):
-    """One step of TransE / pairwise (reduction "sum") / Adam on `pos` (int [B, 3]) in the declared order; corruptions from the
-    shared Philox contract (oracle/philox.py, rows j * b_global + row_offset + i).  Updates `state` in place; returns the
-    batch loss (fp64 sum of the fp32 per-positive losses)."""
+def AdamState(ent, rel, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+    return OptState(ent, rel, "adam", lr, beta1, beta2, eps)
+
+
+def transe_pairwise_step(state, pos, eta, seed, step, margin=1.0, n_ents=None, row_offset=0, b_global=None, return_grads=False,
+                         loss="pairwise", layout="quad"):
+    """One step of TransE / pairwise or absolute_margin (reduction "sum") on `pos` (int [B, 3]) in the declared order, then
+    `state.apply`; corruptions from the shared Philox contract (oracle/philox.py, rows j * b_global + row_offset + i).  Updates
+    `state` in place; returns the batch loss (fp64 sum of the fp32 per-positive losses).  layout: how the kernel that is being
+    restated lays a row over the lanes (_lane_sums).
+    absolute_margin (loss_functions.py:458-464): sum_j max(margin + n_j, 0) - eta P, i.e. dL/dP = -eta whatever is active."""
+    assert loss in ("pairwise", "absolute_margin")
     pos = np.asarray(pos, dtype=np.int64)
     B = pos.shape[0]
     ent, rel = state.ent, state.rel
@@ -91,7 +165,7 @@ def transe_pairwise_step(state, pos, eta, seed, step, margin=1.0, n_ents=None, r
     bg = B if b_global is None else int(b_global)
     margin = F32(margin)
     s, p, o = ent[pos[:, 0]], rel[pos[:, 1]], ent[pos[:, 2]]
-    P, d_pos = transe_scores(s, p, o)
+    P, d_pos = transe_scores(s, p, o, layout)
     Ge = np.zeros(ent.shape, dtype=np.float64)   # integers throughout: exact in fp32 as in fp64, in any order
     Gr = np.zeros(rel.shape, dtype=np.float64)
     n_act = np.zeros(B, dtype=np.int64)
@@ -105,8 +179,8 @@ def transe_pairwise_step(state, pos, eta, seed, step, margin=1.0, n_ents=None, r
         keep = keep.astype(bool)
         # object replaced: fl(fl(s + p) - e); subject replaced: fl(fl(e + p) - o)
         d = np.where(keep[:, None], (sp - e).astype(F32), ((e + p).astype(F32) - o).astype(F32))
-        n_j = (F32(-1.0) * wave_sum(_lane_sums(np.abs(d)))).astype(F32)
-        h = (mP + n_j).astype(F32)
+        n_j = (F32(-1.0) * wave_sum(_lane_sums(np.abs(d), layout))).astype(F32)
+        h = (mP + n_j).astype(F32) if loss == "pairwise" else (margin + n_j).astype(F32)
         act = h >= 0
         h_lanes[:, j % 64] = (h_lanes[:, j % 64] + np.maximum(h, F32(0))).astype(F32)
         n_act += act
@@ -118,11 +192,15 @@ def transe_pairwise_step(state, pos, eta, seed, step, margin=1.0, n_ents=None, r
         np.add.at(Ge, pos[~keep, 2], sg[~keep])        #            d/do = +sign(d)
         np.add.at(Gr, pos[:, 1], -sg)                  # d/dp = -sign(d) on either side
     # positive: dL/dP = -(number of active terms); d P / d(s, p, o) = (-, -, +) sign(d)
+    if loss == "absolute_margin":
+        n_act = np.full(B, eta, dtype=np.int64)
     sgp = np.sign(d_pos).astype(np.float64) * n_act[:, None].astype(np.float64)
     np.add.at(Ge, pos[:, 0], sgp)
     np.add.at(Gr, pos[:, 1], sgp)
     np.add.at(Ge, pos[:, 2], -sgp)
     per = wave_sum(h_lanes)
+    if loss == "absolute_margin":   # per = (wave_sum(acc) - feta * P) / red, red = 1 (kge_train_kernel.h loss_and_dscore)
+        per = (per - (F32(eta) * P).astype(F32)).astype(F32)
     assert np.abs(Ge).max() < 2 ** 24 and np.abs(Gr).max() < 2 ** 24
     if return_grads:   # (tests: the step's ingredients, nothing applied)
         return float(per.astype(np.float64).sum()), Ge, Gr
@@ -130,22 +208,23 @@ def transe_pairwise_step(state, pos, eta, seed, step, margin=1.0, n_ents=None, r
     return float(per.astype(np.float64).sum())
 
 
-def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None):
+def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None, opt="adam", opt_hp=None, layout="quad"):
     """The schedule of tests/test_gpu_learning.py (planted graph, Glorot tables as the drop-in class draws them, sequential
-    batches) through transe_pairwise_step -> (loss history, state, id triples of train / test)."""
-    assert model == "TransE" and loss == "pairwise"
+    batches) through transe_pairwise_step -> (loss history, state, id triples of train / test).  opt / opt_hp: the update rule
+    (kge_opt.h kind name) and its (beta1, beta2) descriptor fields."""
+    assert model == "TransE" and loss in ("pairwise", "absolute_margin")
     d = planted_kg(model, seed=seed)
     train, test = d["train"].astype(str), d["test"].astype(str)
     ents, rels = O.first_seen_index(train)
     Xi = O.to_indexes(train, ents, rels)
     N, R, K = len(ents), len(rels), O.internal_k(model, cfg["k"])
     rng = np.random.Generator(np.random.PCG64(seed))
-    st = AdamState(initialise("glorot_uniform", (N, K), rng), initialise("glorot_uniform", (R, K), rng), cfg["lr"])
+    st = OptState(initialise("glorot_uniform", (N, K), rng), initialise("glorot_uniform", (R, K), rng), opt, cfg["lr"], *(opt_hp or (None, None)))
     steps = (len(Xi) + cfg["batch"] - 1) // cfg["batch"]
     hist = []
     for ep in range(cfg["epochs"] if epochs is None else epochs):
         tot = 0.0
         for b in range(steps):
-            tot += transe_pairwise_step(st, Xi[b * cfg["batch"]:(b + 1) * cfg["batch"]], cfg["eta"], seed, ep * steps + b)
+            tot += transe_pairwise_step(st, Xi[b * cfg["batch"]:(b + 1) * cfg["batch"]], cfg["eta"], seed, ep * steps + b, loss=loss, layout=layout)
         hist.append(tot / steps)
     return np.asarray(hist), st, Xi, O.to_indexes(test, ents, rels)

@@ -456,3 +456,44 @@ def test_fullsize_rotate_alternating_batch_sizes_share_one_workspace(gpu_lib, de
         assert _rotate_rows_close(eng.g_ent, ge1, 2e-4) and _rows_close(eng.g_rel, gr1, 2e-4), (step, B)
         if deterministic:
             assert eng.tiled_status() == 0
+
+
+def test_fullsize_c1_steps_bitwise_against_the_ordered_oracle(gpu_lib):
+    """BASELINE configs[0] at FULL size -- TransE k = 50 (stored as 52 units), eta = 5, pairwise loss, Adam, the FB15K-237 shape,
+    B = 10 000 -- three whole steps of the product's StepLoop (the atomic-scatter kernels and the dense sweep: what C1 takes) against
+    oracle/train_ordered.py: BOTH tables and both Adam slots bit-identical, the loss to 1e-12.  (Integer-valued gradients: the order
+    of 200 000 atomic row-adds does not matter; the score tree, the hinge and the update arithmetic do.)"""
+    import torch
+
+    from oracle import train_ordered as TO
+
+    from ampligraph_amd.datasets import make_synthetic_kg
+    from ampligraph_amd.engine import KgeEngine
+    from ampligraph_amd.latent_features import loss_functions, optimizers
+    from ampligraph_amd.trainer import StepLoop
+
+    d = make_synthetic_kg("synth-fb15k237", seed=0)
+    N, R, k, B, eta = d["n_ents"], d["n_rels"], 50, 10000, 5
+    rng = np.random.default_rng(1)
+    lim_e, lim_r = np.sqrt(6.0 / (N + k)), np.sqrt(6.0 / (R + k))
+    ent = rng.uniform(-lim_e, lim_e, size=(N, k)).astype(np.float32)
+    rel = rng.uniform(-lim_r, lim_r, size=(R, k)).astype(np.float32)
+    eng = KgeEngine("TransE", k, N, R, max_rel_size=R)
+    eng.set_tables(ent, rel)
+    loop = StepLoop(eng, eta, loss_functions.get("pairwise"), optimizers.get("adam", {"learning_rate": 1e-2}), None, seed=3, dist=None)
+    # the oracle works on the STORED rows (k = 50 padded to 52 units: the padding is inert but takes part in the lane layout)
+    pad = lambda a: np.concatenate([a, np.zeros((a.shape[0], 2), np.float32)], 1)   # noqa: E731
+    st = TO.OptState(pad(ent), pad(rel), "adam", 1e-2)
+    X = d["train"]
+    Xd = torch.as_tensor(X).cuda()
+    loop.reset_loss()
+    ref = 0.0
+    for step in range(3):
+        loop.step(Xd[step * B:(step + 1) * B], step)
+        ref += TO.transe_pairwise_step(st, X[step * B:(step + 1) * B], eta, 3, step, layout="unit")   # (52 stored units <= 128: one unit per lane)
+    torch.cuda.synchronize()
+    got = loop.mean_batch_loss() * 3
+    e, r = eng.get_tables()
+    assert np.array_equal(e, st.ent[:, :k]) and np.array_equal(r, st.rel[:, :k]), (int((e != st.ent[:, :k]).sum()), int((r != st.rel[:, :k]).sum()))
+    assert np.array_equal(eng.unpack(eng.slots["m_e"]).cpu().numpy(), st.s0[0][:, :k]) and np.array_equal(eng.unpack(eng.slots["v_e"]).cpu().numpy(), st.s1[0][:, :k])
+    assert np.all(st.ent[:, k:] == 0) and abs(got - ref) <= 1e-12 * abs(ref), (got, ref)

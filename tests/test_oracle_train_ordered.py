@@ -20,12 +20,13 @@ def _problem(rng, N=40, R=3, K=16, B=120, dyadic=False):
     return ent, rel, X
 
 
-@pytest.mark.parametrize("K,eta", [(16, 5), (52, 3), (200, 7), (256, 70)])
-def test_ordered_step_equals_oracle_on_dyadic_tables(K, eta):
+@pytest.mark.parametrize("layout", ["quad", "unit"])
+@pytest.mark.parametrize("K,eta", [(16, 5), (52, 3), (200, 7), (256, 70), (352, 4)])
+def test_ordered_step_equals_oracle_on_dyadic_tables(K, eta, layout):
     rng = np.random.default_rng(K)
     ent, rel, X = _problem(rng, K=K, dyadic=True)
     st = TO.AdamState(ent, rel, 1e-2)
-    loss, Ge, Gr = TO.transe_pairwise_step(st, X, eta, 11, 3, margin=1.0, return_grads=True)
+    loss, Ge, Gr = TO.transe_pairwise_step(st, X, eta, 11, 3, margin=1.0, return_grads=True, layout=layout)
     negs = O.generate_corruptions(X, ent.shape[0], eta, 11, 3)
     tot, Re, Rr, _ = O.dense_gradients("TransE", ent, rel, X, negs, eta, "pairwise", None, "sum", rel.shape[0])
     assert np.array_equal(Ge, Re) and np.array_equal(Gr, Rr)
@@ -74,3 +75,59 @@ def test_replay_learning_runs_and_learns():
 
     h64, _, _ = oracle_learning_run("TransE", "pairwise", 0, epochs=6)
     assert abs(hist[0] - h64[0]) <= 1e-5 * abs(h64[0]) and np.max(np.abs(hist - h64) / np.abs(h64)) < 5e-3
+
+
+@pytest.mark.parametrize("kind,hp,okind,ohp", [("sgd", (None, None), "sgd", {}), ("adagrad", (None, None), "adagrad", {}),
+                                               ("momentum", (0.7, 1.0), "momentum", {"momentum": 0.7, "nesterov": True}),
+                                               ("rmsprop", (0.9, 0.0), "rmsprop", {}), ("rmsprop_mom", (0.9, 0.5), "rmsprop_mom", {"momentum": 0.5}),
+                                               ("adadelta", (0.95, 0.0), "adadelta", {}), ("adamax", (0.9, 0.999), "adamax", {})])
+def test_ordered_update_rules_are_the_oracles_rules(kind, hp, okind, ohp):
+    """OptState restates kge_opt.h's opt_elem per rule in fp32; the main oracle states the same Keras-legacy rules: same values up
+    to the last bits (they differ in where hyper-parameter constants are rounded)."""
+    rng = np.random.default_rng(3)
+    ent, rel, _ = _problem(rng)
+    a = TO.OptState(ent, rel, kind, 1e-2, *hp)
+    b = O.TrainState(ent, rel, okind, 1e-2, **ohp)
+    for t in range(4):
+        Ge = rng.integers(-3, 4, size=ent.shape).astype(np.float64)
+        Gr = rng.integers(-3, 4, size=rel.shape).astype(np.float64)
+        a.apply(Ge, Gr)
+        O.apply_optimizer(b, Ge, Gr)
+        assert np.abs(a.ent - b.ent).max() <= 2e-6 * max(1.0, np.abs(b.ent).max()), (kind, t, np.abs(a.ent - b.ent).max())
+
+
+def test_ordered_absolute_margin_equals_oracle_on_dyadic_tables():
+    rng = np.random.default_rng(4)
+    ent, rel, X = _problem(rng, K=32, dyadic=True)
+    st = TO.OptState(ent, rel, "sgd", 1e-2)
+    loss, Ge, Gr = TO.transe_pairwise_step(st, X, 4, 11, 3, margin=1.0, return_grads=True, loss="absolute_margin")
+    negs = O.generate_corruptions(X, ent.shape[0], 4, 11, 3)
+    tot, Re, Rr, _ = O.dense_gradients("TransE", ent, rel, X, negs, 4, "absolute_margin", None, "sum", rel.shape[0])
+    assert np.array_equal(Ge, Re) and np.array_equal(Gr, Rr) and abs(loss - float(tot)) <= 1e-6 * abs(float(tot))
+
+
+def test_lane_layouts_against_an_independent_restatement():
+    """_lane_sums: both row layouts against a scalar loop over (lane, chunk) written from the kernels' index arithmetic."""
+    rng = np.random.default_rng(8)
+    for K in (4, 16, 52, 128, 200, 260, 512):
+        a = np.abs(rng.normal(size=(3, K))).astype(np.float32)
+        for layout in ("quad", "unit"):
+            ref = np.zeros((3, 64), dtype=np.float32)
+            for row in range(3):
+                for lane in range(64):
+                    part = np.float32(0)
+                    if layout == "unit":   # VEC = 1: unit index = lane + 64 c
+                        for c in range((K + 63) // 64):
+                            u = lane + 64 * c
+                            if u < K:
+                                part = np.float32(part + np.float32(np.float32(0) + a[row, u]))
+                    else:                  # VEC = 4: quad index = lane + 64 c, units 4 q .. 4 q + 3 added in order
+                        for c in range((K // 4 + 63) // 64):
+                            q = lane + 64 * c
+                            if q < K // 4:
+                                acc = np.float32(0)
+                                for u in range(4):
+                                    acc = np.float32(acc + a[row, 4 * q + u])
+                                part = np.float32(part + acc)
+                    ref[row, lane] = part
+            assert np.array_equal(TO._lane_sums(a, layout), ref), (K, layout)
