@@ -1526,12 +1526,20 @@ static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const flo
     if (best_cost < 0) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: entity range too large for one launch; split [ent_lo, ent_hi)");
     // distance models with the early-exit workspace: TWO tile kernels are launched per call and one of them returns at once (the
     // probe's choice, kge_rank_early.h) -- with one tile per block that is ~70 000 workgroups dispatched for nothing (measured
-    // 0.25 ms per side at C2); runs of >= 8 tiles keep the blocks few (and amortise the early-exit kernel's per-block thresholds)
-    if (!mfma && d_screen && g_early.on && tiles_per < 8) {
-        tiles_per = etiles < 8 ? etiles : 8;
-        while (tiles_per < etiles && qtiles * ((etiles + tiles_per - 1) / tiles_per) > 16 * slots) ++tiles_per;
+    // 0.25 ms per side at C2); runs of >= 4 tiles keep the blocks few (and amortise the early-exit kernel's per-block thresholds)
+    if (!mfma && d_screen && g_early.on && tiles_per < 4) {
+        // (the same rounds x length cost as above over runs of 4 .. 16 tiles: a run length whose last round is nearly full -- the
+        // plain kernel, when the probe picks it, pays for an underfull last round in full: runs of 8 cost it 10 % at C2)
+        int64_t best = -1, pick = etiles < 4 ? etiles : 4;
+        for (int64_t tp = pick; tp <= 16 && tp <= etiles; ++tp) {
+            const int64_t blocks = qtiles * ((etiles + tp - 1) / tp);
+            if (blocks > 16 * slots) continue;
+            const int64_t cost = ((blocks + slots - 1) / slots) * (tp * 16 + 1);
+            if (best < 0 || cost < best) { best = cost; pick = tp; }
+        }
+        tiles_per = pick;
+        while (tiles_per < etiles && qtiles * ((etiles + tiles_per - 1) / tiles_per) > 65535ll * 16) ++tiles_per;
     }
-    int64_t splits;
     a.ent_per_block = (int)(tiles_per * et_);
     splits = (etiles + tiles_per - 1) / tiles_per;
     const dim3 grid((unsigned)qtiles, (unsigned)splits);

@@ -32,9 +32,12 @@ constexpr int EARLY_STAGE_PAIRS = 512;   // undecided pairs a tile may hand over
 
 struct EarlyCfg {
     int on = 1;
-    int check_l1 = 2, check_rot = 1;   // stages (of KT = 16 units) between two checks (a check is ~6 % of a TransE stage, ~1 % of a RotatE stage)
-    int cost = 12;                     // a re-checked pair's chain costs about this many tile-kernel pair chains (measured ~10: one lane
-                                       // per pair against a 4 x 4 register tile)
+    int check_l1 = 4, check_rot = 1;   // stages (of KT = 16 units) between two checks.  A check is ~15 % of a TransE stage (1.5 issue slots per
+                                       // pair and unit) and ~2 % of a RotatE stage: measured at the C2 shape on planted tables
+                                       // (profiles/r04d_distance_models_sweep.jsonl) TransE 1.25 ms with 4, 1.56 - 1.96 with 2 or 1;
+                                       // RotatE 6.2 - 6.3 ms with 1, 6.6 - 6.8 with 2
+    int cost = 16;                     // a re-checked pair's chain costs about this many tile-kernel pair chains (measured ~10: one lane
+                                       // per pair against a 4 x 4 register tile; handing over 2 % of the pairs costs what it saves)
     int probe = 1;                     // 0: the early-exit kernel always does the work (tests)
 };
 static EarlyCfg g_early;

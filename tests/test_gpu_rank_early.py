@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 def _always_the_early_kernel(gpu_lib):
     """The device-side probe would send untrained-looking tables to the plain kernel: here the early-exit kernel itself is under
     test, so it always does the work (test_probe_* below check the probe)."""
-    gpu_lib.amdkge_set_rank_early(1, 2, 1, 12, 0)
+    gpu_lib.amdkge_set_rank_early(1, 4, 1, 16, 0)
     yield
-    gpu_lib.amdkge_set_rank_early(1, 2, 1, 12, 1)
+    gpu_lib.amdkge_set_rank_early(1, 4, 1, 16, 1)
 
 
 def _counts(eng, gpu_lib, Xd, side, which, **kw):
@@ -155,7 +155,7 @@ def test_early_exit_overflowing_list_falls_back(gpu_lib, model, k):
         assert flag[1] != 0 and flag[0] > 8200
         assert np.array_equal(counts.cpu().numpy(), plain)
     finally:
-        gpu_lib.amdkge_set_rank_early(1, 2, 1, 12, 1)
+        gpu_lib.amdkge_set_rank_early(1, 4, 1, 16, 1)
 
 
 def test_early_exit_switch_and_settings(gpu_lib):
@@ -181,7 +181,7 @@ def test_early_exit_switch_and_settings(gpu_lib):
         off, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_S, 0)
         assert np.array_equal(off, plain) and st is None
     finally:
-        gpu_lib.amdkge_set_rank_early(1, 2, 1, 12, 1)
+        gpu_lib.amdkge_set_rank_early(1, 4, 1, 16, 1)
 
 
 @pytest.mark.parametrize("model,k", [("TransE", 200), ("RotatE", 100)])
@@ -192,7 +192,7 @@ def test_probe_picks_the_kernel_on_the_device(gpu_lib, model, k):
     from ampligraph_amd.engine import KgeEngine
 
     N, R, n = 5000, 5, 512
-    gpu_lib.amdkge_set_rank_early(1, 2, 1, 12, 1)
+    gpu_lib.amdkge_set_rank_early(1, 4, 1, 16, 1)
     for kind in ("gaussian", "trained"):
         rng = np.random.default_rng(21)
         ent, rel, X = _tables(model, k, N, R, n, kind, rng)
