@@ -1538,8 +1538,9 @@ static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const flo
             if (best < 0 || cost < best) { best = cost; pick = tp; }
         }
         tiles_per = pick;
-        while (tiles_per < etiles && qtiles * ((etiles + tiles_per - 1) / tiles_per) > 65535ll * 16) ++tiles_per;
+        while (tiles_per < etiles && (etiles + tiles_per - 1) / tiles_per > 65535) ++tiles_per;   // (the grid's y extent)
     }
+    int64_t splits;
     a.ent_per_block = (int)(tiles_per * et_);
     splits = (etiles + tiles_per - 1) / tiles_per;
     const dim3 grid((unsigned)qtiles, (unsigned)splits);
