@@ -258,11 +258,60 @@ __device__ __forceinline__ void fast_sig_logsig(float y, float& sig, float& logs
     logsig_neg = fminf(-y, 0.f) - (__builtin_amdgcn_logf(u) * 0.6931471805599453f + (t - (u - 1.f)) * r);
 }
 
+// DETERMINISTIC mode (AMDKGE_TILED_DETERMINISTIC): the loss terms from DECLARED transcendentals -- exp and log built from IEEE
+// fp32 operations only (multiply, add, divide, round-to-even, exact scaling by a power of two; -ffp-contract=off keeps every
+// operation where it is written), so that a CPU restates them bit for bit (oracle/train_ordered.py det_exp / det_log12: the same
+// operations in numpy float32).  The hardware v_exp / v_log / v_rcp of the default mode are 1 ulp functions no CPU reproduces.
+// About 1 ulp accurate themselves; ~30 more instructions per evaluation, which only this mode pays.
+__device__ __forceinline__ float det_exp(float x) {
+    // e^x for |x| <= 80 (clamped): n = rint(x log2 e); r = (x - n ln2_hi) - n ln2_lo (Cody-Waite: ln2_hi = 355/512 has 9 bits, so
+    // n ln2_hi is exact for |n| < 2^15); e^r by its Taylor polynomial of degree 7 in Horner form; scaled by 2^n exactly
+    x = fminf(fmaxf(x, -80.f), 80.f);
+    const float n = rintf(x * 1.4426950216293335f);
+    const float r = (x - n * 0.693359375f) - n * -2.12194440e-4f;
+    float p = 1.f / 5040.f;
+    p = p * r + 1.f / 720.f;
+    p = p * r + 1.f / 120.f;
+    p = p * r + 1.f / 24.f;
+    p = p * r + 1.f / 6.f;
+    p = p * r + 0.5f;
+    p = p * r + 1.f;
+    p = p * r + 1.f;
+    return ldexpf(p, (int)n);
+}
+__device__ __forceinline__ float det_log12(float u) {
+    // log(u) for u in [1, 2]: 2 atanh(z), z = (u - 1) / (u + 1) in [0, 1/3]; the odd series up to z^15 (next term < 2e-9 relative)
+    const float z = (u - 1.f) / (u + 1.f);
+    const float w = z * z;
+    float p = 1.f / 15.f;
+    p = p * w + 1.f / 13.f;
+    p = p * w + 1.f / 11.f;
+    p = p * w + 1.f / 9.f;
+    p = p * w + 1.f / 7.f;
+    p = p * w + 1.f / 5.f;
+    p = p * w + 1.f / 3.f;
+    p = p * w + 1.f;
+    return (2.f * z) * p;
+}
+// sigma(y) and log sigma(-y) = -softplus(y), the declared forms: t = e^-|y|, u = 1 + t, sigma = 1 / u or t / u,
+// softplus = max(y, 0) + log(u) + (t - (u - 1)) / u
+__device__ __forceinline__ void det_sig_logsig(float y, float& sig, float& logsig_neg) {
+    const float t = det_exp(-fabsf(y));
+    const float u = 1.f + t;
+    sig = (y >= 0.f) ? 1.f / u : t / u;
+    logsig_neg = fminf(-y, 0.f) - (det_log12(u) + (t - (u - 1.f)) / u);
+}
+// (the two families behind one call: `det` is wave-uniform)
+__device__ __forceinline__ void sig_logsig(bool det, float y, float& sig, float& logsig_neg) {
+    if (det) det_sig_logsig(y, sig, logsig_neg); else fast_sig_logsig(y, sig, logsig_neg);
+}
+__device__ __forceinline__ float exp_any(bool det, float x) { return det ? det_exp(x) : fast_exp(x); }
+
 // Coefficients of up to 64 rows at once: lane f holds the score n of one row (valid == false: no row).  Returns the
 // lane's c1, c2 and the wave-uniform factor by which everything accumulated so far must be rescaled (self-adversarial
 // loss: the running softmax maximum grew), 1 otherwise.
 __device__ __forceinline__ float onepass_coeff(const amdkge_loss& L, float P, float n, bool valid, OnePassState& st,
-                                               float& c1, float& c2) {
+                                               float& c1, float& c2, bool det = false) {
     c1 = 0.f;
     c2 = 0.f;
     float rescale = 1.f;
@@ -271,7 +320,7 @@ __device__ __forceinline__ float onepass_coeff(const amdkge_loss& L, float P, fl
         case AMDKGE_LOSS_NLL: {
             const bool in = valid && (n >= -75.f) && (n <= 75.f);
             float sg, lsn;
-            fast_sig_logsig(fminf(fmaxf(n, -75.f), 75.f), sg, lsn);
+            sig_logsig(det, fminf(fmaxf(n, -75.f), 75.f), sg, lsn);
             st.Lw += valid ? -lsn : 0.f;   // softplus(clip n) = log(1 + exp(clip n))
             c1 = in ? sg : 0.f;
         } break;
@@ -280,19 +329,19 @@ __device__ __forceinline__ float onepass_coeff(const amdkge_loss& L, float P, fl
             const float x = L.alpha * n;
             const float gm = wave_max(valid ? x : -INFINITY);
             if (gm > st.m) {
-                rescale = (st.m == -INFINITY) ? 0.f : fast_exp(st.m - gm);   // nothing accumulated before the first group
+                rescale = (st.m == -INFINITY) ? 0.f : exp_any(det, st.m - gm);   // nothing accumulated before the first group
                 st.S *= rescale; st.Lw *= rescale; st.m = gm;
             }
-            const float u = valid ? fast_exp(x - st.m) : 0.f;
+            const float u = valid ? exp_any(det, x - st.m) : 0.f;
             float sg, ell;
-            fast_sig_logsig(n + L.margin, sg, ell);   // sigma(n + gamma), l = log sigma(-n - gamma)
+            sig_logsig(det, n + L.margin, sg, ell);   // sigma(n + gamma), l = log sigma(-n - gamma)
             st.S += u; st.Lw += valid ? u * ell : 0.f;
             c1 = valid ? u * (sg - L.alpha * ell) : 0.f;
             c2 = u;
         } break;
         default: {
             const bool in = valid && (n >= -75.f) && (n <= 75.f);
-            const float ex = valid ? fast_exp(fminf(fmaxf(n, -75.f), 75.f)) : 0.f;
+            const float ex = valid ? exp_any(det, fminf(fmaxf(n, -75.f), 75.f)) : 0.f;
             st.Zs += ex;
             c1 = in ? ex : 0.f;
         } break;
@@ -301,7 +350,7 @@ __device__ __forceinline__ float onepass_coeff(const amdkge_loss& L, float P, fl
 }
 
 // st holds the wave totals here (wave_sum of the per-lane partials)
-__device__ __forceinline__ void onepass_kappa(const amdkge_loss& L, float P, int eta, const OnePassState& st, float& k1, float& k2) {
+__device__ __forceinline__ void onepass_kappa(const amdkge_loss& L, float P, int eta, const OnePassState& st, float& k1, float& k2, bool det = false) {
     const float feta = (float)eta;
     float red = L.reduction_mean ? feta : 1.f;
     k2 = 0.f;
@@ -309,7 +358,7 @@ __device__ __forceinline__ void onepass_kappa(const amdkge_loss& L, float P, int
         case AMDKGE_LOSS_NLL: if (L.reduction_mean) red = 2.f * feta; k1 = 1.f / red; break;
         case AMDKGE_LOSS_SELF_ADVERSARIAL: k1 = 1.f / (st.S * red); k2 = L.alpha * (st.Lw / st.S) / (st.S * red); break;
         case AMDKGE_LOSS_MULTICLASS_NLL: {
-            const float eP = fast_exp(fminf(fmaxf(P, -75.f), 75.f));
+            const float eP = exp_any(det, fminf(fmaxf(P, -75.f), 75.f));
             k1 = 1.f / ((st.Zs / red + eP) * red);
         } break;
         default: k1 = 1.f / red; break;
@@ -319,7 +368,7 @@ __device__ __forceinline__ void onepass_kappa(const amdkge_loss& L, float P, int
 // Loss.__call__ for one positive on the single-pass path: same outputs as loss_and_dscore (per-sample loss, dL/dpos,
 // sn[j] <- dL/dneg_j) from the statistics the row loop already gathered (st = wave totals).
 __device__ __forceinline__ void onepass_finish(const amdkge_loss& L, float P, float* sn, int eta, int lane,
-                                               const OnePassState& st, float& per, float& dP) {
+                                               const OnePassState& st, float& per, float& dP, bool det = false) {
     const float feta = (float)eta;
     float red = L.reduction_mean ? feta : 1.f;
     switch (L.kind) {
@@ -327,11 +376,11 @@ __device__ __forceinline__ void onepass_finish(const amdkge_loss& L, float P, fl
             if (L.reduction_mean) red = 2.f * feta;
             const bool inP = (P >= -75.f) && (P <= 75.f);
             float sgP, lsP;
-            fast_sig_logsig(-fminf(fmaxf(P, -75.f), 75.f), sgP, lsP);   // sigma(-Pc), log sigma(Pc)
+            sig_logsig(det, -fminf(fmaxf(P, -75.f), 75.f), sgP, lsP);   // sigma(-Pc), log sigma(Pc)
             for (int j = lane; j < eta; j += KGE_WAVE) {
                 const float n = sn[j];
                 float sg, ls;
-                fast_sig_logsig(fminf(fmaxf(n, -75.f), 75.f), sg, ls);
+                sig_logsig(det, fminf(fmaxf(n, -75.f), 75.f), sg, ls);
                 sn[j] = ((n >= -75.f) && (n <= 75.f)) ? sg / red : 0.f;
             }
             per = (feta * -lsP + st.Lw) / red;   // log(1+exp(-Pc)) = -log sigma(Pc)
@@ -341,26 +390,26 @@ __device__ __forceinline__ void onepass_finish(const amdkge_loss& L, float P, fl
             const float lbar = st.Lw / st.S;
             for (int j = lane; j < eta; j += KGE_WAVE) {
                 const float n = sn[j];
-                const float w = fast_exp(L.alpha * n - st.m) / st.S;
+                const float w = exp_any(det, L.alpha * n - st.m) / st.S;
                 float sg, ell;
-                fast_sig_logsig(n + L.margin, sg, ell);
+                sig_logsig(det, n + L.margin, sg, ell);
                 sn[j] = (w * sg - L.alpha * w * (ell - lbar)) / red;
             }
             float sgP, lsP;
-            fast_sig_logsig(-(L.margin + P), sgP, lsP);   // sigma(-(gamma+P)), log sigma(gamma+P)
+            sig_logsig(det, -(L.margin + P), sgP, lsP);   // sigma(-(gamma+P)), log sigma(gamma+P)
             per = -lsP - lbar / red;
             dP = -sgP;
         } break;
         default: {   // AMDKGE_LOSS_MULTICLASS_NLL :647-654
             const bool inP = (P >= -75.f) && (P <= 75.f);
             const float Pc = fminf(fmaxf(P, -75.f), 75.f);
-            const float eP = fast_exp(Pc);
+            const float eP = exp_any(det, Pc);
             const float Z = st.Zs / red + eP;
             for (int j = lane; j < eta; j += KGE_WAVE) {
                 const float n = sn[j];
-                sn[j] = ((n >= -75.f) && (n <= 75.f)) ? fast_exp(fminf(fmaxf(n, -75.f), 75.f)) / Z / red : 0.f;
+                sn[j] = ((n >= -75.f) && (n <= 75.f)) ? exp_any(det, fminf(fmaxf(n, -75.f), 75.f)) / Z / red : 0.f;
             }
-            per = __builtin_amdgcn_logf(Z) * 0.6931471805599453f - Pc;   // -log(eP / Z)
+            per = (det ? logf(Z) : __builtin_amdgcn_logf(Z) * 0.6931471805599453f) - Pc;   // -log(eP / Z)  (the loss VALUE only: nothing feeds back)
             dP = inP ? -1.f + eP / Z : 0.f;
         } break;
     }
@@ -743,7 +792,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                     if (focus_nl) sh_dfac[jl] = dfl;
                 }
                 float c1l, c2l;
-                const float rs = onepass_coeff(a.loss, P1, nv, lane_valid, ops, c1l, c2l);
+                const float rs = onepass_coeff(a.loss, P1, nv, lane_valid, ops, c1l, c2l, a.det != 0);
                 c1l *= dfl; c2l *= dfl;   // d(neg')/d(neg) folded into the accumulation weights
                 if (rs != 1.f) {   // the running softmax maximum grew: rescale what has been accumulated
 #pragma unroll
@@ -909,7 +958,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     if constexpr (ONEPASS) {
         // pairwise / absolute_margin have no transcendental and keep the generic evaluation
         if (a.loss.kind == AMDKGE_LOSS_PAIRWISE || a.loss.kind == AMDKGE_LOSS_ABSOLUTE_MARGIN) { if (W == 1 || wv == 0) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP); }
-        else if (W == 1 || wv == 0) onepass_finish(a.loss, P, sh_neg, eta, lane, ops, per, dP);   // (rewrites sh_neg in place: one wave)
+        else if (W == 1 || wv == 0) onepass_finish(a.loss, P, sh_neg, eta, lane, ops, per, dP, a.det != 0);   // (rewrites sh_neg in place: one wave)
     } else if (W == 1 || wv == 0) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP);
     if constexpr (W > 1) {
         if (wv == 0 && lane == 0) sh_part[0] = dP;
@@ -1009,7 +1058,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         // E_side = sum_j g_j e_j (g_j incl. score scale) from the two coefficient sums; the gradients of s, p, o are
         // linear in it
         float k1, k2;
-        onepass_kappa(a.loss, P, eta, ops, k1, k2);
+        onepass_kappa(a.loss, P, eta, ops, k1, k2, a.det != 0);
         k1 *= sgn_scale; k2 *= sgn_scale;
 #pragma unroll
         for (int c = 0; c < CH; ++c)

@@ -212,7 +212,7 @@ def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None,
     """The schedule of tests/test_gpu_learning.py (planted graph, Glorot tables as the drop-in class draws them, sequential
     batches) through transe_pairwise_step -> (loss history, state, id triples of train / test).  opt / opt_hp: the update rule
     (kge_opt.h kind name) and its (beta1, beta2) descriptor fields."""
-    assert model == "TransE" and loss in ("pairwise", "absolute_margin")
+    assert model == "TransE" and loss in ("pairwise", "absolute_margin", "nll")
     d = planted_kg(model, seed=seed)
     train, test = d["train"].astype(str), d["test"].astype(str)
     ents, rels = O.first_seen_index(train)
@@ -225,6 +225,156 @@ def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None,
     for ep in range(cfg["epochs"] if epochs is None else epochs):
         tot = 0.0
         for b in range(steps):
-            tot += transe_pairwise_step(st, Xi[b * cfg["batch"]:(b + 1) * cfg["batch"]], cfg["eta"], seed, ep * steps + b, loss=loss, layout=layout)
+            xb = Xi[b * cfg["batch"]:(b + 1) * cfg["batch"]]
+            if loss == "nll":   # (deterministic mode only: the owner-computes pair, quad layout)
+                tot += transe_nll_step_det(st, xb, cfg["eta"], seed, ep * steps + b)
+            else:
+                tot += transe_pairwise_step(st, xb, cfg["eta"], seed, ep * steps + b, loss=loss, layout=layout)
         hist.append(tot / steps)
     return np.asarray(hist), st, Xi, O.to_indexes(test, ents, rels)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# TransE / nll in DETERMINISTIC mode (AMDKGE_TILED_DETERMINISTIC): real-valued coefficients, so the order of every fp32 addition
+# into a gradient row matters -- the mode's canonical order is restated: the loss terms from the DECLARED transcendentals
+# (kge_train_kernel.h det_exp / det_log12: IEEE operations only), the single-pass forward kernel's per-side sums in corruption
+# order, the tile pass adding a row's entries sorted by (positive, role, bits of g), the relation gradient in batch order.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _f(a):
+    return np.asarray(a).astype(F32)
+
+
+def det_exp(x):
+    x = np.clip(_f(x), F32(-80.0), F32(80.0))
+    n = np.rint(_f(x * F32(1.4426950216293335)))
+    r = _f(_f(x - _f(n * F32(0.693359375))) - _f(n * F32(-2.12194440e-4)))
+    p = np.full_like(r, F32(1.0) / F32(5040.0))
+    for c in (F32(1.0) / F32(720.0), F32(1.0) / F32(120.0), F32(1.0) / F32(24.0), F32(1.0) / F32(6.0), F32(0.5), F32(1.0), F32(1.0)):
+        p = _f(_f(p * r) + c)
+    return np.ldexp(p, n.astype(np.int32)).astype(F32)
+
+
+def det_log12(u):
+    u = _f(u)
+    z = _f(_f(u - F32(1.0)) / _f(u + F32(1.0)))
+    w = _f(z * z)
+    p = np.full_like(z, F32(1.0) / F32(15.0))
+    for c in (F32(1.0) / F32(13.0), F32(1.0) / F32(11.0), F32(1.0) / F32(9.0), F32(1.0) / F32(7.0), F32(1.0) / F32(5.0), F32(1.0) / F32(3.0), F32(1.0)):
+        p = _f(_f(p * w) + c)
+    return _f(_f(F32(2.0) * z) * p)
+
+
+def det_sig_logsig(y):
+    """(sigma(y), log sigma(-y)) as kge_train_kernel.h det_sig_logsig."""
+    y = _f(y)
+    t = det_exp(-np.abs(y))
+    u = _f(F32(1.0) + t)
+    sig = np.where(y >= 0, _f(F32(1.0) / u), _f(t / u)).astype(F32)
+    ls = _f(np.minimum(-y, F32(0.0)) - _f(det_log12(u) + _f(_f(t - _f(u - F32(1.0))) / u)))
+    return sig, ls
+
+
+def transe_nll_step_det(state, pos, eta, seed, step, n_ents=None, return_grads=False):
+    """One step of TransE / nll (reduction "sum") as the owner-computes pair carries it out in deterministic mode (rows of up to
+    256 units: one wave per positive, one quad per lane).  Updates `state`; returns the batch loss."""
+    PF = 6   # rows the forward kernel scores per group (KGE_PF): only the lane layout of the loss VALUE depends on it
+    pos = np.asarray(pos, dtype=np.int64)
+    B = pos.shape[0]
+    ent, rel = state.ent, state.rel
+    K = ent.shape[1]
+    assert K % 4 == 0 and K <= 256
+    N = ent.shape[0] if n_ents is None else int(n_ents)
+    s, p, o = ent[pos[:, 0]], rel[pos[:, 1]], ent[pos[:, 2]]
+    P, d_pos = transe_scores(s, p, o, "quad")
+    sp = _f(s + p)
+    keep = np.zeros((B, eta), dtype=bool)
+    repl = np.zeros((B, eta), dtype=np.int64)
+    sgn = np.zeros((B, eta, K), dtype=F32)      # sign(d_j) per unit
+    nsc = np.zeros((B, eta), dtype=F32)
+    for j in range(eta):
+        rows = np.uint64(j) * np.uint64(B) + np.arange(B, dtype=np.uint64)
+        kj, rj = sample_corruption_draws(rows, step, seed, N)
+        keep[:, j], repl[:, j] = kj.astype(bool), rj
+        e = ent[rj]
+        d = np.where(keep[:, j][:, None], _f(sp - e), _f(_f(e + p) - o))
+        sgn[:, j] = np.sign(d)
+        nsc[:, j] = _f(F32(-1.0) * wave_sum(_lane_sums(np.abs(d), "quad")))
+    inr = (nsc >= F32(-75.0)) & (nsc <= F32(75.0))
+    sg, lsn = det_sig_logsig(np.clip(nsc, F32(-75.0), F32(75.0)))
+    c1 = np.where(inr, sg, F32(0.0)).astype(F32)                 # dL/dn_j (red = 1)
+    # per-side sums  sum_j c1_j sign(d_j)  in corruption order within the side (object-replaced rows first, then subject-replaced)
+    av = np.zeros((2, B, K), dtype=F32)
+    for j in range(eta):
+        term = _f(c1[:, j][:, None] * sgn[:, j])                # (+-c1 or 0: exact)
+        kj = keep[:, j]
+        av[0][kj] = _f(av[0][kj] + term[kj])
+        av[1][~kj] = _f(av[1][~kj] + term[~kj])
+    Go, Gs = _f(F32(-1.0) * av[0]), _f(F32(-1.0) * av[1])       # k1 = 1 / red * sgn_scale = -1, k2 = 0
+    # the positive: dP = -eta sigma(-Pc) (in range), g = dP * sgn_scale
+    Pc = np.clip(P, F32(-75.0), F32(75.0))
+    sgP, lsP = det_sig_logsig(-Pc)
+    inP = (P >= F32(-75.0)) & (P <= F32(75.0))
+    dP = np.where(inP, _f(_f(F32(-float(eta)) * sgP) / F32(1.0)), F32(0.0)).astype(F32)
+    gpos = _f(dP * F32(-1.0))
+    sgv = _f(np.sign(d_pos) * gpos[:, None])                    # g sign(d): ds = dp = sgv, dd = -sgv
+    gs = _f(sgv + Go)
+    gp = _f(sgv + _f(Go + Gs))
+    go = _f(_f(-sgv) - Gs)
+    # loss value: per = (eta * -lsP + Lw) / red, Lw = wave tree over the lanes' partial sums (lane f takes row f of every group of PF)
+    lanes = np.zeros((B, 64), dtype=F32)
+    soft = _f(-lsn)                                             # softplus(clip n_j)
+    order = np.argsort(~keep, axis=1, kind="stable")            # object-replaced (keep) first, j ascending within a side
+    nkeep = keep.sum(1)
+    for side in (0, 1):
+        cnt = nkeep if side == 0 else eta - nkeep
+        start = np.zeros(B, dtype=np.int64) if side == 0 else nkeep
+        for g0 in range(0, eta, PF):
+            for f in range(PF):
+                idx = g0 + f
+                ok = idx < cnt
+                jj = order[np.arange(B), np.minimum(start + idx, eta - 1)]
+                val = np.where(ok, soft[np.arange(B), jj], F32(0.0)).astype(F32)
+                lanes[:, f] = np.where(ok, _f(lanes[:, f] + val), lanes[:, f])
+    Lw = wave_sum(lanes)
+    per = _f(_f(_f(F32(float(eta)) * _f(-lsP)) + Lw) / F32(1.0))
+    # ---- tile pass, deterministic: a row's entries sorted by (positive, role, bits of g), added from 0 in that order ----
+    ent_dest, ent_pos, ent_role, ent_g, ent_vec = [], [], [], [], []
+    ar = np.arange(B)
+    for j in range(eta):
+        g_e = _f(c1[:, j] * F32(-1.0))                          # entry g = dL/dn_j * sgn_scale
+        live = g_e != 0
+        role = np.where(keep[:, j], 0, 1)
+        # role 0: out = -(g sign(d)) ; role 1: out = g sign(d)
+        gs_d = _f(g_e[:, None] * sgn[:, j])
+        vec = np.where(keep[:, j][:, None], _f(-gs_d), gs_d).astype(F32)
+        ent_dest.append(repl[live, j]); ent_pos.append(ar[live]); ent_role.append(role[live]); ent_g.append(g_e[live]); ent_vec.append(vec[live])
+    one = np.ones(B, dtype=F32)
+    ent_dest += [pos[:, 0], pos[:, 2]]; ent_pos += [ar, ar]; ent_role += [np.full(B, 2), np.full(B, 3)]; ent_g += [one, one]; ent_vec += [gs, go]
+    dest = np.concatenate(ent_dest); epos = np.concatenate(ent_pos); role = np.concatenate(ent_role)
+    gbits = np.concatenate(ent_g).astype(F32).view(np.uint32).astype(np.int64)
+    vec = np.concatenate(ent_vec).astype(F32)
+    srt = np.lexsort((gbits, role, epos, dest))
+    dest, vec = dest[srt], vec[srt]
+    Ge = np.zeros(ent.shape, dtype=F32)
+    first = np.r_[True, dest[1:] != dest[:-1]]
+    start_of = np.maximum.accumulate(np.where(first, np.arange(len(dest)), 0))
+    rank_in_row = np.arange(len(dest)) - start_of
+    for r in range(int(rank_in_row.max()) + 1 if len(dest) else 0):
+        m = rank_in_row == r
+        Ge[dest[m]] = _f(Ge[dest[m]] + vec[m])
+    # ---- relation gradient: the positives' staged rows added per relation in batch order ----
+    Gr = np.zeros(rel.shape, dtype=F32)
+    rrel = pos[:, 1]
+    srt_r = np.argsort(rrel, kind="stable")
+    rs, gpv = rrel[srt_r], gp[srt_r]
+    first = np.r_[True, rs[1:] != rs[:-1]]
+    start_of = np.maximum.accumulate(np.where(first, np.arange(B), 0))
+    rk = np.arange(B) - start_of
+    for r in range(int(rk.max()) + 1 if B else 0):
+        m = rk == r
+        Gr[rs[m]] = _f(Gr[rs[m]] + gpv[m])
+    loss = float(per.astype(np.float64).sum())
+    if return_grads:
+        return loss, Ge, Gr
+    state.apply(Ge, Gr)
+    return loss

@@ -131,3 +131,28 @@ def test_lane_layouts_against_an_independent_restatement():
                                 part = np.float32(part + acc)
                     ref[row, lane] = part
             assert np.array_equal(TO._lane_sums(a, layout), ref), (K, layout)
+
+
+def test_declared_transcendentals_are_accurate():
+    """det_exp / det_log12 / det_sig_logsig (the deterministic mode's CPU-reproducible loss terms): within a few 1e-7 of libm."""
+    x = np.linspace(-80, 80, 100001).astype(np.float32)
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(TO.det_exp(x).astype(np.float64) - ref) / ref) < 3e-7
+    u = np.linspace(1, 2, 50001).astype(np.float32)
+    assert np.max(np.abs(TO.det_log12(u).astype(np.float64) - np.log(u.astype(np.float64)))) < 3e-7
+    y = np.linspace(-75, 75, 30001).astype(np.float32)
+    sg, ls = TO.det_sig_logsig(y)
+    rs, rl = 1 / (1 + np.exp(-y.astype(np.float64))), -np.logaddexp(0, y.astype(np.float64))
+    assert np.max(np.abs(sg - rs) / rs) < 5e-7 and np.max(np.abs(ls - rl) / np.maximum(np.abs(rl), 1e-300)) < 1e-6
+
+
+@pytest.mark.parametrize("K,eta", [(16, 5), (64, 13), (200, 3)])
+def test_ordered_nll_step_is_the_oracles_step_up_to_rounding(K, eta):
+    rng = np.random.default_rng(K)
+    ent, rel, X = _problem(rng, N=60, K=K, B=300)
+    st = TO.OptState(ent, rel, "adam", 1e-2)
+    loss, Ge, Gr = TO.transe_nll_step_det(st, X, eta, 5, 2, return_grads=True)
+    negs = O.generate_corruptions(X, ent.shape[0], eta, 5, 2)
+    tot, Re, Rr, _ = O.dense_gradients("TransE", ent, rel, X, negs, eta, "nll", None, "sum", rel.shape[0])
+    assert abs(loss - float(tot)) <= 2e-6 * abs(float(tot))
+    assert np.abs(Ge - Re).max() <= 2e-6 * np.abs(Re).max() and np.abs(Gr - Rr).max() <= 2e-6 * np.abs(Rr).max()
