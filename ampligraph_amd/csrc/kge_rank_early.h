@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256) void rank_early_probe_kernel(ProbeArgs a) {
     const float thr = early_threshold(a.qpos[qi], a.sgn_scale);
     const int half = ((a.g.U / 2) + 3) & ~3;
     float acc = 0.f;
+    // (four quads per trip: the probe sits on the call's critical path and a thread's loads are independent of its running sum --
+    // one quad at a time cost ~25 dependent round trips to rows nobody has touched yet, ~50 us)
+#pragma unroll 4
     for (int u0 = 0; u0 < half; u0 += 4) {
         float qv[NQF][4], ev[NEF][4];
 #pragma unroll
