@@ -187,25 +187,32 @@ __global__ __launch_bounds__(256) void rank_early_probe_kernel(ProbeArgs a) {
     const float thr = early_threshold(a.qpos[qi], a.sgn_scale);
     const int half = ((a.g.U / 2) + 3) & ~3;
     float acc = 0.f;
-    // (four quads per trip: the probe sits on the call's critical path and a thread's loads are independent of its running sum --
-    // one quad at a time cost ~25 dependent round trips to rows nobody has touched yet, ~50 us)
-#pragma unroll 4
-    for (int u0 = 0; u0 < half; u0 += 4) {
-        float qv[NQF][4], ev[NEF][4];
+    // (four quads per trip, all their loads issued before the first is used: the probe sits on the call's critical path and a
+    // thread's loads do not depend on its running sum -- one quad at a time cost ~25 dependent round trips to rows nobody has
+    // touched yet, ~50 us)
+    for (int u0 = 0; u0 < half; u0 += 16) {
+        float4 q4[4][NQF], e4[4][NEF];
 #pragma unroll
-        for (int f = 0; f < NQF; ++f) { const float4 v = *reinterpret_cast<const float4*>(qrow + (int64_t)f * a.g.qplane + u0); qv[f][0] = v.x; qv[f][1] = v.y; qv[f][2] = v.z; qv[f][3] = v.w; }
+        for (int t = 0; t < 4; ++t) {
+            const int uu = min(u0 + 4 * t, half - 4);   // (past the end: a re-read that is not used)
 #pragma unroll
-        for (int f = 0; f < NEF; ++f) { const float4 v = *reinterpret_cast<const float4*>(erow + (int64_t)f * a.g.eplane + u0); ev[f][0] = v.x; ev[f][1] = v.y; ev[f][2] = v.z; ev[f][3] = v.w; }
+            for (int f = 0; f < NQF; ++f) q4[t][f] = *reinterpret_cast<const float4*>(qrow + (int64_t)f * a.g.qplane + uu);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (u0 + u < a.g.U) {
-                float qq[NQF], ee[NEF];
+            for (int f = 0; f < NEF; ++f) e4[t][f] = *reinterpret_cast<const float4*>(erow + (int64_t)f * a.g.eplane + uu);
+        }
 #pragma unroll
-                for (int f = 0; f < NQF; ++f) qq[f] = qv[f][u];
+        for (int t = 0; t < 4; ++t) {
 #pragma unroll
-                for (int f = 0; f < NEF; ++f) ee[f] = ev[f][u];
-                if constexpr (MODE == MODE_ROT_O || MODE == MODE_ROT_S) acc = rot_exact_op<MODE>(acc, qq, ee);
-                else acc = rank_op<MODE>(acc, qq, ee, a.g.sgn);
+            for (int u = 0; u < 4; ++u) {
+                if (u0 + 4 * t + u < half && u0 + 4 * t + u < a.g.U) {
+                    float qq[NQF], ee[NEF];
+#pragma unroll
+                    for (int f = 0; f < NQF; ++f) qq[f] = (&q4[t][f].x)[u];
+#pragma unroll
+                    for (int f = 0; f < NEF; ++f) ee[f] = (&e4[t][f].x)[u];
+                    if constexpr (MODE == MODE_ROT_O || MODE == MODE_ROT_S) acc = rot_exact_op<MODE>(acc, qq, ee);
+                    else acc = rank_op<MODE>(acc, qq, ee, a.g.sgn);
+                }
             }
         }
     }
