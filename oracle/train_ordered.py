@@ -212,7 +212,7 @@ def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None,
     """The schedule of tests/test_gpu_learning.py (planted graph, Glorot tables as the drop-in class draws them, sequential
     batches) through transe_pairwise_step -> (loss history, state, id triples of train / test).  opt / opt_hp: the update rule
     (kge_opt.h kind name) and its (beta1, beta2) descriptor fields."""
-    assert model == "TransE" and loss in ("pairwise", "absolute_margin", "nll")
+    assert model == "TransE" and loss in ("pairwise", "absolute_margin", "nll", "self_adversarial", "multiclass_nll")
     d = planted_kg(model, seed=seed)
     train, test = d["train"].astype(str), d["test"].astype(str)
     ents, rels = O.first_seen_index(train)
@@ -226,8 +226,8 @@ def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None,
         tot = 0.0
         for b in range(steps):
             xb = Xi[b * cfg["batch"]:(b + 1) * cfg["batch"]]
-            if loss == "nll":   # (deterministic mode only: the owner-computes pair, quad layout)
-                tot += transe_nll_step_det(st, xb, cfg["eta"], seed, ep * steps + b)
+            if loss in ("nll", "self_adversarial", "multiclass_nll"):   # (deterministic mode only: the owner-computes pair, quad layout)
+                tot += transe_step_det(st, xb, cfg["eta"], seed, ep * steps + b, loss)
             else:
                 tot += transe_pairwise_step(st, xb, cfg["eta"], seed, ep * steps + b, loss=loss, layout=layout)
         hist.append(tot / steps)
@@ -274,22 +274,30 @@ def det_sig_logsig(y):
     return sig, ls
 
 
-def transe_nll_step_det(state, pos, eta, seed, step, n_ents=None, return_grads=False):
-    """One step of TransE / nll (reduction "sum") as the owner-computes pair carries it out in deterministic mode (rows of up to
-    256 units: one wave per positive, one quad per lane).  Updates `state`; returns the batch loss."""
-    PF = 6   # rows the forward kernel scores per group (KGE_PF): only the lane layout of the loss VALUE depends on it
+def transe_step_det(state, pos, eta, seed, step, loss="nll", margin=None, alpha=0.5, n_ents=None, return_grads=False):
+    """One step of TransE with a transcendental loss -- "nll", "self_adversarial" or "multiclass_nll", reduction "sum" -- as the
+    owner-computes pair carries it out in DETERMINISTIC mode (rows of up to 256 units: one wave per positive, one quad per lane).
+    The single-pass forward kernel's protocol is restated group by group (kge_train_kernel.h onepass_coeff / onepass_kappa /
+    onepass_finish): corruptions ordered by side (object-replaced first), scored PF = 6 at a time, lane f of a group holding row f's
+    loss terms and its share of the running statistics; self_adversarial's online softmax (running maximum, rescale of everything
+    accumulated so far when it grows).  Updates `state`; returns the batch loss."""
+    assert loss in ("nll", "self_adversarial", "multiclass_nll")
+    PF = 6
     pos = np.asarray(pos, dtype=np.int64)
     B = pos.shape[0]
     ent, rel = state.ent, state.rel
     K = ent.shape[1]
     assert K % 4 == 0 and K <= 256
     N = ent.shape[0] if n_ents is None else int(n_ents)
+    gamma = F32(3.0 if margin is None else margin)   # self_adversarial's margin (loss_functions.py:26)
+    alpha = F32(alpha)
+    feta = F32(float(eta))
     s, p, o = ent[pos[:, 0]], rel[pos[:, 1]], ent[pos[:, 2]]
     P, d_pos = transe_scores(s, p, o, "quad")
     sp = _f(s + p)
     keep = np.zeros((B, eta), dtype=bool)
     repl = np.zeros((B, eta), dtype=np.int64)
-    sgn = np.zeros((B, eta, K), dtype=F32)      # sign(d_j) per unit
+    sgn = np.zeros((B, eta, K), dtype=F32)
     nsc = np.zeros((B, eta), dtype=F32)
     for j in range(eta):
         rows = np.uint64(j) * np.uint64(B) + np.arange(B, dtype=np.uint64)
@@ -299,54 +307,116 @@ def transe_nll_step_det(state, pos, eta, seed, step, n_ents=None, return_grads=F
         d = np.where(keep[:, j][:, None], _f(sp - e), _f(_f(e + p) - o))
         sgn[:, j] = np.sign(d)
         nsc[:, j] = _f(F32(-1.0) * wave_sum(_lane_sums(np.abs(d), "quad")))
-    inr = (nsc >= F32(-75.0)) & (nsc <= F32(75.0))
-    sg, lsn = det_sig_logsig(np.clip(nsc, F32(-75.0), F32(75.0)))
-    c1 = np.where(inr, sg, F32(0.0)).astype(F32)                 # dL/dn_j (red = 1)
-    # per-side sums  sum_j c1_j sign(d_j)  in corruption order within the side (object-replaced rows first, then subject-replaced)
-    av = np.zeros((2, B, K), dtype=F32)
-    for j in range(eta):
-        term = _f(c1[:, j][:, None] * sgn[:, j])                # (+-c1 or 0: exact)
-        kj = keep[:, j]
-        av[0][kj] = _f(av[0][kj] + term[kj])
-        av[1][~kj] = _f(av[1][~kj] + term[~kj])
-    Go, Gs = _f(F32(-1.0) * av[0]), _f(F32(-1.0) * av[1])       # k1 = 1 / red * sgn_scale = -1, k2 = 0
-    # the positive: dP = -eta sigma(-Pc) (in range), g = dP * sgn_scale
-    Pc = np.clip(P, F32(-75.0), F32(75.0))
-    sgP, lsP = det_sig_logsig(-Pc)
-    inP = (P >= F32(-75.0)) & (P <= F32(75.0))
-    dP = np.where(inP, _f(_f(F32(-float(eta)) * sgP) / F32(1.0)), F32(0.0)).astype(F32)
-    gpos = _f(dP * F32(-1.0))
-    sgv = _f(np.sign(d_pos) * gpos[:, None])                    # g sign(d): ds = dp = sgv, dd = -sgv
-    gs = _f(sgv + Go)
-    gp = _f(sgv + _f(Go + Gs))
-    go = _f(_f(-sgv) - Gs)
-    # loss value: per = (eta * -lsP + Lw) / red, Lw = wave tree over the lanes' partial sums (lane f takes row f of every group of PF)
-    lanes = np.zeros((B, 64), dtype=F32)
-    soft = _f(-lsn)                                             # softplus(clip n_j)
+    ar = np.arange(B)
     order = np.argsort(~keep, axis=1, kind="stable")            # object-replaced (keep) first, j ascending within a side
     nkeep = keep.sum(1)
+    # ---- the row loop: per positive, per side, groups of PF rows; lane f of a group evaluates row f ----
+    av1 = np.zeros((2, B, K), dtype=F32)
+    av2 = np.zeros((2, B, K), dtype=F32)
+    S_l = np.zeros((B, 64), dtype=F32)      # per-lane partial sums of the running statistics
+    Lw_l = np.zeros((B, 64), dtype=F32)
+    Zs_l = np.zeros((B, 64), dtype=F32)
+    m_run = np.full(B, -np.inf, dtype=F32)  # self_adversarial: running maximum of alpha * n (wave-uniform)
+    two = loss == "self_adversarial"
     for side in (0, 1):
         cnt = nkeep if side == 0 else eta - nkeep
         start = np.zeros(B, dtype=np.int64) if side == 0 else nkeep
         for g0 in range(0, eta, PF):
+            act = g0 < cnt                                       # positives that have this group at all
+            if not act.any():
+                continue
+            jf = np.zeros((B, PF), dtype=np.int64)
+            ok = np.zeros((B, PF), dtype=bool)
             for f in range(PF):
-                idx = g0 + f
-                ok = idx < cnt
-                jj = order[np.arange(B), np.minimum(start + idx, eta - 1)]
-                val = np.where(ok, soft[np.arange(B), jj], F32(0.0)).astype(F32)
-                lanes[:, f] = np.where(ok, _f(lanes[:, f] + val), lanes[:, f])
-    Lw = wave_sum(lanes)
-    per = _f(_f(_f(F32(float(eta)) * _f(-lsP)) + Lw) / F32(1.0))
+                ok[:, f] = (g0 + f < cnt)
+                jf[:, f] = order[ar, np.minimum(start + g0 + f, eta - 1)]
+            nv = nsc[ar[:, None], jf]                            # (B, PF) scores of the group's rows (garbage where not ok)
+            c1 = np.zeros((B, PF), dtype=F32)
+            c2 = np.zeros((B, PF), dtype=F32)
+            rs = np.ones(B, dtype=F32)
+            if loss == "nll":
+                inr = ok & (nv >= F32(-75.0)) & (nv <= F32(75.0))
+                sg, lsn = det_sig_logsig(np.clip(nv, F32(-75.0), F32(75.0)))
+                Lw_l[:, :PF] = np.where(ok, _f(Lw_l[:, :PF] + _f(-lsn)), Lw_l[:, :PF])
+                c1 = np.where(inr, sg, F32(0.0)).astype(F32)
+            elif loss == "multiclass_nll":
+                inr = ok & (nv >= F32(-75.0)) & (nv <= F32(75.0))
+                ex = np.where(ok, det_exp(np.clip(nv, F32(-75.0), F32(75.0))), F32(0.0)).astype(F32)
+                Zs_l[:, :PF] = _f(Zs_l[:, :PF] + ex)             # (adds 0 for rows that do not exist)
+                c1 = np.where(inr, ex, F32(0.0)).astype(F32)
+            else:
+                x = _f(alpha * nv)
+                gm = np.max(np.where(ok, x, F32(-np.inf)), axis=1).astype(F32)
+                grow = act & (gm > m_run)
+                resc = np.where(np.isinf(m_run), F32(0.0), det_exp(np.where(grow, _f(m_run - gm), F32(0.0)))).astype(F32)
+                rs = np.where(grow, resc, F32(1.0)).astype(F32)
+                S_l = np.where(grow[:, None], _f(S_l * rs[:, None]), S_l)
+                Lw_l = np.where(grow[:, None], _f(Lw_l * rs[:, None]), Lw_l)
+                m_run = np.where(grow, gm, m_run).astype(F32)
+                u = np.where(ok, det_exp(_f(x - m_run[:, None])), F32(0.0)).astype(F32)
+                sg, ell = det_sig_logsig(_f(nv + gamma))
+                S_l[:, :PF] = np.where(act[:, None], _f(S_l[:, :PF] + u), S_l[:, :PF])
+                Lw_l[:, :PF] = np.where(ok, _f(Lw_l[:, :PF] + _f(u * ell)), Lw_l[:, :PF])
+                c1 = np.where(ok, _f(u * _f(sg - _f(alpha * ell))), F32(0.0)).astype(F32)
+                c2 = u
+                # the running maximum grew: everything accumulated so far is rescaled (all four accumulators of both sides)
+                g_ = grow & (rs != 1)
+                for dd in (0, 1):
+                    av1[dd] = np.where(g_[:, None], _f(av1[dd] * rs[:, None]), av1[dd])
+                    av2[dd] = np.where(g_[:, None], _f(av2[dd] * rs[:, None]), av2[dd])
+            for f in range(PF):                                   # the rows join the side's sums in order
+                m_ = ok[:, f]
+                if not m_.any():
+                    continue
+                sg_f = sgn[ar, jf[:, f]]
+                av1[side][m_] = _f(av1[side][m_] + _f(c1[:, f][:, None] * sg_f)[m_])
+                if two:
+                    av2[side][m_] = _f(av2[side][m_] + _f(c2[:, f][:, None] * sg_f)[m_])
+    S, Lw, Zs = wave_sum(S_l), wave_sum(Lw_l), wave_sum(Zs_l)
+    # ---- kappa (x sgn_scale = -1), the positive's coefficient, the entries' g, the per-positive loss ----
+    Pc = np.clip(P, F32(-75.0), F32(75.0))
+    inP = (P >= F32(-75.0)) & (P <= F32(75.0))
+    inr_all = (nsc >= F32(-75.0)) & (nsc <= F32(75.0))
+    if loss == "nll":
+        k1, k2 = np.full(B, F32(1.0)), np.zeros(B, dtype=F32)
+        sgP, lsP = det_sig_logsig(-Pc)
+        dP = np.where(inP, _f(_f(-feta * sgP) / F32(1.0)), F32(0.0)).astype(F32)
+        sg_all, _ = det_sig_logsig(np.clip(nsc, F32(-75.0), F32(75.0)))
+        sn = np.where(inr_all, _f(sg_all / F32(1.0)), F32(0.0)).astype(F32)
+        per = _f(_f(_f(feta * _f(-lsP)) + Lw) / F32(1.0))
+    elif loss == "multiclass_nll":
+        eP = det_exp(Pc)
+        Z = _f(_f(Zs / F32(1.0)) + eP)
+        k1, k2 = _f(F32(1.0) / _f(Z * F32(1.0))), np.zeros(B, dtype=F32)
+        dP = np.where(inP, _f(F32(-1.0) + _f(eP / Z)), F32(0.0)).astype(F32)
+        sn = np.where(inr_all, _f(_f(det_exp(np.clip(nsc, F32(-75.0), F32(75.0))) / Z[:, None]) / F32(1.0)), F32(0.0)).astype(F32)
+        per = _f(np.log(Z.astype(np.float64)).astype(F32) - Pc)   # (libm logf on the device: the loss VALUE only, nothing feeds back)
+    else:
+        k1 = _f(F32(1.0) / _f(S * F32(1.0)))
+        k2 = _f(_f(alpha * _f(Lw / S)) / _f(S * F32(1.0)))
+        lbar = _f(Lw / S)
+        w = _f(det_exp(_f(_f(alpha * nsc) - m_run[:, None])) / S[:, None])
+        sg_all, ell_all = det_sig_logsig(_f(nsc + gamma))
+        sn = _f(_f(_f(w * sg_all) - _f(_f(alpha * w) * _f(ell_all - lbar[:, None]))) / F32(1.0))
+        sgP, lsP = det_sig_logsig(_f(-_f(gamma + P)))
+        dP = _f(-sgP)
+        per = _f(_f(-lsP) - _f(lbar / F32(1.0)))
+    k1, k2 = _f(k1 * F32(-1.0)), _f(k2 * F32(-1.0))
+    Go = _f(_f(k1[:, None] * av1[0]) + _f(k2[:, None] * av2[0]))
+    Gs = _f(_f(k1[:, None] * av1[1]) + _f(k2[:, None] * av2[1]))
+    gpos = _f(dP * F32(-1.0))
+    sgv = _f(np.sign(d_pos) * gpos[:, None])
+    gs = _f(sgv + Go)
+    gp = _f(sgv + _f(Go + Gs))
+    go = _f(_f(-sgv) - Gs)
     # ---- tile pass, deterministic: a row's entries sorted by (positive, role, bits of g), added from 0 in that order ----
     ent_dest, ent_pos, ent_role, ent_g, ent_vec = [], [], [], [], []
-    ar = np.arange(B)
     for j in range(eta):
-        g_e = _f(c1[:, j] * F32(-1.0))                          # entry g = dL/dn_j * sgn_scale
+        g_e = _f(sn[:, j] * F32(-1.0))                          # entry g = dL/dn_j * sgn_scale
         live = g_e != 0
         role = np.where(keep[:, j], 0, 1)
-        # role 0: out = -(g sign(d)) ; role 1: out = g sign(d)
-        gs_d = _f(g_e[:, None] * sgn[:, j])
-        vec = np.where(keep[:, j][:, None], _f(-gs_d), gs_d).astype(F32)
+        gs_d = _f(g_e[:, None] * sgn[:, j])                     # g sign(d)
+        vec = np.where(keep[:, j][:, None], _f(-gs_d), gs_d).astype(F32)   # role 0: dd = -(g sign d); role 1: ds = g sign d
         ent_dest.append(repl[live, j]); ent_pos.append(ar[live]); ent_role.append(role[live]); ent_g.append(g_e[live]); ent_vec.append(vec[live])
     one = np.ones(B, dtype=F32)
     ent_dest += [pos[:, 0], pos[:, 2]]; ent_pos += [ar, ar]; ent_role += [np.full(B, 2), np.full(B, 3)]; ent_g += [one, one]; ent_vec += [gs, go]
@@ -366,15 +436,20 @@ def transe_nll_step_det(state, pos, eta, seed, step, n_ents=None, return_grads=F
     Gr = np.zeros(rel.shape, dtype=F32)
     rrel = pos[:, 1]
     srt_r = np.argsort(rrel, kind="stable")
-    rs, gpv = rrel[srt_r], gp[srt_r]
-    first = np.r_[True, rs[1:] != rs[:-1]]
+    rs_, gpv = rrel[srt_r], gp[srt_r]
+    first = np.r_[True, rs_[1:] != rs_[:-1]]
     start_of = np.maximum.accumulate(np.where(first, np.arange(B), 0))
     rk = np.arange(B) - start_of
     for r in range(int(rk.max()) + 1 if B else 0):
         m = rk == r
-        Gr[rs[m]] = _f(Gr[rs[m]] + gpv[m])
-    loss = float(per.astype(np.float64).sum())
+        Gr[rs_[m]] = _f(Gr[rs_[m]] + gpv[m])
+    total = float(per.astype(np.float64).sum())
     if return_grads:
-        return loss, Ge, Gr
+        return total, Ge, Gr
     state.apply(Ge, Gr)
-    return loss
+    return total
+
+
+def transe_nll_step_det(state, pos, eta, seed, step, n_ents=None, return_grads=False):
+    """TransE / nll in deterministic mode (the first of the transcendental losses to be restated; kept under its own name)."""
+    return transe_step_det(state, pos, eta, seed, step, "nll", n_ents=n_ents, return_grads=return_grads)

@@ -260,10 +260,12 @@ def test_transe_integer_gradient_fits_are_bitwise_for_every_update_rule(gpu_lib,
     assert report["loss_history_max_rel"] <= 1e-12, report
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
-def test_transe_nll_deterministic_fit_equals_ordered_oracle_bit_for_bit(gpu_lib, seed):
-    """TransE / nll -- real-valued gradient coefficients, so every fp32 addition's place matters -- in DETERMINISTIC mode against
-    oracle/train_ordered.transe_nll_step_det: the loss terms from the mode's declared transcendentals (IEEE operations only, the same
+@pytest.mark.parametrize("seed,loss", [(0, "nll"), (1, "nll"), (2, "nll"), (3, "nll"), (0, "self_adversarial"), (1, "self_adversarial"),
+                                       (0, "multiclass_nll"), (1, "multiclass_nll")])
+def test_transe_nll_deterministic_fit_equals_ordered_oracle_bit_for_bit(gpu_lib, seed, loss):
+    """TransE with the losses that have transcendentals (nll, self_adversarial -- the online softmax of the single-pass kernel --,
+    multiclass_nll) -- real-valued gradient coefficients, so every fp32 addition's place matters -- in DETERMINISTIC mode against
+    oracle/train_ordered.transe_step_det: the loss terms from the mode's declared transcendentals (IEEE operations only, the same
     in numpy), the forward kernel's per-side sums in corruption order, the tile pass adding each row's entries sorted by (positive,
     role, bits of g), the relation gradient in batch order, opt_elem's Adam.  160 Adam steps: both tables bit-identical, hence the
     same filtered ranks and the same MRR -- the north_star's +-0.002 holds per seed with 0.002 to spare."""
@@ -278,19 +280,19 @@ def test_transe_nll_deterministic_fit_equals_ordered_oracle_bit_for_bit(gpu_lib,
     d = planted_kg("TransE", seed=seed)
     train, test = d["train"].astype(str), d["test"].astype(str)
     m = ScoringBasedEmbeddingModel(eta=ETA, k=K, scoring_type="TransE", seed=seed)
-    m.compile(optimizer=optimizers.get("adam", {"learning_rate": LR}), loss="nll", deterministic=True)
+    m.compile(optimizer=optimizers.get("adam", {"learning_rate": LR}), loss=loss, deterministic=True)
     got = np.asarray(m.fit(train, batch_size=BATCH, epochs=EPOCHS, verbose=False).history["loss"])
-    hist, st, Xi, ti = TO.replay_learning("TransE", "nll", seed, LEARNING, planted_kg, initialise)
+    hist, st, Xi, ti = TO.replay_learning("TransE", loss, seed, LEARNING, planted_kg, initialise)
     ents, rels = O.first_seen_index(train)
     E = m.get_embeddings(np.array(sorted(ents, key=ents.get)), embedding_type="e")
     Rm = m.get_embeddings(np.array(sorted(rels, key=rels.get)), embedding_type="r")
-    report = dict(seed=seed, entity_elements_differing=int((E != st.ent).sum()), relation_elements_differing=int((Rm != st.rel).sum()),
+    report = dict(seed=seed, loss=loss, entity_elements_differing=int((E != st.ent).sum()), relation_elements_differing=int((Rm != st.rel).sum()),
                   max_abs_diff=float(max(np.abs(E - st.ent).max(), np.abs(Rm - st.rel).max())),
                   loss_history_max_rel=float(np.max(np.abs(got - hist) / np.abs(hist))),
                   first_epoch_loss_rel=float(abs(got[0] - hist[0]) / abs(hist[0])))
-    print("TransE nll (deterministic) vs ordered oracle", report)
+    print("TransE transcendental loss (deterministic) vs ordered oracle", report)
     assert report["entity_elements_differing"] == 0 and report["relation_elements_differing"] == 0, report
-    assert report["loss_history_max_rel"] <= 1e-7, report
+    assert report["loss_history_max_rel"] <= 1e-6, report   # (multiclass: the per-positive log of the loss VALUE is libm's on either side)
     ranks = m.evaluate(test, use_filter={"train": train, "test": test}, corrupt_side="s,o", verbose=False)
     fs, fo = O.filter_sets(ti, [Xi, ti])
     ref = RO.evaluate_ranks("TransE", st.ent, st.rel, ti, fs, fo, corrupt_side="s,o", ranking_strategy="worst")
