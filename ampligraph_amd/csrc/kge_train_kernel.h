@@ -444,7 +444,10 @@ __device__ __forceinline__ void slot_sync() {
 // float part[W][eta+1] (W>1 only).  Tail of the block: double blockloss[SLOTS].
 // (Forcing 4 waves/SIMD with __launch_bounds__(256, 4) was measured: no gain over the natural 3 -- the row gather is
 // bound by fabric bandwidth, not by loads in flight -- and it costs spills.)
-template <int MODEL, int VEC, int W, int CH, bool STAGE = false>
+// DET: the declared (CPU-reproducible) transcendentals of the deterministic mode are a compile-time variant -- as a
+// run-time branch they cost every instantiation 7 VGPRs, which took the C2 kernel from 168 to 175 registers, i.e. from
+// 3 to 2 waves per SIMD (F 74 -> 84 us, measured in profiles/r04g_*).
+template <int MODEL, int VEC, int W, int CH, bool STAGE = false, bool DET = false>
 #ifdef KGE_F_WAVES   // development builds: force an occupancy
 __attribute__((amdgpu_waves_per_eu(KGE_F_WAVES, KGE_F_WAVES)))
 #endif
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                     if (focus_nl) sh_dfac[jl] = dfl;
                 }
                 float c1l, c2l;
-                const float rs = onepass_coeff(a.loss, P1, nv, lane_valid, ops, c1l, c2l, a.det != 0);
+                const float rs = onepass_coeff(a.loss, P1, nv, lane_valid, ops, c1l, c2l, DET);
                 c1l *= dfl; c2l *= dfl;   // d(neg')/d(neg) folded into the accumulation weights
                 if (rs != 1.f) {   // the running softmax maximum grew: rescale what has been accumulated
 #pragma unroll
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
     if constexpr (ONEPASS) {
         // pairwise / absolute_margin have no transcendental and keep the generic evaluation
         if (a.loss.kind == AMDKGE_LOSS_PAIRWISE || a.loss.kind == AMDKGE_LOSS_ABSOLUTE_MARGIN) { if (W == 1 || wv == 0) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP); }
-        else if (W == 1 || wv == 0) onepass_finish(a.loss, P, sh_neg, eta, lane, ops, per, dP, a.det != 0);   // (rewrites sh_neg in place: one wave)
+        else if (W == 1 || wv == 0) onepass_finish(a.loss, P, sh_neg, eta, lane, ops, per, dP, DET);   // (rewrites sh_neg in place: one wave)
     } else if (W == 1 || wv == 0) loss_and_dscore(a.loss, P, sh_neg, eta, lane, per, dP);
     if constexpr (W > 1) {
         if (wv == 0 && lane == 0) sh_part[0] = dP;
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         // E_side = sum_j g_j e_j (g_j incl. score scale) from the two coefficient sums; the gradients of s, p, o are
         // linear in it
         float k1, k2;
-        onepass_kappa(a.loss, P, eta, ops, k1, k2, a.det != 0);
+        onepass_kappa(a.loss, P, eta, ops, k1, k2, DET);
         k1 *= sgn_scale; k2 *= sgn_scale;
 #pragma unroll
         for (int c = 0; c < CH; ++c)

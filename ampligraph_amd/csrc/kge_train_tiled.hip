@@ -888,8 +888,8 @@ static int launch_tile(const TileArgs& a, size_t shmem, hipStream_t st) {
     return check_launch("tile_backward");
 }
 
-template <int MODEL, int W, int CHF>
-static int launch_forward(TrainArgs& f, hipStream_t st) {
+template <int MODEL, int W, int CHF, bool DET>
+static int launch_forward_v(TrainArgs& f, hipStream_t st) {
     constexpr int slots = 4 / W;
     // LDS: per-slot score / id arrays, per-slot loss, and the transpose rows of emit_row (one per wave, or one per
     // workgroup when a positive spans the whole workgroup)
@@ -899,14 +899,18 @@ static int launch_forward(TrainArgs& f, hipStream_t st) {
     if (shmem > 64 * 1024) {
         static bool attr = false;
         if (!attr) {
-            if (hipError_t e = hipFuncSetAttribute((const void*)train_fwdbwd_kernel<MODEL, 4, W, CHF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+            if (hipError_t e = hipFuncSetAttribute((const void*)train_fwdbwd_kernel<MODEL, 4, W, CHF, true, DET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
                 return set_error_hip(e, "hipFuncSetAttribute(train_forward_stage)");
             attr = true;
         }
     }
     const unsigned grid = KGE_DBG(f, 8192) ? 0u : (unsigned)((f.B + slots - 1) / slots);   // (ablation 8192: no forward launch)
-    if (grid) hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, 4, W, CHF, true>), dim3(grid), dim3(256), shmem, st, f);
+    if (grid) hipLaunchKernelGGL((train_fwdbwd_kernel<MODEL, 4, W, CHF, true, DET>), dim3(grid), dim3(256), shmem, st, f);
     return check_launch("train_forward_stage");
+}
+template <int MODEL, int W, int CHF>
+static int launch_forward(TrainArgs& f, hipStream_t st) {
+    return f.det ? launch_forward_v<MODEL, W, CHF, true>(f, st) : launch_forward_v<MODEL, W, CHF, false>(f, st);
 }
 
 template <int MODEL>
