@@ -210,9 +210,10 @@ def transe_pairwise_step(state, pos, eta, seed, step, margin=1.0, n_ents=None, r
 
 def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None, opt="adam", opt_hp=None, layout="quad"):
     """The schedule of tests/test_gpu_learning.py (planted graph, Glorot tables as the drop-in class draws them, sequential
-    batches) through transe_pairwise_step -> (loss history, state, id triples of train / test).  opt / opt_hp: the update rule
+    batches) through transe_pairwise_step / transe_step_det / trilinear_step_det -> (loss history, state, id triples of train / test).  opt / opt_hp: the update rule
     (kge_opt.h kind name) and its (beta1, beta2) descriptor fields."""
-    assert model == "TransE" and loss in ("pairwise", "absolute_margin", "nll", "self_adversarial", "multiclass_nll")
+    assert model in ("TransE", "DistMult", "ComplEx", "HolE") and loss in ("pairwise", "absolute_margin", "nll", "self_adversarial", "multiclass_nll")
+    assert model == "TransE" or loss in ("nll", "self_adversarial", "multiclass_nll")
     d = planted_kg(model, seed=seed)
     train, test = d["train"].astype(str), d["test"].astype(str)
     ents, rels = O.first_seen_index(train)
@@ -226,7 +227,9 @@ def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None,
         tot = 0.0
         for b in range(steps):
             xb = Xi[b * cfg["batch"]:(b + 1) * cfg["batch"]]
-            if loss in ("nll", "self_adversarial", "multiclass_nll"):   # (deterministic mode only: the owner-computes pair, quad layout)
+            if model != "TransE":                                       # (deterministic mode only)
+                tot += trilinear_step_det(model, st, xb, cfg["eta"], seed, ep * steps + b, loss)
+            elif loss in ("nll", "self_adversarial", "multiclass_nll"):   # (deterministic mode only: the owner-computes pair, quad layout)
                 tot += transe_step_det(st, xb, cfg["eta"], seed, ep * steps + b, loss)
             else:
                 tot += transe_pairwise_step(st, xb, cfg["eta"], seed, ep * steps + b, loss=loss, layout=layout)
@@ -310,14 +313,63 @@ def transe_step_det(state, pos, eta, seed, step, loss="nll", margin=None, alpha=
     ar = np.arange(B)
     order = np.argsort(~keep, axis=1, kind="stable")            # object-replaced (keep) first, j ascending within a side
     nkeep = keep.sum(1)
-    # ---- the row loop: per positive, per side, groups of PF rows; lane f of a group evaluates row f ----
     av1 = np.zeros((2, B, K), dtype=F32)
     av2 = np.zeros((2, B, K), dtype=F32)
+    two = loss == "self_adversarial"
+
+    def add_rows(side, m_, jcol, c1, c2):                        # a row joins its side's sums: c sign(d)
+        sg_f = sgn[ar, jcol]
+        av1[side][m_] = _f(av1[side][m_] + _f(c1[:, None] * sg_f)[m_])
+        if two:
+            av2[side][m_] = _f(av2[side][m_] + _f(c2[:, None] * sg_f)[m_])
+
+    def rescale(g_, rs):
+        for dd in (0, 1):
+            av1[dd] = np.where(g_[:, None], _f(av1[dd] * rs[:, None]), av1[dd])
+            av2[dd] = np.where(g_[:, None], _f(av2[dd] * rs[:, None]), av2[dd])
+
+    S, Lw, Zs, m_run = _det_row_protocol(loss, nsc, order, nkeep, eta, alpha, gamma, PF, add_rows, rescale)
+    k1, k2, dP, sn, per = _det_finish(loss, P, nsc, S, Lw, Zs, m_run, alpha, gamma, feta)
+    k1, k2 = _f(k1 * F32(-1.0)), _f(k2 * F32(-1.0))
+    Go = _f(_f(k1[:, None] * av1[0]) + _f(k2[:, None] * av2[0]))
+    Gs = _f(_f(k1[:, None] * av1[1]) + _f(k2[:, None] * av2[1]))
+    gpos = _f(dP * F32(-1.0))
+    sgv = _f(np.sign(d_pos) * gpos[:, None])
+    gs = _f(sgv + Go)
+    gp = _f(sgv + _f(Go + Gs))
+    go = _f(_f(-sgv) - Gs)
+    # ---- tile pass, deterministic: a row's entries sorted by (positive, role, bits of g), added from 0 in that order ----
+    ent_dest, ent_pos, ent_role, ent_g, ent_vec = [], [], [], [], []
+    for j in range(eta):
+        g_e = _f(sn[:, j] * F32(-1.0))                          # entry g = dL/dn_j * sgn_scale
+        live = g_e != 0
+        role = np.where(keep[:, j], 0, 1)
+        gs_d = _f(g_e[:, None] * sgn[:, j])                     # g sign(d)
+        vec = np.where(keep[:, j][:, None], _f(-gs_d), gs_d).astype(F32)   # role 0: dd = -(g sign d); role 1: ds = g sign d
+        ent_dest.append(repl[live, j]); ent_pos.append(ar[live]); ent_role.append(role[live]); ent_g.append(g_e[live]); ent_vec.append(vec[live])
+    one = np.ones(B, dtype=F32)
+    ent_dest += [pos[:, 0], pos[:, 2]]; ent_pos += [ar, ar]; ent_role += [np.full(B, 2), np.full(B, 3)]; ent_g += [one, one]; ent_vec += [gs, go]
+    Ge = _sorted_row_sums(ent.shape, ent_dest, ent_pos, ent_role, ent_g, ent_vec)
+    # ---- relation gradient: the positives' staged rows added per relation in batch order ----
+    Gr = _batch_order_row_sums(rel.shape, pos[:, 1], gp)
+    total = float(per.astype(np.float64).sum())
+    if return_grads:
+        return total, Ge, Gr
+    state.apply(Ge, Gr)
+    return total
+
+
+def _det_row_protocol(loss, nsc, order, nkeep, eta, alpha, gamma, PF, add_rows, rescale):
+    """The single-pass forward kernel's row loop (kge_train_kernel.h onepass_coeff): per positive and side, groups of PF rows,
+    lane f of a group evaluating row f's loss terms and holding its share of the running statistics; self_adversarial's online
+    softmax.  `add_rows(side, mask, j, c1, c2)` lets the rows join the side's sums in order, `rescale(mask, rs)` rescales what
+    has been accumulated when the running maximum grew.  Returns the wave sums (S, Lw, Zs) and the final running maximum."""
+    B = nsc.shape[0]
+    ar = np.arange(B)
     S_l = np.zeros((B, 64), dtype=F32)      # per-lane partial sums of the running statistics
     Lw_l = np.zeros((B, 64), dtype=F32)
     Zs_l = np.zeros((B, 64), dtype=F32)
     m_run = np.full(B, -np.inf, dtype=F32)  # self_adversarial: running maximum of alpha * n (wave-uniform)
-    two = loss == "self_adversarial"
     for side in (0, 1):
         cnt = nkeep if side == 0 else eta - nkeep
         start = np.zeros(B, dtype=np.int64) if side == 0 else nkeep
@@ -333,7 +385,6 @@ def transe_step_det(state, pos, eta, seed, step, loss="nll", margin=None, alpha=
             nv = nsc[ar[:, None], jf]                            # (B, PF) scores of the group's rows (garbage where not ok)
             c1 = np.zeros((B, PF), dtype=F32)
             c2 = np.zeros((B, PF), dtype=F32)
-            rs = np.ones(B, dtype=F32)
             if loss == "nll":
                 inr = ok & (nv >= F32(-75.0)) & (nv <= F32(75.0))
                 sg, lsn = det_sig_logsig(np.clip(nv, F32(-75.0), F32(75.0)))
@@ -348,7 +399,8 @@ def transe_step_det(state, pos, eta, seed, step, loss="nll", margin=None, alpha=
                 x = _f(alpha * nv)
                 gm = np.max(np.where(ok, x, F32(-np.inf)), axis=1).astype(F32)
                 grow = act & (gm > m_run)
-                resc = np.where(np.isinf(m_run), F32(0.0), det_exp(np.where(grow, _f(m_run - gm), F32(0.0)))).astype(F32)
+                with np.errstate(invalid="ignore"):
+                    resc = np.where(np.isinf(m_run), F32(0.0), det_exp(np.where(grow, _f(m_run - gm), F32(0.0)))).astype(F32)
                 rs = np.where(grow, resc, F32(1.0)).astype(F32)
                 S_l = np.where(grow[:, None], _f(S_l * rs[:, None]), S_l)
                 Lw_l = np.where(grow[:, None], _f(Lw_l * rs[:, None]), Lw_l)
@@ -360,20 +412,18 @@ def transe_step_det(state, pos, eta, seed, step, loss="nll", margin=None, alpha=
                 c1 = np.where(ok, _f(u * _f(sg - _f(alpha * ell))), F32(0.0)).astype(F32)
                 c2 = u
                 # the running maximum grew: everything accumulated so far is rescaled (all four accumulators of both sides)
-                g_ = grow & (rs != 1)
-                for dd in (0, 1):
-                    av1[dd] = np.where(g_[:, None], _f(av1[dd] * rs[:, None]), av1[dd])
-                    av2[dd] = np.where(g_[:, None], _f(av2[dd] * rs[:, None]), av2[dd])
+                rescale(grow & (rs != 1), rs)
             for f in range(PF):                                   # the rows join the side's sums in order
                 m_ = ok[:, f]
-                if not m_.any():
-                    continue
-                sg_f = sgn[ar, jf[:, f]]
-                av1[side][m_] = _f(av1[side][m_] + _f(c1[:, f][:, None] * sg_f)[m_])
-                if two:
-                    av2[side][m_] = _f(av2[side][m_] + _f(c2[:, f][:, None] * sg_f)[m_])
-    S, Lw, Zs = wave_sum(S_l), wave_sum(Lw_l), wave_sum(Zs_l)
-    # ---- kappa (x sgn_scale = -1), the positive's coefficient, the entries' g, the per-positive loss ----
+                if m_.any():
+                    add_rows(side, m_, jf[:, f], c1[:, f], c2[:, f])
+    return wave_sum(S_l), wave_sum(Lw_l), wave_sum(Zs_l), m_run
+
+
+def _det_finish(loss, P, nsc, S, Lw, Zs, m_run, alpha, gamma, feta):
+    """kge_train_kernel.h onepass_kappa / onepass_finish with the declared transcendentals: (k1, k2) of E_side = k1 av1 + k2 av2
+    (before the score scale), the positive's dL/dP, every corruption's dL/dn_j and the per-positive loss."""
+    B = P.shape[0]
     Pc = np.clip(P, F32(-75.0), F32(75.0))
     inP = (P >= F32(-75.0)) & (P <= F32(75.0))
     inr_all = (nsc >= F32(-75.0)) & (nsc <= F32(75.0))
@@ -401,48 +451,185 @@ def transe_step_det(state, pos, eta, seed, step, loss="nll", margin=None, alpha=
         sgP, lsP = det_sig_logsig(_f(-_f(gamma + P)))
         dP = _f(-sgP)
         per = _f(_f(-lsP) - _f(lbar / F32(1.0)))
-    k1, k2 = _f(k1 * F32(-1.0)), _f(k2 * F32(-1.0))
-    Go = _f(_f(k1[:, None] * av1[0]) + _f(k2[:, None] * av2[0]))
-    Gs = _f(_f(k1[:, None] * av1[1]) + _f(k2[:, None] * av2[1]))
-    gpos = _f(dP * F32(-1.0))
-    sgv = _f(np.sign(d_pos) * gpos[:, None])
-    gs = _f(sgv + Go)
-    gp = _f(sgv + _f(Go + Gs))
-    go = _f(_f(-sgv) - Gs)
-    # ---- tile pass, deterministic: a row's entries sorted by (positive, role, bits of g), added from 0 in that order ----
-    ent_dest, ent_pos, ent_role, ent_g, ent_vec = [], [], [], [], []
-    for j in range(eta):
-        g_e = _f(sn[:, j] * F32(-1.0))                          # entry g = dL/dn_j * sgn_scale
-        live = g_e != 0
-        role = np.where(keep[:, j], 0, 1)
-        gs_d = _f(g_e[:, None] * sgn[:, j])                     # g sign(d)
-        vec = np.where(keep[:, j][:, None], _f(-gs_d), gs_d).astype(F32)   # role 0: dd = -(g sign d); role 1: ds = g sign d
-        ent_dest.append(repl[live, j]); ent_pos.append(ar[live]); ent_role.append(role[live]); ent_g.append(g_e[live]); ent_vec.append(vec[live])
-    one = np.ones(B, dtype=F32)
-    ent_dest += [pos[:, 0], pos[:, 2]]; ent_pos += [ar, ar]; ent_role += [np.full(B, 2), np.full(B, 3)]; ent_g += [one, one]; ent_vec += [gs, go]
+    return k1, k2, dP, sn, per
+
+
+def _sorted_row_sums(shape, ent_dest, ent_pos, ent_role, ent_g, ent_vec):
+    """The deterministic tile pass: a row's entries sorted by (positive, role, bits of g) and added from 0 in that order."""
     dest = np.concatenate(ent_dest); epos = np.concatenate(ent_pos); role = np.concatenate(ent_role)
     gbits = np.concatenate(ent_g).astype(F32).view(np.uint32).astype(np.int64)
     vec = np.concatenate(ent_vec).astype(F32)
     srt = np.lexsort((gbits, role, epos, dest))
     dest, vec = dest[srt], vec[srt]
-    Ge = np.zeros(ent.shape, dtype=F32)
+    G = np.zeros(shape, dtype=F32)
+    if not len(dest):
+        return G
     first = np.r_[True, dest[1:] != dest[:-1]]
     start_of = np.maximum.accumulate(np.where(first, np.arange(len(dest)), 0))
     rank_in_row = np.arange(len(dest)) - start_of
-    for r in range(int(rank_in_row.max()) + 1 if len(dest) else 0):
+    for r in range(int(rank_in_row.max()) + 1):
         m = rank_in_row == r
-        Ge[dest[m]] = _f(Ge[dest[m]] + vec[m])
-    # ---- relation gradient: the positives' staged rows added per relation in batch order ----
-    Gr = np.zeros(rel.shape, dtype=F32)
-    rrel = pos[:, 1]
-    srt_r = np.argsort(rrel, kind="stable")
-    rs_, gpv = rrel[srt_r], gp[srt_r]
+        G[dest[m]] = _f(G[dest[m]] + vec[m])
+    return G
+
+
+def _batch_order_row_sums(shape, rows, vecs):
+    """rel_backward_det_kernel: the positives' staged relation-gradient rows added per relation in batch order."""
+    G = np.zeros(shape, dtype=F32)
+    B = len(rows)
+    if not B:
+        return G
+    srt_r = np.argsort(rows, kind="stable")
+    rs_, gpv = rows[srt_r], vecs[srt_r]
     first = np.r_[True, rs_[1:] != rs_[:-1]]
     start_of = np.maximum.accumulate(np.where(first, np.arange(B), 0))
     rk = np.arange(B) - start_of
-    for r in range(int(rk.max()) + 1 if B else 0):
+    for r in range(int(rk.max()) + 1):
         m = rk == r
-        Gr[rs_[m]] = _f(Gr[rs_[m]] + gpv[m])
+        G[rs_[m]] = _f(G[rs_[m]] + gpv[m])
+    return G
+
+
+def fmaf32(a, b, c):
+    """fl32(a * b + c) with ONE rounding, element-wise on fp32 arrays (numpy has no fma).  a * b is exact in fp64 (48-bit product);
+    the fp64 sum is turned into its round-to-odd value with the exact residual of the addition (TwoSum), and a round-to-odd
+    53-bit value rounds to the nearest fp32 exactly as the unrounded sum does (53 >= 2 * 24 + 2).  Pinned against libm's fmaf
+    (tests/test_oracle_train_ordered.py)."""
+    a, b, c = np.broadcast_arrays(_f(a).astype(np.float64), _f(b).astype(np.float64), _f(c).astype(np.float64))
+    with np.errstate(invalid="ignore", over="ignore"):
+        p = a * b
+        s = p + c
+        bb = s - p
+        err = (p - (s - bb)) + (c - bb)
+    si = np.ascontiguousarray(s).view(np.int64).copy()
+    fin = np.isfinite(s) & np.isfinite(err)
+    odd_fix = fin & (err != 0) & ((si & 1) == 0)
+    up = (err > 0) == (s > 0)                       # the exact sum lies beyond s in magnitude
+    si = np.where(odd_fix, np.where(up, si + 1, si - 1), si)
+    return si.view(np.float64).astype(F32)
+
+
+def _unit_chain(vals):
+    """[n, k] per-unit values -> [n, 64] lane sums in the quad layout (lane q adds its quad's four units in order from 0)."""
+    return _lane_sums(_f(vals), "quad")
+
+
+def trilinear_step_det(model, state, pos, eta, seed, step, loss="self_adversarial", margin=None, alpha=0.5, n_ents=None,
+                       return_grads=False):
+    """One step of DistMult / ComplEx / HolE with "nll", "self_adversarial" or "multiclass_nll" (reduction "sum") as the
+    owner-computes pair carries it out in DETERMINISTIC mode, one wave per positive and one quad per component and lane (stored
+    k <= 256).  What differs from transe_step_det is the model arithmetic (kge_train_kernel.h, ONEPASS branch; kge_device.h
+    score_unit / grad_unit -- plain products and sums, each rounded where it is written, -ffp-contract=off):
+      * the positive's score: score_unit per unit (DistMult.py:48, ComplEx.py:58-62), a quad's units added in order, wave tree;
+      * a corruption's score as a dot product with the side row A = d/do (s, p) or B = d/ds (p, o) (the query-vector form of
+        ComplEx.py:93-107,138-150): per lane ONE fmaf chain over (unit, component), then the wave tree;
+      * sum_j c_j e_j per side by fmaf(c_j, e_j, acc) in the side-ordered row sequence, rescaled when the running softmax
+        maximum grows; E_side = fl(fl(k1 av1) + fl(k2 av2)); the row gradients follow from grad_unit on (s, p, E_obj) and
+        (E_subj, p, o);
+      * tile pass: an entry adds fl(g A) or fl(g B) (own rows: 1 * staged gradient), a row's entries in sorted order.
+    State rows are the STORED rows: [re | im] halves for the complex models."""
+    assert model in ("DistMult", "ComplEx", "HolE") and loss in ("nll", "self_adversarial", "multiclass_nll")
+    PF = 6
+    pos = np.asarray(pos, dtype=np.int64)
+    B = pos.shape[0]
+    ent, rel = state.ent, state.rel
+    K = ent.shape[1]
+    NC = 1 if model == "DistMult" else 2
+    k = K // NC
+    assert k % 4 == 0 and k <= 256
+    N = ent.shape[0] if n_ents is None else int(n_ents)
+    gamma = F32(3.0 if margin is None else margin)
+    alpha = F32(alpha)
+    feta = F32(float(eta))
+    sgn_scale = F32(1.0)
+    if model == "HolE":
+        sgn_scale = F32(F32(2.0) / F32(float(getattr(state, "k_live", k))))
+    comp = (lambda t: [t[:, h * k:(h + 1) * k] for h in range(NC)])
+    s, p, o = comp(ent[pos[:, 0]]), comp(rel[pos[:, 1]]), comp(ent[pos[:, 2]])
+
+    def grad_unit(s_, p_, o_, g):
+        """kge_device.h grad_unit: g d(score)/d(s, p, o) per unit; g [n] or [n, 1]-broadcastable."""
+        g = _f(g)
+        if g.ndim == 1:
+            g = g[:, None]
+        if NC == 1:
+            return ([_f(g * _f(p_[0] * o_[0]))], [_f(g * _f(s_[0] * o_[0]))], [_f(g * _f(s_[0] * p_[0]))])
+        ds = [_f(g * _f(_f(p_[0] * o_[0]) + _f(p_[1] * o_[1]))), _f(g * _f(_f(p_[0] * o_[1]) - _f(p_[1] * o_[0])))]
+        dp = [_f(g * _f(_f(s_[0] * o_[0]) + _f(s_[1] * o_[1]))), _f(g * _f(_f(s_[0] * o_[1]) - _f(s_[1] * o_[0])))]
+        dd = [_f(g * _f(_f(s_[0] * p_[0]) - _f(s_[1] * p_[1]))), _f(g * _f(_f(s_[0] * p_[1]) + _f(s_[1] * p_[0])))]
+        return ds, dp, dd
+
+    one = np.ones(B, dtype=F32)
+    dsA, _, ddA = grad_unit(s, p, o, one)
+    A, Bq = ddA, dsA                                             # A = d/do (s, p), B = d/ds (p, o)
+    if NC == 1:
+        su = _f(_f(s[0] * p[0]) * o[0])
+    else:
+        su = _f(_f(s[0] * _f(_f(p[0] * o[0]) + _f(p[1] * o[1]))) + _f(s[1] * _f(_f(p[0] * o[1]) - _f(p[1] * o[0]))))
+    P = _f(sgn_scale * wave_sum(_unit_chain(su)))
+
+    def row_score(q, e):
+        """per lane: t = fmaf(q[u][h], e[u][h], t) over u = 0..3, h = 0..NC-1 from 0; lanes by the wave tree."""
+        n = q[0].shape[0]
+        t = np.zeros((n, k // 4), dtype=F32)
+        for u in range(4):
+            for h in range(NC):
+                t = fmaf32(q[h][:, u::4], e[h][:, u::4], t)
+        lanes = np.zeros((n, 64), dtype=F32)
+        lanes[:, :k // 4] = t
+        return _f(sgn_scale * wave_sum(lanes))
+
+    keep = np.zeros((B, eta), dtype=bool)
+    repl = np.zeros((B, eta), dtype=np.int64)
+    nsc = np.zeros((B, eta), dtype=F32)
+    for j in range(eta):
+        rows = np.uint64(j) * np.uint64(B) + np.arange(B, dtype=np.uint64)
+        kj, rj = sample_corruption_draws(rows, step, seed, N)
+        keep[:, j], repl[:, j] = kj.astype(bool), rj
+        e = comp(ent[rj])
+        nsc[:, j] = np.where(keep[:, j], row_score(A, e), row_score(Bq, e))
+    ar = np.arange(B)
+    order = np.argsort(~keep, axis=1, kind="stable")
+    nkeep = keep.sum(1)
+    av1 = np.zeros((2, B, K), dtype=F32)
+    av2 = np.zeros((2, B, K), dtype=F32)
+    two = loss == "self_adversarial"
+
+    def add_rows(side, m_, jcol, c1, c2):
+        e = ent[repl[ar, jcol]]
+        av1[side][m_] = fmaf32(c1[:, None], e, av1[side])[m_]
+        if two:
+            av2[side][m_] = fmaf32(c2[:, None], e, av2[side])[m_]
+
+    def rescale(g_, rs):
+        for dd in (0, 1):
+            av1[dd] = np.where(g_[:, None], _f(av1[dd] * rs[:, None]), av1[dd])
+            av2[dd] = np.where(g_[:, None], _f(av2[dd] * rs[:, None]), av2[dd])
+
+    S, Lw, Zs, m_run = _det_row_protocol(loss, nsc, order, nkeep, eta, alpha, gamma, PF, add_rows, rescale)
+    k1, k2, dP, sn, per = _det_finish(loss, P, nsc, S, Lw, Zs, m_run, alpha, gamma, feta)
+    k1, k2 = _f(k1 * sgn_scale), _f(k2 * sgn_scale)
+    Eo = comp(_f(_f(k1[:, None] * av1[0]) + _f(k2[:, None] * av2[0])))
+    Es = comp(_f(_f(k1[:, None] * av1[1]) + _f(k2[:, None] * av2[1])))
+    gs, gp, go = grad_unit(s, p, o, _f(dP * sgn_scale))
+    ds1, dp1, _ = grad_unit(s, p, Eo, one)                        # corruptions (s, p, e_j)
+    gs = [_f(gs[h] + ds1[h]) for h in range(NC)]
+    gp = [_f(gp[h] + dp1[h]) for h in range(NC)]
+    _, dp2, dd2 = grad_unit(Es, p, o, one)                        # corruptions (e_j, p, o)
+    go = [_f(go[h] + dd2[h]) for h in range(NC)]
+    gp = [_f(gp[h] + dp2[h]) for h in range(NC)]
+    gs, gp, go = np.concatenate(gs, 1), np.concatenate(gp, 1), np.concatenate(go, 1)
+    Arow, Brow = np.concatenate(A, 1), np.concatenate(Bq, 1)
+    ent_dest, ent_pos, ent_role, ent_g, ent_vec = [], [], [], [], []
+    for j in range(eta):
+        g_e = _f(sn[:, j] * sgn_scale)
+        live = g_e != 0
+        role = np.where(keep[:, j], 0, 1)
+        vec = _f(g_e[:, None] * np.where(keep[:, j][:, None], Arow, Brow))
+        ent_dest.append(repl[live, j]); ent_pos.append(ar[live]); ent_role.append(role[live]); ent_g.append(g_e[live]); ent_vec.append(vec[live])
+    ent_dest += [pos[:, 0], pos[:, 2]]; ent_pos += [ar, ar]; ent_role += [np.full(B, 2), np.full(B, 3)]; ent_g += [one, one]; ent_vec += [gs, go]
+    Ge = _sorted_row_sums(ent.shape, ent_dest, ent_pos, ent_role, ent_g, ent_vec)
+    Gr = _batch_order_row_sums(rel.shape, pos[:, 1], gp)
     total = float(per.astype(np.float64).sum())
     if return_grads:
         return total, Ge, Gr

@@ -297,3 +297,47 @@ def test_transe_nll_deterministic_fit_equals_ordered_oracle_bit_for_bit(gpu_lib,
     fs, fo = O.filter_sets(ti, [Xi, ti])
     ref = RO.evaluate_ranks("TransE", st.ent, st.rel, ti, fs, fo, corrupt_side="s,o", ranking_strategy="worst")
     assert np.array_equal(ranks, ref) and O.mrr_score(ranks) == O.mrr_score(ref)
+
+
+TRILINEAR_DET = [(0, "ComplEx", "self_adversarial"), (1, "ComplEx", "self_adversarial"), (0, "ComplEx", "nll"), (1, "ComplEx", "multiclass_nll"),
+                 (0, "DistMult", "self_adversarial"), (1, "DistMult", "nll"), (0, "HolE", "self_adversarial"), (1, "HolE", "multiclass_nll")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,model,loss", TRILINEAR_DET)
+def test_trilinear_deterministic_fit_equals_ordered_oracle_bit_for_bit(gpu_lib, seed, model, loss):
+    """The headline model family in DETERMINISTIC mode against oracle/train_ordered.trilinear_step_det: ComplEx (the model of
+    BASELINE configs[1], with its self-adversarial loss), DistMult and HolE.  Side rows A = d/do(s, p), B = d/ds(p, o) from
+    grad_unit's products; a corruption's score one fmaf chain per lane over (unit, component) + the wave tree; sum_j c_j e_j per
+    side by fmaf in corruption order with the online-softmax rescale; the row gradients from grad_unit on the sums; the tile
+    pass adding fl(g A) / fl(g B) per entry in sorted order; the relation gradient in batch order; opt_elem's Adam.  160 Adam
+    steps: both tables bit-identical to the numpy replay, hence identical filtered ranks and MRR."""
+    from planted import LEARNING, planted_kg
+
+    from oracle import rank_ordered as RO
+    from oracle import train_ordered as TO
+
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers
+    from ampligraph_amd.latent_features.initializers import initialise
+
+    d = planted_kg(model, seed=seed)
+    train, test = d["train"].astype(str), d["test"].astype(str)
+    m = ScoringBasedEmbeddingModel(eta=ETA, k=K, scoring_type=model, seed=seed)
+    m.compile(optimizer=optimizers.get("adam", {"learning_rate": LR}), loss=loss, deterministic=True)
+    got = np.asarray(m.fit(train, batch_size=BATCH, epochs=EPOCHS, verbose=False).history["loss"])
+    hist, st, Xi, ti = TO.replay_learning(model, loss, seed, LEARNING, planted_kg, initialise)
+    ents, rels = O.first_seen_index(train)
+    E = m.get_embeddings(np.array(sorted(ents, key=ents.get)), embedding_type="e")
+    Rm = m.get_embeddings(np.array(sorted(rels, key=rels.get)), embedding_type="r")
+    report = dict(seed=seed, model=model, loss=loss, entity_elements_differing=int((E != st.ent).sum()),
+                  relation_elements_differing=int((Rm != st.rel).sum()),
+                  max_abs_diff=float(max(np.abs(E - st.ent).max(), np.abs(Rm - st.rel).max())),
+                  loss_history_max_rel=float(np.max(np.abs(got - hist) / np.abs(hist))),
+                  first_epoch_loss_rel=float(abs(got[0] - hist[0]) / abs(hist[0])))
+    print("trilinear model (deterministic) vs ordered oracle", report)
+    assert report["entity_elements_differing"] == 0 and report["relation_elements_differing"] == 0, report
+    assert report["loss_history_max_rel"] <= 1e-6, report
+    ranks = m.evaluate(test, use_filter={"train": train, "test": test}, corrupt_side="s,o", verbose=False)
+    fs, fo = O.filter_sets(ti, [Xi, ti])
+    ref = RO.evaluate_ranks(model, st.ent, st.rel, ti, fs, fo, corrupt_side="s,o", ranking_strategy="worst")
+    assert np.array_equal(ranks, ref) and O.mrr_score(ranks) == O.mrr_score(ref)

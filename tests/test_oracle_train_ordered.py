@@ -161,3 +161,41 @@ def test_ordered_transcendental_loss_steps_are_the_oracles_steps_up_to_rounding(
     assert abs(loss - float(tot)) <= 2e-6 * abs(float(tot))
     # (+ one fp32 ulp of 1: with every score clipped out of range the gradient is -1 + eP / Z = 0 up to the rounding of the quotient)
     assert np.abs(Ge - Re).max() <= 2e-6 * np.abs(Re).max() + 1.3e-7 and np.abs(Gr - Rr).max() <= 2e-6 * np.abs(Rr).max() + 2e-5
+
+
+def test_fmaf32_is_libm_fmaf():
+    """The numpy restatement of the one-rounding fma (round-to-odd in fp64) against libm's fmaf, incl. products that cancel the
+    addend almost exactly (where a double rounding would show)."""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.fmaf.restype = ctypes.c_float
+    libm.fmaf.argtypes = [ctypes.c_float] * 3
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal(20000).astype(np.float32)
+    b = rng.standard_normal(20000).astype(np.float32)
+    c = rng.standard_normal(20000).astype(np.float32)
+    c[::3] = -(a[::3] * b[::3]).astype(np.float32)                      # near-cancellation
+    c[1::7] = (c[1::7] * np.float32(1e-7)).astype(np.float32)              # addend far below the product
+    # exact ties of the fp64 sum at an fp32 rounding boundary: a * b = 1 + 2^-24 (odd neighbour decides), c tiny of either sign
+    a[:4] = np.float32(1.0 + 2.0 ** -12); b[:4] = np.float32(1.0 - 2.0 ** -12 + 2.0 ** -23)
+    c[:4] = np.array([2.0 ** -60, -2.0 ** -60, 2.0 ** -90, -2.0 ** -90], dtype=np.float32)
+    got = TO.fmaf32(a, b, c)
+    ref = np.array([libm.fmaf(float(x), float(y), float(z)) for x, y, z in zip(a, b, c)], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("loss", ["nll", "self_adversarial", "multiclass_nll"])
+@pytest.mark.parametrize("model,K,eta", [("DistMult", 16, 5), ("ComplEx", 32, 5), ("ComplEx", 400, 3), ("HolE", 64, 13), ("DistMult", 200, 7)])
+def test_ordered_trilinear_steps_are_the_oracles_steps_up_to_rounding(model, K, eta, loss):
+    """trilinear_step_det (side rows, fmaf score chains, sum_j c_j e_j with the online softmax, grad_unit transforms, sorted tile
+    sums) against the fp64 oracle's loss and dense gradients."""
+    rng = np.random.default_rng(K + eta)
+    ent, rel, X = _problem(rng, N=60, K=K, B=300)
+    ent *= np.float32(0.5); rel *= np.float32(0.5)
+    st = TO.OptState(ent, rel, "adam", 1e-2)
+    loss_v, Ge, Gr = TO.trilinear_step_det(model, st, X, eta, 5, 2, loss, return_grads=True)
+    negs = O.generate_corruptions(X, ent.shape[0], eta, 5, 2)
+    tot, Re, Rr, _ = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, "sum", rel.shape[0])
+    assert abs(loss_v - float(tot)) <= 4e-6 * abs(float(tot))
+    assert np.abs(Ge - Re).max() <= 4e-6 * np.abs(Re).max() + 1.3e-7 and np.abs(Gr - Rr).max() <= 4e-6 * np.abs(Rr).max() + 2e-5
