@@ -336,7 +336,9 @@ def test_trilinear_deterministic_fit_equals_ordered_oracle_bit_for_bit(gpu_lib, 
                   first_epoch_loss_rel=float(abs(got[0] - hist[0]) / abs(hist[0])))
     print("trilinear model (deterministic) vs ordered oracle", report)
     assert report["entity_elements_differing"] == 0 and report["relation_elements_differing"] == 0, report
-    assert report["loss_history_max_rel"] <= 1e-6, report
+    # the loss VALUE: identical but for multiclass_nll, whose per-positive log(Z) is libm's logf on the device and numpy's log
+    # here (measured 1.4e-6 / 1.9e-6 of the epoch means, profiles/r04l_pytest_trilinear_det.log); nothing of it feeds back
+    assert report["loss_history_max_rel"] <= (5e-6 if loss == "multiclass_nll" else 0.0), report
     ranks = m.evaluate(test, use_filter={"train": train, "test": test}, corrupt_side="s,o", verbose=False)
     fs, fo = O.filter_sets(ti, [Xi, ti])
     ref = RO.evaluate_ranks(model, st.ent, st.rel, ti, fs, fo, corrupt_side="s,o", ranking_strategy="worst")
