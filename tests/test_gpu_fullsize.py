@@ -497,3 +497,45 @@ def test_fullsize_c1_steps_bitwise_against_the_ordered_oracle(gpu_lib):
     assert np.array_equal(e, st.ent[:, :k]) and np.array_equal(r, st.rel[:, :k]), (int((e != st.ent[:, :k]).sum()), int((r != st.rel[:, :k]).sum()))
     assert np.array_equal(eng.unpack(eng.slots["m_e"]).cpu().numpy(), st.s0[0][:, :k]) and np.array_equal(eng.unpack(eng.slots["v_e"]).cpu().numpy(), st.s1[0][:, :k])
     assert np.all(st.ent[:, k:] == 0) and abs(got - ref) <= 1e-12 * abs(ref), (got, ref)
+
+
+@pytest.mark.gpu
+def test_fullsize_c2_deterministic_steps_bitwise_against_the_ordered_oracle(gpu_lib):
+    """BASELINE configs[1] -- the headline workload -- at FULL size: ComplEx k = 200, eta = 20, self-adversarial loss, Adam, the
+    FB15K-237 shape, B = 10 000, in DETERMINISTIC mode: two whole steps of the product's StepLoop (the owner-computes pair with
+    sorted tile sums and the batch-ordered relation gradient) against oracle/train_ordered.trilinear_step_det -- 210 000 scores by
+    fmaf chains, the online softmax over 20 corruptions in groups of 6, 230 000 tile entries in sorted order, the dense Adam sweep:
+    BOTH tables and both Adam slots bit-identical, the loss to 1e-12."""
+    import torch
+
+    from oracle import train_ordered as TO
+
+    from ampligraph_amd.datasets import make_synthetic_kg
+    from ampligraph_amd.engine import KgeEngine
+    from ampligraph_amd.latent_features import loss_functions, optimizers
+    from ampligraph_amd.trainer import StepLoop
+
+    d = make_synthetic_kg("synth-fb15k237", seed=0)
+    N, R, k, B, eta = d["n_ents"], d["n_rels"], 200, 10000, 20
+    rng = np.random.default_rng(2)
+    lim_e, lim_r = np.sqrt(6.0 / (N + 2 * k)), np.sqrt(6.0 / (R + 2 * k))
+    ent = rng.uniform(-lim_e, lim_e, size=(N, 2 * k)).astype(np.float32)
+    rel = rng.uniform(-lim_r, lim_r, size=(R, 2 * k)).astype(np.float32)
+    eng = KgeEngine("ComplEx", k, N, R, max_rel_size=R)
+    eng.set_tables(ent, rel)
+    loop = StepLoop(eng, eta, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-3}), None, seed=4, dist=None)
+    loop.deterministic = True
+    st = TO.OptState(ent.copy(), rel.copy(), "adam", 1e-3)
+    X = d["train"]
+    Xd = torch.as_tensor(X).cuda()
+    loop.reset_loss()
+    ref = 0.0
+    for step in range(2):
+        loop.step(Xd[step * B:(step + 1) * B], step)
+        ref += TO.trilinear_step_det("ComplEx", st, X[step * B:(step + 1) * B], eta, 4, step, "self_adversarial")
+    torch.cuda.synchronize()
+    got = loop.mean_batch_loss() * 2
+    e, r = eng.get_tables()
+    assert np.array_equal(e, st.ent) and np.array_equal(r, st.rel), (int((e != st.ent).sum()), int((r != st.rel).sum()))
+    assert np.array_equal(eng.unpack(eng.slots["m_e"]).cpu().numpy(), st.s0[0]) and np.array_equal(eng.unpack(eng.slots["v_e"]).cpu().numpy(), st.s1[0])
+    assert abs(got - ref) <= 1e-12 * abs(ref), (got, ref)
