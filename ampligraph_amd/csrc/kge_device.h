@@ -185,8 +185,15 @@ __device__ __forceinline__ float sqrt_rn(float x) {
 #define KGE_DIV(a, b) ((a) / (b))
 #endif
 
+// EXACT (the deterministic train mode): IEEE square root and division -- correctly rounded, the same bits as numpy's -- instead
+// of the hardware approximations (v_sqrt_f32 / v_rcp_f32, 1 ulp, implementation-defined bits) the train kernels otherwise use
+template <bool EXACT>
+__device__ __forceinline__ float kge_sqrt_t(float x) { if constexpr (EXACT) return sqrtf(x); else return KGE_SQRT(x); }
+template <bool EXACT>
+__device__ __forceinline__ float kge_div_t(float a, float b) { if constexpr (EXACT) return a / b; else return KGE_DIV(a, b); }
+
 // un-negated, un-scaled contribution of one unit to the score
-template <int MODEL>
+template <int MODEL, bool EXACT = false>
 __device__ __forceinline__ float score_unit(const float (&s)[ModelTraits<MODEL>::NC], const float (&p)[ModelTraits<MODEL>::NC],
                                             const float (&o)[ModelTraits<MODEL>::NC]) {
     if constexpr (MODEL == AMDKGE_TRANSE) {
@@ -200,7 +207,7 @@ __device__ __forceinline__ float score_unit(const float (&s)[ModelTraits<MODEL>:
         // RotatE.py:100-104 ; p = (cos, sin)
         const float re = s[0] * p[0] - s[1] * p[1] - o[0];
         const float im = s[0] * p[1] + s[1] * p[0] - o[1];
-        return KGE_SQRT(re * re + im * im);
+        return kge_sqrt_t<EXACT>(re * re + im * im);
     }
 }
 
@@ -210,7 +217,7 @@ __device__ __forceinline__ float score_unit(const float (&s)[ModelTraits<MODEL>:
 // padding unit has s = o = 0, hence modulus 0 and g / 0 * 0 = NaN; adding pad1 to the modulus makes its gradient the
 // exact zero it must be, while a live unit's modulus is unchanged bit for bit (m + 0.0f == m, NaN for a true m == 0 as
 // in the reference).  Every other model's padding units give exact zeros on their own.
-template <int MODEL>
+template <int MODEL, bool EXACT = false>
 __device__ __forceinline__ void grad_unit(const float (&s)[ModelTraits<MODEL>::NC], const float (&p)[ModelTraits<MODEL>::NC],
                                           const float (&o)[ModelTraits<MODEL>::NC], float g,
                                           float (&ds)[ModelTraits<MODEL>::NC], float (&dp)[ModelTraits<MODEL>::NC],
@@ -229,8 +236,8 @@ __device__ __forceinline__ void grad_unit(const float (&s)[ModelTraits<MODEL>::N
         const float c = p[0], sn = p[1];
         const float re = s[0] * c - s[1] * sn - o[0];
         const float im = s[0] * sn + s[1] * c - o[1];
-        const float m = KGE_SQRT(re * re + im * im) + pad1;
-        const float gm = KGE_DIV(g, m);  // no epsilon: m == 0 -> NaN exactly like the reference (RotatE.py:102-104)
+        const float m = kge_sqrt_t<EXACT>(re * re + im * im) + pad1;
+        const float gm = kge_div_t<EXACT>(g, m);  // no epsilon: m == 0 -> NaN exactly like the reference (RotatE.py:102-104)
         ds[0] = gm * (re * c + im * sn);
         ds[1] = gm * (-re * sn + im * c);
         dp[0] = gm * (re * (-s[0] * sn - s[1] * c) + im * (s[0] * c - s[1] * sn));

@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                     qa[c][u][h] = dd[h]; qb[c][u][h] = ds[h];
                     av1[0][c][u][h] = 0.f; av1[1][c][u][h] = 0.f; av2[0][c][u][h] = 0.f; av2[1][c][u][h] = 0.f;
                 }
-                acc += score_unit<MODEL>(s[c][u], p[c][u], o[c][u]);   // the positive keeps the reference's op order
+                acc += score_unit<MODEL, DET>(s[c][u], p[c][u], o[c][u]);   // the positive keeps the reference's op order
             }
             part += qok[c] ? acc : 0.f;
         }
@@ -755,9 +755,9 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                                     zr = e[f][c][u][0] * p[c][u][0] - e[f][c][u][1] * p[c][u][1] - o[c][u][0];
                                     zi = e[f][c][u][0] * p[c][u][1] + e[f][c][u][1] * p[c][u][0] - o[c][u][1];
                                 }
-                                const float m = KGE_SQRT(zr * zr + zi * zi);
+                                const float m = kge_sqrt_t<DET>(zr * zr + zi * zi);
                                 t += m;
-                                const float inv = KGE_DIV(1.f, m + pad1[c][u]);   // m == 0 in a unit of the model: NaN, like the reference
+                                const float inv = kge_div_t<DET>(1.f, m + pad1[c][u]);   // m == 0 in a unit of the model: NaN, like the reference
                                 e[f][c][u][0] = zr * inv; e[f][c][u][1] = zi * inv;   // the unit vector, kept in place of the row
                             }
                         } else {
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 } else {
 #pragma unroll
                     for (int u = 0; u < VEC; ++u)
-                        acc += keepv[f] ? score_unit<MODEL>(s[c][u], p[c][u], e[f][c][u]) : score_unit<MODEL>(e[f][c][u], p[c][u], o[c][u]);
+                        acc += keepv[f] ? score_unit<MODEL, DET>(s[c][u], p[c][u], e[f][c][u]) : score_unit<MODEL, DET>(e[f][c][u], p[c][u], o[c][u]);
                 }
                 part += qok[c] ? acc : 0.f;
             }
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
         for (int u = 0; u < VEC; ++u) {
             float ds[NC], dp[NC], dd[NC];
-            grad_unit<MODEL>(s[c][u], p[c][u], o[c][u], dP * sgn_scale, ds, dp, dd, pad1[c][u]);
+            grad_unit<MODEL, DET>(s[c][u], p[c][u], o[c][u], dP * sgn_scale, ds, dp, dd, pad1[c][u]);
 #pragma unroll
             for (int h = 0; h < NC; ++h) { gs[c][u][h] = ds[h]; gp[c][u][h] = dp[h]; go[c][u][h] = dd[h]; }
         }
@@ -1146,11 +1146,11 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                 for (int u = 0; u < VEC; ++u) {
                     float ds[NC], dp[NC], dd[NC];
                     if (keepv[f]) {   // (s, p, e): object replaced
-                        grad_unit<MODEL>(s[c][u], p[c][u], e[f][c][u], g, ds, dp, dd, pad1[c][u]);
+                        grad_unit<MODEL, DET>(s[c][u], p[c][u], e[f][c][u], g, ds, dp, dd, pad1[c][u]);
 #pragma unroll
                         for (int h = 0; h < NC; ++h) { gs[c][u][h] += ds[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = dd[h]; }
                     } else {          // (e, p, o): subject replaced
-                        grad_unit<MODEL>(e[f][c][u], p[c][u], o[c][u], g, ds, dp, dd, pad1[c][u]);
+                        grad_unit<MODEL, DET>(e[f][c][u], p[c][u], o[c][u], g, ds, dp, dd, pad1[c][u]);
 #pragma unroll
                         for (int h = 0; h < NC; ++h) { go[c][u][h] += dd[h]; gp[c][u][h] += dp[h]; gr[c][u][h] = ds[h]; }
                     }

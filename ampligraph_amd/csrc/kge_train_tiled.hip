@@ -124,7 +124,8 @@ struct TileArgs {
 // over the waves of the workgroup instead (local row % TILE_WAVES) and every wave updates its own rows with
 // plain 16-byte LDS read-modify-writes; all waves scan the tile's whole bucket and pick their entries with a
 // ballot.
-template <int MODEL, int CH, int UNROLL>
+// DET (RotatE in deterministic mode only): IEEE square root and division in the entry arithmetic (kge_device.h kge_sqrt_t)
+template <int MODEL, int CH, int UNROLL, bool DET = false>
 __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a) {
     using T = ModelTraits<MODEL>;
     constexpr int NC = T::NC;
@@ -271,8 +272,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float dr = (&eo[c][0].x)[u] - (&v[c][0].x)[u], di = (&eo[c][1].x)[u] - (&v[c][1].x)[u];
-                    const float m = KGE_SQRT(dr * dr + di * di) + ((qoff[c] + u >= a.k_live) ? 1.f : 0.f);   // (padding units: 0 / 1)
-                    const float gm = KGE_DIV(g, m);
+                    const float m = kge_sqrt_t<DET>(dr * dr + di * di) + ((qoff[c] + u >= a.k_live) ? 1.f : 0.f);   // (padding units: 0 / 1)
+                    const float gm = kge_div_t<DET>(g, m);
                     (&out[c][0].x)[u] = gm * dr;
                     (&out[c][1].x)[u] = gm * di;
                 }
@@ -876,15 +877,15 @@ static int plan_guard(const void* d_work, const TiledPlan& p, char* w, hipStream
     return AMDKGE_OK;
 }
 
-template <int MODEL, int CH, int UNROLL>
+template <int MODEL, int CH, int UNROLL, bool DET = false>
 static int launch_tile(const TileArgs& a, size_t shmem, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)tile_backward_kernel<MODEL, CH, UNROLL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))   // (the kernel has a few bytes of static LDS)
+        if (hipError_t e = hipFuncSetAttribute((const void*)tile_backward_kernel<MODEL, CH, UNROLL, DET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))   // (the kernel has a few bytes of static LDS)
             return set_error_hip(e, "hipFuncSetAttribute(tile_backward)");
         attr = true;
     }
-    hipLaunchKernelGGL((tile_backward_kernel<MODEL, CH, UNROLL>), dim3(a.n_tiles + a.rel_blocks), dim3(TILE_THREADS), shmem, st, a);
+    hipLaunchKernelGGL((tile_backward_kernel<MODEL, CH, UNROLL, DET>), dim3(a.n_tiles + a.rel_blocks), dim3(TILE_THREADS), shmem, st, a);
     return check_launch("tile_backward");
 }
 
@@ -943,6 +944,12 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st) {
     // rows per entry, RotatE two complex ones)
     constexpr int U1 = TRILINEAR ? 8 : 4;
     constexpr int U2 = TRILINEAR ? 4 : 2;
+    if constexpr (MODEL == AMDKGE_ROTATE) {
+        if (te.det) {
+            if (f.nq <= 64 || f.nq > 128) return launch_tile<MODEL, 1, U1, true>(te, shmem_t, st);
+            return launch_tile<MODEL, 2, U2, true>(te, shmem_t, st);
+        }
+    }
     if (f.nq <= 64 || f.nq > 128) return launch_tile<MODEL, 1, U1>(te, shmem_t, st);
     return launch_tile<MODEL, 2, U2>(te, shmem_t, st);
 }

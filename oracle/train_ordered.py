@@ -212,7 +212,7 @@ def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None,
     """The schedule of tests/test_gpu_learning.py (planted graph, Glorot tables as the drop-in class draws them, sequential
     batches) through transe_pairwise_step / transe_step_det / trilinear_step_det -> (loss history, state, id triples of train / test).  opt / opt_hp: the update rule
     (kge_opt.h kind name) and its (beta1, beta2) descriptor fields."""
-    assert model in ("TransE", "DistMult", "ComplEx", "HolE") and loss in ("pairwise", "absolute_margin", "nll", "self_adversarial", "multiclass_nll")
+    assert model in ("TransE", "DistMult", "ComplEx", "HolE", "RotatE") and loss in ("pairwise", "absolute_margin", "nll", "self_adversarial", "multiclass_nll")
     assert model == "TransE" or loss in ("nll", "self_adversarial", "multiclass_nll")
     d = planted_kg(model, seed=seed)
     train, test = d["train"].astype(str), d["test"].astype(str)
@@ -227,7 +227,9 @@ def replay_learning(model, loss, seed, cfg, planted_kg, initialise, epochs=None,
         tot = 0.0
         for b in range(steps):
             xb = Xi[b * cfg["batch"]:(b + 1) * cfg["batch"]]
-            if model != "TransE":                                       # (deterministic mode only)
+            if model == "RotatE":                                       # (deterministic mode only)
+                tot += rotate_step_det(st, xb, cfg["eta"], seed, ep * steps + b, loss, max_rel_size=R)
+            elif model != "TransE":                                     # (deterministic mode only)
                 tot += trilinear_step_det(model, st, xb, cfg["eta"], seed, ep * steps + b, loss)
             elif loss in ("nll", "self_adversarial", "multiclass_nll"):   # (deterministic mode only: the owner-computes pair, quad layout)
                 tot += transe_step_det(st, xb, cfg["eta"], seed, ep * steps + b, loss)
@@ -543,7 +545,7 @@ def trilinear_step_det(model, state, pos, eta, seed, step, loss="self_adversaria
     feta = F32(float(eta))
     sgn_scale = F32(1.0)
     if model == "HolE":
-        sgn_scale = F32(F32(2.0) / F32(float(getattr(state, "k_live", k))))
+        sgn_scale = F32(2.0 / float(getattr(state, "k_live", k)))   # (float)(2.0 / k), kge_host.h model_const (HolE.py:45)
     comp = (lambda t: [t[:, h * k:(h + 1) * k] for h in range(NC)])
     s, p, o = comp(ent[pos[:, 0]]), comp(rel[pos[:, 1]]), comp(ent[pos[:, 2]])
 
@@ -627,6 +629,130 @@ def trilinear_step_det(model, state, pos, eta, seed, step, loss="self_adversaria
         role = np.where(keep[:, j], 0, 1)
         vec = _f(g_e[:, None] * np.where(keep[:, j][:, None], Arow, Brow))
         ent_dest.append(repl[live, j]); ent_pos.append(ar[live]); ent_role.append(role[live]); ent_g.append(g_e[live]); ent_vec.append(vec[live])
+    ent_dest += [pos[:, 0], pos[:, 2]]; ent_pos += [ar, ar]; ent_role += [np.full(B, 2), np.full(B, 3)]; ent_g += [one, one]; ent_vec += [gs, go]
+    Ge = _sorted_row_sums(ent.shape, ent_dest, ent_pos, ent_role, ent_g, ent_vec)
+    Gr = _batch_order_row_sums(rel.shape, pos[:, 1], gp)
+    total = float(per.astype(np.float64).sum())
+    if return_grads:
+        return total, Ge, Gr
+    state.apply(Ge, Gr)
+    return total
+
+
+def rotate_step_det(state, pos, eta, seed, step, loss="self_adversarial", margin=None, alpha=0.5, n_ents=None, max_rel_size=None,
+                    return_grads=False, debug=None):
+    """One step of RotatE (RotatE.py:62-105) with "nll", "self_adversarial" or "multiclass_nll" as the owner-computes pair carries
+    it out in DETERMINISTIC mode (stored k <= 256, a multiple of 4: one quad per component and lane, no padding units):
+      * the relation as (cos, sin) of the fp32 phase theta / fl32(embedding_range / pi), each correctly rounded (fp64 libm,
+        rounded once: rel_phase_kernel / prep_rel_exact);
+      * z = s o r - o with the reference's operations on both sides (object side: A - e with A = s o r; subject side:
+        e o r - o), |z| = sqrtf(fl(fl(zr zr) + fl(zi zi))) (IEEE square root), a lane adds its quad's moduli in order, wave tree,
+        score = -sum;
+      * per corruption the UNIT VECTOR z / |z| (one IEEE division 1 / |z|, two products), sum_j c_j z_j/|z_j| per side by fmaf in
+        corruption order, groups of THREE rows (PF = 3 for RotatE), online-softmax rescale;
+      * row gradients: d/ds = conj(r) o Z_obj, d/do = -Z_subj, d/dphase = Im(conj(A) Z_obj) + Im(conj(o) Z_subj), on top of
+        grad_unit's gradient of the positive; d/dtheta = d/dphase * fl(1 / phase_div);
+      * tile pass: an entry adds g (e - S) / |e - S| with S the staged side row (A, or B = o o conj(r)) and e the owner's live row."""
+    assert loss in ("nll", "self_adversarial", "multiclass_nll")
+    PF = 3
+    pos = np.asarray(pos, dtype=np.int64)
+    B = pos.shape[0]
+    ent, rel = state.ent, state.rel
+    K = ent.shape[1]
+    k = K // 2
+    assert k % 4 == 0 and k <= 256
+    N = ent.shape[0] if n_ents is None else int(n_ents)
+    gamma = F32(3.0 if margin is None else margin)
+    alpha = F32(alpha)
+    feta = F32(float(eta))
+    sgn_scale = F32(-1.0)
+    div = O.rotate_phase_divisor(k, rel.shape[0] if max_rel_size is None else max_rel_size)
+    m = lambda a, b: _f(a * b)   # noqa: E731
+    comp = lambda t: (t[:, :k], t[:, k:])   # noqa: E731
+    s0, s1 = comp(ent[pos[:, 0]])
+    o0, o1 = comp(ent[pos[:, 2]])
+    phi = _f(rel[pos[:, 1], :k] / div)
+    cs, sn_ = np.cos(phi.astype(np.float64)).astype(F32), np.sin(phi.astype(np.float64)).astype(F32)
+    A0, A1 = _f(m(s0, cs) - m(s1, sn_)), _f(m(s0, sn_) + m(s1, cs))      # A = s o r
+    B0, B1 = _f(m(o0, cs) + m(o1, sn_)), _f(m(o1, cs) - m(o0, sn_))      # B = o o conj(r)
+
+    def modulus(zr, zi):
+        return np.sqrt(_f(m(zr, zr) + m(zi, zi))).astype(F32)
+
+    re, im = _f(A0 - o0), _f(A1 - o1)
+    mp = modulus(re, im)
+    P = _f(sgn_scale * wave_sum(_unit_chain(mp)))
+    keep = np.zeros((B, eta), dtype=bool)
+    repl = np.zeros((B, eta), dtype=np.int64)
+    nsc = np.zeros((B, eta), dtype=F32)
+    unit = np.zeros((B, eta, K), dtype=F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for j in range(eta):
+            rows = np.uint64(j) * np.uint64(B) + np.arange(B, dtype=np.uint64)
+            kj, rj = sample_corruption_draws(rows, step, seed, N)
+            keep[:, j], repl[:, j] = kj.astype(bool), rj
+            e0, e1 = comp(ent[rj])
+            kk = keep[:, j][:, None]
+            zr = np.where(kk, _f(A0 - e0), _f(_f(m(e0, cs) - m(e1, sn_)) - o0))
+            zi = np.where(kk, _f(A1 - e1), _f(_f(m(e0, sn_) + m(e1, cs)) - o1))
+            mj = modulus(zr, zi)
+            nsc[:, j] = _f(sgn_scale * wave_sum(_unit_chain(mj)))
+            inv = _f(F32(1.0) / mj)
+            unit[:, j, :k], unit[:, j, k:] = m(zr, inv), m(zi, inv)
+    ar = np.arange(B)
+    order = np.argsort(~keep, axis=1, kind="stable")
+    nkeep = keep.sum(1)
+    av1 = np.zeros((2, B, K), dtype=F32)
+    av2 = np.zeros((2, B, K), dtype=F32)
+    two = loss == "self_adversarial"
+
+    def add_rows(side, m_, jcol, c1, c2):
+        e = unit[ar, jcol]
+        av1[side][m_] = fmaf32(c1[:, None], e, av1[side])[m_]
+        if two:
+            av2[side][m_] = fmaf32(c2[:, None], e, av2[side])[m_]
+
+    def rescale(g_, rs):
+        for dd in (0, 1):
+            av1[dd] = np.where(g_[:, None], _f(av1[dd] * rs[:, None]), av1[dd])
+            av2[dd] = np.where(g_[:, None], _f(av2[dd] * rs[:, None]), av2[dd])
+
+    S, Lw, Zs, m_run = _det_row_protocol(loss, nsc, order, nkeep, eta, alpha, gamma, PF, add_rows, rescale)
+    k1, k2, dP, sn, per = _det_finish(loss, P, nsc, S, Lw, Zs, m_run, alpha, gamma, feta)
+    k1, k2 = _f(k1 * sgn_scale)[:, None], _f(k2 * sgn_scale)[:, None]
+    eo0, eo1 = comp(_f(m(k1, av1[0]) + m(k2, av2[0])))             # Z_obj
+    es0, es1 = comp(_f(m(k1, av1[1]) + m(k2, av2[1])))             # Z_subj
+    # the positive's own gradient: grad_unit<RotatE>(s, (cos, sin), o, dP * sgn_scale)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        gm = _f(_f(dP * sgn_scale)[:, None] / mp)
+    gs0 = m(gm, _f(m(re, cs) + m(im, sn_)))
+    gs1 = m(gm, _f(m(-re, sn_) + m(im, cs)))
+    gp0 = m(gm, _f(m(re, _f(m(-s0, sn_) - m(s1, cs))) + m(im, _f(m(s0, cs) - m(s1, sn_)))))
+    go0, go1 = m(-gm, re), m(-gm, im)
+    # + the corruptions' parts
+    gs0 = _f(gs0 + _f(m(eo0, cs) + m(eo1, sn_)))
+    gs1 = _f(gs1 + _f(m(eo1, cs) - m(eo0, sn_)))
+    go0, go1 = _f(go0 - es0), _f(go1 - es1)
+    gp0 = _f(gp0 + _f(_f(m(eo1, A0) - m(eo0, A1)) + _f(m(es1, o0) - m(es0, o1))))
+    gs, go = np.concatenate([gs0, gs1], 1), np.concatenate([go0, go1], 1)
+    if debug is not None:
+        debug.update(P=P, nsc=nsc, keep=keep, repl=repl, gs=gs, go=go, sn=sn, dP=dP, per=per)
+    mul = _f(F32(1.0) / div)
+    gp = np.concatenate([m(gp0, mul), np.zeros((B, k), dtype=F32)], 1)     # d/dtheta; the second half of a relation row gets nothing
+    # ---- tile pass: g (e - S) / |e - S| per corruption entry, the owner's live row e ----
+    ent_dest, ent_pos, ent_role, ent_g, ent_vec = [], [], [], [], []
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for j in range(eta):
+            g_e = _f(sn[:, j] * sgn_scale)
+            live = g_e != 0
+            role = np.where(keep[:, j], 0, 1)
+            e0, e1 = comp(ent[repl[:, j]])
+            kk = keep[:, j][:, None]
+            dr, di = _f(e0 - np.where(kk, A0, B0)), _f(e1 - np.where(kk, A1, B1))
+            gmj = _f(g_e[:, None] / modulus(dr, di))
+            vec = np.concatenate([m(gmj, dr), m(gmj, di)], 1)
+            ent_dest.append(repl[live, j]); ent_pos.append(ar[live]); ent_role.append(role[live]); ent_g.append(g_e[live]); ent_vec.append(vec[live])
+    one = np.ones(B, dtype=F32)
     ent_dest += [pos[:, 0], pos[:, 2]]; ent_pos += [ar, ar]; ent_role += [np.full(B, 2), np.full(B, 3)]; ent_g += [one, one]; ent_vec += [gs, go]
     Ge = _sorted_row_sums(ent.shape, ent_dest, ent_pos, ent_role, ent_g, ent_vec)
     Gr = _batch_order_row_sums(rel.shape, pos[:, 1], gp)

@@ -34,7 +34,7 @@ HOT = [
     (_f(0, 1, 1), 4),     # TransE single pass
     (_f(4, 1, 1), 3),     # RotatE k <= 128 quads
     (_f(4, 4, 1), 3),     # C5 row width: four waves per positive
-    ("_ZN3kge20tile_backward_kernelILi2ELi1ELi8EEEvNS_8TileArgsE", 5),
+    ("_ZN3kge20tile_backward_kernelILi2ELi1ELi8ELb0EEEvNS_8TileArgsE", 5),
     ("_ZN3kge18tile_direct_kernelILi4ELi4EEEvNS_8TileArgsE", 3),
     ("_ZN3kge27rank_count_mfma_pipe_kernelENS_9CountArgsE", 2),
     ("_ZN3kge18rank_screen_kernelENS_10ScreenArgsE", 2),

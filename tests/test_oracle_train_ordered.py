@@ -199,3 +199,19 @@ def test_ordered_trilinear_steps_are_the_oracles_steps_up_to_rounding(model, K, 
     tot, Re, Rr, _ = O.dense_gradients(model, ent, rel, X, negs, eta, loss, None, "sum", rel.shape[0])
     assert abs(loss_v - float(tot)) <= 4e-6 * abs(float(tot))
     assert np.abs(Ge - Re).max() <= 4e-6 * np.abs(Re).max() + 1.3e-7 and np.abs(Gr - Rr).max() <= 4e-6 * np.abs(Rr).max() + 2e-5
+
+
+@pytest.mark.parametrize("loss", ["nll", "self_adversarial", "multiclass_nll"])
+@pytest.mark.parametrize("K,eta", [(32, 5), (400, 4), (128, 11)])
+def test_ordered_rotate_steps_are_the_oracles_steps_up_to_rounding(K, eta, loss):
+    """rotate_step_det (phases, unit vectors, per-side sums in groups of three, the gradient transform, the tile entries on the
+    owner's live rows) against the fp64 oracle's loss and dense gradients."""
+    rng = np.random.default_rng(K + eta)
+    ent, rel, X = _problem(rng, N=60, K=K, B=300)
+    st = TO.OptState(ent, rel, "adam", 1e-2)
+    R = rel.shape[0]
+    loss_v, Ge, Gr = TO.rotate_step_det(st, X, eta, 5, 2, loss, max_rel_size=R, return_grads=True)
+    negs = O.generate_corruptions(X, ent.shape[0], eta, 5, 2)
+    tot, Re, Rr, _ = O.dense_gradients("RotatE", ent, rel, X, negs, eta, loss, None, "sum", R)
+    assert abs(loss_v - float(tot)) <= 4e-6 * abs(float(tot))
+    assert np.abs(Ge - Re).max() <= 1e-5 * np.abs(Re).max() + 1.3e-7 and np.abs(Gr - Rr).max() <= 1e-5 * np.abs(Rr).max() + 2e-5
