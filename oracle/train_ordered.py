@@ -511,16 +511,53 @@ def fmaf32(a, b, c):
     return si.view(np.float64).astype(F32)
 
 
+def _pf_of(model, nq):
+    """Rows in flight per group of the forward kernel (kge_train_kernel.h: PF) for a row of nq quads per component: the launch
+    geometry is one wave per positive with 1 (nq <= 64) or 2 (<= 128) quads per component and lane, or four waves per positive
+    with 1 (<= 256) or 2 quads (kge_train_tiled.hip run_tiled)."""
+    ch = 1 if nq <= 64 else (2 if nq <= 128 else (1 if nq <= 256 else 2))
+    nc = 1 if model in ("DistMult", "TransE") else 2
+    return (3 if model == "RotatE" else 6) if ch * nc * 4 <= 8 else 2
+
+
+def _reduce_quads(tq):
+    """[n, nq] per-QUAD partial sums -> [n] row sums in the forward kernel's declared order.  Up to 128 quads: ONE wave, lane l
+    holds quads l and l + 64 (added from 0 in that order), the wave64 DPP tree.  More (four waves per positive, 256 threads):
+    thread t holds quads t and t + 256, every wave reduces its 64 threads by the tree, the four wave sums are added in wave
+    order from 0 (they meet in LDS)."""
+    tq = _f(tq)
+    n, nq = tq.shape
+    assert nq <= 512
+    width = 64 if nq <= 128 else 256
+    thr = np.zeros((n, width), dtype=F32)
+    for c0 in range(0, nq, width):
+        blk = tq[:, c0:c0 + width]
+        thr[:, :blk.shape[1]] = _f(thr[:, :blk.shape[1]] + blk)
+    if width == 64:
+        return wave_sum(thr)
+    tot = np.zeros(n, dtype=F32)
+    for w in range(4):
+        tot = _f(tot + wave_sum(thr[:, 64 * w:64 * w + 64]))
+    return tot
+
+
 def _unit_chain(vals):
-    """[n, k] per-unit values -> [n, 64] lane sums in the quad layout (lane q adds its quad's four units in order from 0)."""
-    return _lane_sums(_f(vals), "quad")
+    """[n, k] per-unit values -> [n] row sums: a quad's four units added in order from 0, then _reduce_quads."""
+    vals = _f(vals)
+    n, k = vals.shape
+    q = vals.reshape(n, k // 4, 4)
+    acc = np.zeros((n, k // 4), dtype=F32)
+    for u in range(4):
+        acc = _f(acc + q[:, :, u])
+    return _reduce_quads(acc)
 
 
 def trilinear_step_det(model, state, pos, eta, seed, step, loss="self_adversarial", margin=None, alpha=0.5, n_ents=None,
                        return_grads=False):
     """One step of DistMult / ComplEx / HolE with "nll", "self_adversarial" or "multiclass_nll" (reduction "sum") as the
-    owner-computes pair carries it out in DETERMINISTIC mode, one wave per positive and one quad per component and lane (stored
-    k <= 256).  What differs from transe_step_det is the model arithmetic (kge_train_kernel.h, ONEPASS branch; kge_device.h
+    owner-computes pair carries it out in DETERMINISTIC mode, in every launch geometry of the forward kernel (one wave per
+    positive with one or two quads per component and lane, four waves per positive for stored k > 512: _reduce_quads, _pf_of).
+    What differs from transe_step_det is the model arithmetic (kge_train_kernel.h, ONEPASS branch; kge_device.h
     score_unit / grad_unit -- plain products and sums, each rounded where it is written, -ffp-contract=off):
       * the positive's score: score_unit per unit (DistMult.py:48, ComplEx.py:58-62), a quad's units added in order, wave tree;
       * a corruption's score as a dot product with the side row A = d/do (s, p) or B = d/ds (p, o) (the query-vector form of
@@ -531,14 +568,14 @@ def trilinear_step_det(model, state, pos, eta, seed, step, loss="self_adversaria
       * tile pass: an entry adds fl(g A) or fl(g B) (own rows: 1 * staged gradient), a row's entries in sorted order.
     State rows are the STORED rows: [re | im] halves for the complex models."""
     assert model in ("DistMult", "ComplEx", "HolE") and loss in ("nll", "self_adversarial", "multiclass_nll")
-    PF = 6
     pos = np.asarray(pos, dtype=np.int64)
     B = pos.shape[0]
     ent, rel = state.ent, state.rel
     K = ent.shape[1]
     NC = 1 if model == "DistMult" else 2
     k = K // NC
-    assert k % 4 == 0 and k <= 256
+    assert k % 4 == 0 and k <= 2048
+    PF = _pf_of(model, k // 4)
     N = ent.shape[0] if n_ents is None else int(n_ents)
     gamma = F32(3.0 if margin is None else margin)
     alpha = F32(alpha)
@@ -568,18 +605,16 @@ def trilinear_step_det(model, state, pos, eta, seed, step, loss="self_adversaria
         su = _f(_f(s[0] * p[0]) * o[0])
     else:
         su = _f(_f(s[0] * _f(_f(p[0] * o[0]) + _f(p[1] * o[1]))) + _f(s[1] * _f(_f(p[0] * o[1]) - _f(p[1] * o[0]))))
-    P = _f(sgn_scale * wave_sum(_unit_chain(su)))
+    P = _f(sgn_scale * _unit_chain(su))
 
     def row_score(q, e):
-        """per lane: t = fmaf(q[u][h], e[u][h], t) over u = 0..3, h = 0..NC-1 from 0; lanes by the wave tree."""
+        """per quad: t = fmaf(q[u][h], e[u][h], t) over u = 0..3, h = 0..NC-1 from 0; quads by _reduce_quads."""
         n = q[0].shape[0]
         t = np.zeros((n, k // 4), dtype=F32)
         for u in range(4):
             for h in range(NC):
                 t = fmaf32(q[h][:, u::4], e[h][:, u::4], t)
-        lanes = np.zeros((n, 64), dtype=F32)
-        lanes[:, :k // 4] = t
-        return _f(sgn_scale * wave_sum(lanes))
+        return _f(sgn_scale * _reduce_quads(t))
 
     keep = np.zeros((B, eta), dtype=bool)
     repl = np.zeros((B, eta), dtype=np.int64)
@@ -642,25 +677,25 @@ def trilinear_step_det(model, state, pos, eta, seed, step, loss="self_adversaria
 def rotate_step_det(state, pos, eta, seed, step, loss="self_adversarial", margin=None, alpha=0.5, n_ents=None, max_rel_size=None,
                     return_grads=False, debug=None):
     """One step of RotatE (RotatE.py:62-105) with "nll", "self_adversarial" or "multiclass_nll" as the owner-computes pair carries
-    it out in DETERMINISTIC mode (stored k <= 256, a multiple of 4: one quad per component and lane, no padding units):
+    it out in DETERMINISTIC mode (stored k a multiple of 4, i.e. no padding units; every launch geometry: _reduce_quads, _pf_of):
       * the relation as (cos, sin) of the fp32 phase theta / fl32(embedding_range / pi), each correctly rounded (fp64 libm,
         rounded once: rel_phase_kernel / prep_rel_exact);
       * z = s o r - o with the reference's operations on both sides (object side: A - e with A = s o r; subject side:
         e o r - o), |z| = sqrtf(fl(fl(zr zr) + fl(zi zi))) (IEEE square root), a lane adds its quad's moduli in order, wave tree,
         score = -sum;
       * per corruption the UNIT VECTOR z / |z| (one IEEE division 1 / |z|, two products), sum_j c_j z_j/|z_j| per side by fmaf in
-        corruption order, groups of THREE rows (PF = 3 for RotatE), online-softmax rescale;
+        corruption order, groups of THREE rows (two with two quads per lane), online-softmax rescale;
       * row gradients: d/ds = conj(r) o Z_obj, d/do = -Z_subj, d/dphase = Im(conj(A) Z_obj) + Im(conj(o) Z_subj), on top of
         grad_unit's gradient of the positive; d/dtheta = d/dphase * fl(1 / phase_div);
       * tile pass: an entry adds g (e - S) / |e - S| with S the staged side row (A, or B = o o conj(r)) and e the owner's live row."""
     assert loss in ("nll", "self_adversarial", "multiclass_nll")
-    PF = 3
     pos = np.asarray(pos, dtype=np.int64)
     B = pos.shape[0]
     ent, rel = state.ent, state.rel
     K = ent.shape[1]
     k = K // 2
-    assert k % 4 == 0 and k <= 256
+    assert k % 4 == 0 and k <= 2048
+    PF = _pf_of("RotatE", k // 4)
     N = ent.shape[0] if n_ents is None else int(n_ents)
     gamma = F32(3.0 if margin is None else margin)
     alpha = F32(alpha)
@@ -681,7 +716,7 @@ def rotate_step_det(state, pos, eta, seed, step, loss="self_adversarial", margin
 
     re, im = _f(A0 - o0), _f(A1 - o1)
     mp = modulus(re, im)
-    P = _f(sgn_scale * wave_sum(_unit_chain(mp)))
+    P = _f(sgn_scale * _unit_chain(mp))
     keep = np.zeros((B, eta), dtype=bool)
     repl = np.zeros((B, eta), dtype=np.int64)
     nsc = np.zeros((B, eta), dtype=F32)
@@ -696,7 +731,7 @@ def rotate_step_det(state, pos, eta, seed, step, loss="self_adversarial", margin
             zr = np.where(kk, _f(A0 - e0), _f(_f(m(e0, cs) - m(e1, sn_)) - o0))
             zi = np.where(kk, _f(A1 - e1), _f(_f(m(e0, sn_) + m(e1, cs)) - o1))
             mj = modulus(zr, zi)
-            nsc[:, j] = _f(sgn_scale * wave_sum(_unit_chain(mj)))
+            nsc[:, j] = _f(sgn_scale * _unit_chain(mj))
             inv = _f(F32(1.0) / mj)
             unit[:, j, :k], unit[:, j, k:] = m(zr, inv), m(zi, inv)
     ar = np.arange(B)

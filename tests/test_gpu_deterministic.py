@@ -76,3 +76,53 @@ def test_deterministic_fit_is_reproducible(gpu_lib):
         outs.append((m._engine.ent.clone(), m._engine.rel.clone(), h.history["loss"]))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert np.allclose(outs[0][2], outs[1][2], rtol=1e-12)
+
+
+WIDE = [("DistMult", 400, 30, "self_adversarial"),     # C3's row: 100 quads, two per lane, groups of six rows
+        ("ComplEx", 352, 20, "self_adversarial"),      # the reference's published k = 350 as stored: 88 quads per component, groups of two
+        ("ComplEx", 600, 8, "nll"),                    # four waves per positive, one quad per component and thread
+        ("DistMult", 1200, 6, "multiclass_nll"),       # four waves, two quads per thread
+        ("RotatE", 1000, 64, "self_adversarial"),      # C5's row and eta: four waves, groups of three
+        ("RotatE", 352, 20, "nll")]                    # one wave, two quads per lane, groups of two
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,k,eta,loss", WIDE, ids=[f"{m}-{k}-{e}-{l}" for m, k, e, l in WIDE])
+def test_deterministic_steps_bitwise_in_every_launch_geometry(gpu_lib, model, k, eta, loss):
+    """Two whole deterministic steps (owner-computes pair + dense Adam) at the row widths that take the forward kernel's other
+    launch geometries -- two quads per lane, four waves per positive (partial sums meeting in LDS), groups of two / three / six
+    rows -- against oracle/train_ordered (trilinear_step_det / rotate_step_det: _reduce_quads, _pf_of): tables and Adam slots
+    bit-identical.  Incl. BASELINE configs[2]'s row (DistMult k = 400, eta = 30) and configs[4]'s (RotatE k = 1000, eta = 64)."""
+    import torch
+
+    from oracle import train_ordered as TO
+
+    from ampligraph_amd.engine import KgeEngine
+    from ampligraph_amd.latent_features import loss_functions, optimizers
+    from ampligraph_amd.trainer import StepLoop
+
+    N, R, B = 1500, 7, 1024
+    rng = np.random.default_rng(k + eta)
+    K = k if model == "DistMult" else 2 * k
+    ent = rng.uniform(-0.2, 0.2, size=(N, K)).astype(np.float32)
+    rel = rng.uniform(-0.2, 0.2, size=(R, K)).astype(np.float32)
+    X = np.stack([rng.integers(0, N, 2 * B), rng.integers(0, R, 2 * B), rng.integers(0, N, 2 * B)], 1).astype(np.int32)
+    eng = KgeEngine(model, k, N, R, max_rel_size=R)
+    eng.set_tables(ent, rel)
+    loop = StepLoop(eng, eta, loss_functions.get(loss), optimizers.get("adam", {"learning_rate": 1e-2}), None, seed=6, dist=None)
+    loop.deterministic = True
+    st = TO.OptState(ent.copy(), rel.copy(), "adam", 1e-2)
+    Xd = torch.as_tensor(X).cuda()
+    loop.reset_loss()
+    ref = 0.0
+    for step in range(2):
+        loop.step(Xd[step * B:(step + 1) * B], step)
+        xb = X[step * B:(step + 1) * B]
+        ref += (TO.rotate_step_det(st, xb, eta, 6, step, loss, max_rel_size=R) if model == "RotatE"
+                else TO.trilinear_step_det(model, st, xb, eta, 6, step, loss))
+    torch.cuda.synchronize()
+    got = loop.mean_batch_loss() * 2
+    e, r = eng.get_tables()
+    assert np.array_equal(e, st.ent) and np.array_equal(r, st.rel), (int((e != st.ent).sum()), int((r != st.rel).sum()), float(np.abs(e - st.ent).max()))
+    assert np.array_equal(eng.unpack(eng.slots["m_e"]).cpu().numpy(), st.s0[0]) and np.array_equal(eng.unpack(eng.slots["v_e"]).cpu().numpy(), st.s1[0])
+    assert abs(got - ref) <= (5e-6 if loss == "multiclass_nll" else 1e-12) * abs(ref), (got, ref)

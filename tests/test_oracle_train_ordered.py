@@ -186,7 +186,8 @@ def test_fmaf32_is_libm_fmaf():
 
 
 @pytest.mark.parametrize("loss", ["nll", "self_adversarial", "multiclass_nll"])
-@pytest.mark.parametrize("model,K,eta", [("DistMult", 16, 5), ("ComplEx", 32, 5), ("ComplEx", 400, 3), ("HolE", 64, 13), ("DistMult", 200, 7)])
+@pytest.mark.parametrize("model,K,eta", [("DistMult", 16, 5), ("ComplEx", 32, 5), ("ComplEx", 400, 3), ("HolE", 64, 13), ("DistMult", 200, 7),
+                                         ("DistMult", 400, 7), ("ComplEx", 704, 5), ("ComplEx", 1200, 3), ("DistMult", 1200, 4)])
 def test_ordered_trilinear_steps_are_the_oracles_steps_up_to_rounding(model, K, eta, loss):
     """trilinear_step_det (side rows, fmaf score chains, sum_j c_j e_j with the online softmax, grad_unit transforms, sorted tile
     sums) against the fp64 oracle's loss and dense gradients."""
@@ -202,7 +203,7 @@ def test_ordered_trilinear_steps_are_the_oracles_steps_up_to_rounding(model, K, 
 
 
 @pytest.mark.parametrize("loss", ["nll", "self_adversarial", "multiclass_nll"])
-@pytest.mark.parametrize("K,eta", [(32, 5), (400, 4), (128, 11)])
+@pytest.mark.parametrize("K,eta", [(32, 5), (400, 4), (128, 11), (200 * 2 + 8, 5), (2000, 7)])
 def test_ordered_rotate_steps_are_the_oracles_steps_up_to_rounding(K, eta, loss):
     """rotate_step_det (phases, unit vectors, per-side sums in groups of three, the gradient transform, the tile entries on the
     owner's live rows) against the fp64 oracle's loss and dense gradients."""
