@@ -517,19 +517,25 @@ class KgeEngine:
         return [float(v) for v in out.tolist()]
 
     # ------------------------------------------------------------------ evaluate
-    def _workspace(self, n):
+    def _workspace(self, n, lane=0):
         need = int(self.lib.amdkge_rank_workspace_bytes(C.byref(self.model), n))
+        if lane:
+            return self._buf(f"rank_work_lane{lane}", (need,), torch.uint8)
         if self._work is None or self._work.numel() < need:
             self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._work
 
     SCREEN_MAX_BYTES = 4 << 30
 
-    def _side_stream(self):
-        """Second stream of this engine's device (the filter pass of rank_side runs on it beside the count pass)."""
-        if getattr(self, "_fstream", None) is None:
-            self._fstream = torch.cuda.Stream(device=self.device)
-        return self._fstream
+    def _side_stream(self, lane=0):
+        """Extra streams of this engine's device: 2 * lane for the filter pass of rank_side (beside the count pass), 2 * lane + 1
+        for the lane itself when rank_sides runs several corruption sides at once."""
+        st = getattr(self, "_fstreams", None)
+        if st is None:
+            st = self._fstreams = {}
+        if lane not in st:
+            st[lane] = torch.cuda.Stream(device=self.device)
+        return st[lane]
 
     def screen_stats(self):
         """(rechecked pairs, fell back to the exact kernel?) of the last rank_side call's screening pass, or None when it ran
@@ -540,16 +546,38 @@ class KgeEngine:
         v = s[:8].view(torch.int32).cpu().numpy()
         return int(v[0]), bool(v[1])
 
+    def rank_sides(self, triples, jobs, strategy="worst", ent_ids=None, subset_pos=None):
+        """Several corruption sides of the same triples AT ONCE: jobs = [(side, flt, out, out_stride), ...], each on a stream and
+        with workspaces of its own, joined into the current stream.  A side is one long kernel (the screening / count pass) between
+        a dozen short latency-bound ones (query vectors, limbs, thresholds, merge, compose: ~13 % of a side at the C2 shape); with
+        two sides in flight the short kernels of one run under the long kernel of the other."""
+        if len(jobs) == 1:
+            side, flt, out, stride = jobs[0]
+            return [self.rank_side(triples, side, strategy, flt, ent_ids, subset_pos, out=out, out_stride=stride)]
+        main = torch.cuda.current_stream()
+        res, lanes = [], []
+        for i, (side, flt, out, stride) in enumerate(jobs):
+            st = self._side_stream(2 * i + 1)
+            st.wait_stream(main)
+            lanes.append(st)
+            with torch.cuda.stream(st):
+                res.append(self.rank_side(triples, side, strategy, flt, ent_ids, subset_pos, out=out, out_stride=stride, lane=i))
+        for st in lanes:
+            main.wait_stream(st)
+        return res
+
     def rank_side(self, triples, side, strategy="worst", flt=None, ent_ids=None, subset_pos=None,
-                  ent_lo=0, ent_hi=None, out=None, out_stride=1, flt_range=None):
+                  ent_lo=0, ent_hi=None, out=None, out_stride=1, flt_range=None, lane=0):
         """Ranks (1-based, reference semantics) of `triples` for one corruption side.
 
         flt: None or (lo int64[n], hi int64[n], ids int32[*]) cuda tensors; flt_range: id range the filter ids are
-        checked against when it differs from the candidate positions [ent_lo, ent_hi) (row-sharded subsets)."""
+        checked against when it differs from the candidate positions [ent_lo, ent_hi) (row-sharded subsets); lane: which set of
+        workspaces / side stream to use (rank_sides)."""
         n = int(triples.shape[0])
         if ent_hi is None:
             ent_hi = self.n_ents if ent_ids is None else int(ent_ids.shape[0])
-        work = self._workspace(n)
+        work = self._workspace(n, lane)
+        sfx = f"_lane{lane}" if lane else ""
         counts = torch.zeros(n, 2, dtype=torch.int32, device=self.device)
         # contraction models: the int8 screening pass + exact recheck (kge_rank_screen.h) -- the same counts, bit for bit, at a
         # multiple of the fp32 matrix rate; its workspace (fixed-point copies of the query vectors and the candidate rows, the
@@ -557,7 +585,7 @@ class KgeEngine:
         screen, sbytes = None, 0
         need = int(self.lib.amdkge_rank_screen_workspace_bytes(C.byref(self.model), n, int(ent_hi) - int(ent_lo))) if n > 0 else 0
         if 0 < need <= self.SCREEN_MAX_BYTES:
-            screen, sbytes = self._buf("rank_screen", (need,), torch.uint8), need
+            screen, sbytes = self._buf("rank_screen" + sfx, (need,), torch.uint8), need
         self._last_screen = screen
         # The filter pass (a latency-bound walk over each triple's known positives) is independent of the count pass: it runs
         # beside it on a second stream with a workspace of its own and is joined before the two are composed.
@@ -566,8 +594,8 @@ class KgeEngine:
             lo, hi, ids = flt
             sub = torch.zeros(n, dtype=torch.int32, device=self.device)
             f_lo, f_hi = (ent_lo, ent_hi) if flt_range is None else flt_range
-            fwork = self._buf("rank_work_filter", (work.numel(),), torch.uint8)
-            fstream = self._side_stream()
+            fwork = self._buf("rank_work_filter" + sfx, (work.numel(),), torch.uint8)
+            fstream = self._side_stream(2 * lane)
             fstream.wait_stream(main)
             with torch.cuda.stream(fstream):
                 check(self.lib.amdkge_rank_filter(C.byref(self.model), _ptr(self.ent), _ptr(self.rel), _ptr(triples),

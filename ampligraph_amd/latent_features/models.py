@@ -512,10 +512,11 @@ class ScoringBasedEmbeddingModel:
         CH = 1 << 16
         for c0 in range(0, n, CH):
             xs = Xd[c0:c0 + CH]
+            jobs = []
             for col, sd in enumerate(sides):
                 flt = fi.device_filter(eng, xs, sd) if fi is not None else None   # range lookup on the device
-                eng.rank_side(xs, _ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, ranking_strategy, flt, ent_ids,
-                              subset_pos, out=ranks[c0:c0 + CH, col], out_stride=len(sides))
+                jobs.append((_ffi.SIDE_S if sd == "s" else _ffi.SIDE_O, flt, ranks[c0:c0 + CH, col], len(sides)))
+            eng.rank_sides(xs, jobs, ranking_strategy, ent_ids, subset_pos)   # the sides run beside each other
         r = ranks.cpu().numpy()
         if corrupt_side == "s+o":  # :1459-1463 sums the two 0-based sides, then +1 (:1684)
             r = (r.sum(1, keepdims=True) - 1).astype(np.int32)

@@ -205,9 +205,12 @@ def eval_bench(eng, data, rank, triples=None, filter_sets=None):
     index_ms = (time.perf_counter() - t0) * 1e3
     ranks = torch.empty(n, 2, dtype=torch.int32, device=dev)
 
-    def run():
-        eng.rank_side(Xd, _ffi.SIDE_S, "worst", fs, out=ranks[:, 0], out_stride=2)
-        eng.rank_side(Xd, _ffi.SIDE_O, "worst", fo, out=ranks[:, 1], out_stride=2)
+    def run():   # (what models.evaluate does: both sides in flight, each on its own stream)
+        if os.environ.get("AMDKGE_BENCH_EVAL_SERIAL", "0") == "1":
+            eng.rank_side(Xd, _ffi.SIDE_S, "worst", fs, out=ranks[:, 0], out_stride=2)
+            eng.rank_side(Xd, _ffi.SIDE_O, "worst", fo, out=ranks[:, 1], out_stride=2)
+        else:
+            eng.rank_sides(Xd, [(_ffi.SIDE_S, fs, ranks[:, 0], 2), (_ffi.SIDE_O, fo, ranks[:, 1], 2)], "worst")
 
     run()
     torch.cuda.synchronize()
