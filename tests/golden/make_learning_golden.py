@@ -22,6 +22,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # 0.0038 / 0.0009 / 0.0024 / 0.0127) -- the standard error of the mean distance is at most 0.0006, under a third of the
 # north_star's +-0.002.  A GPU fit + evaluate of one seed takes ~30 ms, so the seeds are cheap; the oracle's side is not (1 - 3 s).
 CASES = [("TransE", "nll", 512), ("TransE", "pairwise", 512), ("RotatE", "self_adversarial", 512), ("RotatE", "nll", 2048)]
+# Second stage of a SEQUENTIAL test (key "<model>/<loss>/ext", seeds n .. n + m - 1): RotatE / nll is the one case whose bar is
+# only ~3 standard errors from its measured mean distance (-0.0004 +- 0.00055 against 0.002), i.e. one run in ~500 would fail by
+# chance; when the first stage's mean distance is beyond 0.0012 the test fits these seeds too and asserts on all of them
+# (standard error 0.00039: ~4 sigma).  `--extend` adds the keys to the existing file without recomputing the first stage.
+EXTENSIONS = [("RotatE", "nll", 2048, 2048)]
 
 
 def one(job):
@@ -43,5 +48,20 @@ def build():
     return out
 
 
+def extend():
+    path = os.path.join(HERE, "learning_mrr_v1.npz")
+    out = dict(np.load(path))
+    with Pool(os.cpu_count() or 4) as pool:
+        for model, loss, first, m in EXTENSIONS:
+            res = np.asarray(pool.map(one, [(model, loss, s) for s in range(first, first + m)]), dtype=np.float64)
+            out[f"{model}/{loss}/ext"] = res
+            print(model, loss, "extension", first, "..", first + m - 1, ": oracle MRR mean", res[:, 0].mean(), "sd", res[:, 0].std(), flush=True)
+    np.savez_compressed(path, **out)
+
+
 if __name__ == "__main__":
-    np.savez_compressed(os.path.join(HERE, "learning_mrr_v1.npz"), **build())
+    if "--extend" in sys.argv:
+        extend()
+    else:
+        np.savez_compressed(os.path.join(HERE, "learning_mrr_v1.npz"), **build())
+        extend()

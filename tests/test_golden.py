@@ -27,7 +27,7 @@ def test_oracle_reproduces_golden_bitwise():
 
 
 @pytest.mark.parametrize("model,loss,seed", [("TransE", "nll", 5), ("TransE", "pairwise", 511), ("RotatE", "self_adversarial", 340),
-                                             ("RotatE", "nll", 2047)])
+                                             ("RotatE", "nll", 2047), ("RotatE", "nll", 2048 + 1777)])
 def test_oracle_reproduces_learning_golden(model, loss, seed):
     """tests/golden/learning_mrr_v1.npz (the oracle's side of test_gpu_learning's many-seed MRR test): a sample re-derived."""
     import sys
@@ -37,9 +37,13 @@ def test_oracle_reproduces_learning_golden(model, loss, seed):
     import make_learning_golden
 
     L = np.load(os.path.join(HERE, "golden", "learning_mrr_v1.npz"))
-    assert {f"{m}/{ls}": n for m, ls, n in make_learning_golden.CASES} == {k: len(L[k]) for k in L.files}
+    want = {f"{m}/{ls}": n for m, ls, n in make_learning_golden.CASES}
+    want.update({f"{m}/{ls}/ext": n for m, ls, _, n in make_learning_golden.EXTENSIONS})
+    assert want == {k: len(L[k]) for k in L.files}
     got = make_learning_golden.one((model, loss, seed))
-    assert np.array_equal(np.asarray(got, dtype=np.float64), L[f"{model}/{loss}"][seed]), (got, L[f"{model}/{loss}"][seed])
+    n1 = want[f"{model}/{loss}"]
+    ref = L[f"{model}/{loss}"][seed] if seed < n1 else L[f"{model}/{loss}/ext"][seed - n1]   # (second-stage seeds follow the first stage's)
+    assert np.array_equal(np.asarray(got, dtype=np.float64), ref), (got, ref)
 
 
 @pytest.mark.gpu
