@@ -1046,12 +1046,14 @@ extern "C" int amdkge_train_step_tiled(const amdkge_model* m, const amdkge_loss*
     te.reg_loss = d_reg_loss; te.n_rows = m->n_ents; te.k = ks; te.K = K; te.k_live = m->k; te.nq = ks / 4;
     te.tile_rows = p.tile_rows; te.n_tiles = p.n_tiles; te.cap = p.cap; te.ovf_cap = p.ovf_cap; te.rb = p.rb; te.mc = f.mc;
     fill_opt_args(te.opt, opt);
-    // Whole step in two launches when nothing in the tile pass reads the live relation table (trilinear models)
-    // and the tables are updated in place: the relation sweep rides in extra workgroups of the tile kernel.
-    // TransE / RotatE tiles read live relation rows, so their relation sweep stays a separate launch behind.
+    // Whole step in two launches when nothing in the tile pass reads the live relation table and the tables are updated in
+    // place: the relation sweep rides in extra workgroups of the tile kernel.  That holds for the trilinear models (their
+    // entries need the staged side row only) and for RotatE (staged side row, already rotated, + the owner's row; the forward
+    // kernel read the relation through the per-step phase table).  TransE tiles read live relation rows (the three-row form of
+    // an entry: all of them in deterministic mode, the near-zero units otherwise), so its sweep stays a separate launch behind.
     const bool rel_here = apply_update && d_rel_slot_ok;
     // (the touched-rows relation sweep is row-wise: it runs as its own launch behind the tiles)
-    const bool fuse_rel = rel_here && !lazy && (m->scoring_type == AMDKGE_DISTMULT || m->scoring_type == AMDKGE_COMPLEX || m->scoring_type == AMDKGE_HOLE);
+    const bool fuse_rel = rel_here && !lazy && m->scoring_type != AMDKGE_TRANSE;
     te.rel_blocks = 0;
     if (rel_here) {
         te.rel_opt = te.opt;
