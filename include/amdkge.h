@@ -223,7 +223,11 @@ int amdkge_opt_step(const amdkge_opt* opt, float* d_x, float* d_grad, float* d_s
  * positive and added per relation in batch order by a second kernel: no atomics touch a gradient.  Costs a smaller tile (the LDS
  * is shared with the sort buffer), the sort, and a fifth staged row per positive.  Excludes POS_ATOMIC.  A tile whose entries
  * exceed the sort buffer (an extremely hot tile) is processed unsorted and reported by amdkge_train_tiled_status.
- * (The fp64 loss accumulators still use atomics: they agree to ~1e-15 relative and feed nothing back into the tables.) */
+ * (The fp64 loss accumulators still use atomics: they agree to ~1e-15 relative and feed nothing back into the tables.)
+ * The mode is also CPU-REPRODUCIBLE: its kernels evaluate the loss terms with declared transcendentals (IEEE add / mul / div
+ * only: Cody-Waite exp, atanh-series log) and RotatE's moduli with IEEE sqrtf / division instead of the hardware
+ * approximations, so that a numpy restatement of the declared order (oracle/train_ordered.py, test infrastructure) yields the
+ * same bits for every model -- tests/test_gpu_learning.py, test_gpu_deterministic.py, test_gpu_fullsize.py. */
 #define AMDKGE_TILED_DETERMINISTIC 2
 /* AMDKGE_TILED_HOT_ROWS: skewed graphs.  Up to 64 "hot" entity rows, declared beforehand with amdkge_train_tiled_set_hot_rows,
  * receive the gradient rows of the positives whose s / o they are through atomic row-adds spread over 16 replica rows each
