@@ -26,6 +26,22 @@ the ranks (oracle/rank_ordered.py) ONE order has to be fixed for "identical" to 
 Only the fp64 sum of the per-positive losses is order-dependent (~1e-16 relative; nothing feeds back).  Pinned on the CPU
 (tests/test_oracle_train_ordered.py): equal to kge_oracle.train_step wherever no decision is within rounding of its boundary
 (dyadic tables: bit for bit), and the wave tree against an independent restatement.
+
+The losses with transcendentals and the other four models (round 4, second half).  The default kernels evaluate exp / log / rcp /
+sqrt with the hardware approximations (1-2 ulp, implementation-defined bits), which no CPU can reproduce; the DETERMINISTIC mode
+(AMDKGE_TILED_DETERMINISTIC) uses declared forms built from IEEE operations only -- det_exp / det_log12 / det_sig_logsig below are
+the same formulas in numpy -- and IEEE sqrtf / division, adds every gradient row's entries in a canonical sorted order and the
+relation gradient in batch order.  Restated here for that mode, whole steps:
+  * transe_step_det       TransE x {nll, self_adversarial, multiclass_nll} (rows of up to 256 units);
+  * trilinear_step_det    DistMult / ComplEx / HolE x the same losses, every launch geometry of the forward kernel
+                          (DistMult.py:48, ComplEx.py:58-62,93-107,138-150, HolE.py:45);
+  * rotate_step_det       RotatE (RotatE.py:62-105), every launch geometry;
+with the shared protocol of the single-pass forward kernel (_det_row_protocol: rows ordered by side, groups of PF rows, the
+online softmax of the self-adversarial loss with its rescale), its closing arithmetic (_det_finish), the sorted tile sums
+(_sorted_row_sums) and the batch-ordered relation gradient (_batch_order_row_sums).  fmaf32 restates the one-rounding fma (numpy
+has none) and is pinned against libm's.  Pinned on the CPU against kge_oracle's fp64 loss and dense gradients to a few 1e-6; on the
+GPU the deterministic fits are BIT-IDENTICAL to replay_learning for all five models (tests/test_gpu_learning.py,
+test_gpu_deterministic.py, test_gpu_fullsize.py).
 """
 import math
 
