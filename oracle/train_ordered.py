@@ -82,8 +82,12 @@ def _lane_sums(absd, layout="quad"):
 
 
 def transe_scores(s, p, o, layout="quad"):
-    """-(sum |fl(fl(s + p) - o)|) in the declared order; s, p, o fp32 [n, K]."""
+    """-(sum |fl(fl(s + p) - o)|) in the declared order; s, p, o fp32 [n, K].  Rows beyond 512 units (quad layout only): four
+    waves per positive, their sums added in wave order (_reduce_quads)."""
     d = ((s + p).astype(F32) - o).astype(F32)
+    if d.shape[1] > 512:
+        assert layout == "quad"
+        return (F32(-1.0) * _unit_chain(np.abs(d))).astype(F32), d
     return (F32(-1.0) * wave_sum(_lane_sums(np.abs(d), layout))).astype(F32), d
 
 
@@ -195,7 +199,7 @@ def transe_pairwise_step(state, pos, eta, seed, step, margin=1.0, n_ents=None, r
         keep = keep.astype(bool)
         # object replaced: fl(fl(s + p) - e); subject replaced: fl(fl(e + p) - o)
         d = np.where(keep[:, None], (sp - e).astype(F32), ((e + p).astype(F32) - o).astype(F32))
-        n_j = (F32(-1.0) * wave_sum(_lane_sums(np.abs(d), layout))).astype(F32)
+        n_j = ((F32(-1.0) * _unit_chain(np.abs(d))) if d.shape[1] > 512 else (F32(-1.0) * wave_sum(_lane_sums(np.abs(d), layout)))).astype(F32)
         h = (mP + n_j).astype(F32) if loss == "pairwise" else (margin + n_j).astype(F32)
         act = h >= 0
         h_lanes[:, j % 64] = (h_lanes[:, j % 64] + np.maximum(h, F32(0))).astype(F32)

@@ -83,7 +83,9 @@ WIDE = [("DistMult", 400, 30, "self_adversarial"),     # C3's row: 100 quads, tw
         ("ComplEx", 600, 8, "nll"),                    # four waves per positive, one quad per component and thread
         ("DistMult", 1200, 6, "multiclass_nll"),       # four waves, two quads per thread
         ("RotatE", 1000, 64, "self_adversarial"),      # C5's row and eta: four waves, groups of three
-        ("RotatE", 352, 20, "nll")]                    # one wave, two quads per lane, groups of two
+        ("RotatE", 352, 20, "nll"),                    # one wave, two quads per lane, groups of two
+        ("TransE", 600, 8, "pairwise"),                # four waves per positive, the sign-stash form (integer gradients)
+        ("TransE", 352, 20, "absolute_margin")]        # one wave, two quads per lane
 
 
 @pytest.mark.gpu
@@ -103,7 +105,7 @@ def test_deterministic_steps_bitwise_in_every_launch_geometry(gpu_lib, model, k,
 
     N, R, B = 1500, 7, 1024
     rng = np.random.default_rng(k + eta)
-    K = k if model == "DistMult" else 2 * k
+    K = k if model in ("DistMult", "TransE") else 2 * k
     ent = rng.uniform(-0.2, 0.2, size=(N, K)).astype(np.float32)
     rel = rng.uniform(-0.2, 0.2, size=(R, K)).astype(np.float32)
     X = np.stack([rng.integers(0, N, 2 * B), rng.integers(0, R, 2 * B), rng.integers(0, N, 2 * B)], 1).astype(np.int32)
@@ -119,6 +121,7 @@ def test_deterministic_steps_bitwise_in_every_launch_geometry(gpu_lib, model, k,
         loop.step(Xd[step * B:(step + 1) * B], step)
         xb = X[step * B:(step + 1) * B]
         ref += (TO.rotate_step_det(st, xb, eta, 6, step, loss, max_rel_size=R) if model == "RotatE"
+                else TO.transe_pairwise_step(st, xb, eta, 6, step, loss=loss, layout="quad") if model == "TransE"
                 else TO.trilinear_step_det(model, st, xb, eta, 6, step, loss))
     torch.cuda.synchronize()
     got = loop.mean_batch_loss() * 2
