@@ -94,9 +94,9 @@ def parse():
     if args.optimizer_mode is None:
         args.optimizer_mode = "dense"
     args.preset = args.config or ("C2" if all(getattr(args, k_) == v_ for k_, v_ in PRESETS["C2"].items()) else None)
-    if args.also is None:   # the driver's single command also reports C3
-        args.also = "C3" if (args.preset == "C2" and args.gpus == 1 and args.popularity == "uniform" and not args.deterministic
-                             and args.optimizer_mode == "dense") else "none"
+    if args.also is None:   # the driver's single command also reports C3 and C4 on one GPU (Missing #6)
+        args.also = "C3,C4" if (args.preset == "C2" and args.gpus == 1 and args.popularity == "uniform" and not args.deterministic
+                                and args.optimizer_mode == "dense") else "none"
     return args
 
 
@@ -110,6 +110,8 @@ def preset_args(base, name):
     a.config = a.preset = name
     a.optimizer_mode = PRESETS[name].get("optimizer_mode", "dense")
     a.also = "none"
+    if name == "C4" and base.preset != "C4":   # riding along in another config's line: its CPU legs (a 123 k-row dense Adam on the host) are left out
+        a.no_cpu_baseline = True
     return a
 
 
@@ -368,10 +370,16 @@ def main():
             if ctx.multi:
                 break
             torch.cuda.empty_cache()
-            e = run_config(preset_args(args, name), ctx)
+            t_extra = time.perf_counter()
+            try:   # an extra configuration must never cost the headline line
+                e = run_config(preset_args(args, name), ctx)
+            except Exception as exc:   # noqa: BLE001 -- reported in the line
+                extra[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                continue
             # the same fields, without repeating what does not change between configs
             extra[name] = {k_: e[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "dtype",
-                                                "config", "roofline", "eval", "cpu_baseline") if k_ in e}
+                                                "config", "roofline", "eval", "eval_trained_like", "cpu_baseline") if k_ in e}
+            extra[name]["wall_s"] = round(time.perf_counter() - t_extra, 1)
         if extra:
             out["extra_configs"] = extra
         print(json.dumps(out), flush=True)
