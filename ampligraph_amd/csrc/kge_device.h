@@ -276,7 +276,7 @@ __device__ __forceinline__ void grad_unit(const float (&s)[ModelTraits<MODEL>::N
                                           float (&dd)[ModelTraits<MODEL>::NC], float pad1 = 0.f) {
     if constexpr (MODEL == AMDKGE_TRANSE) {
         const float d = s[0] + p[0] - o[0];
-        const float sg = (d > 0.f) ? g : ((d < 0.f) ? -g : 0.f);  // g*sign(d), sign(0)=0 ; g carries the minus
+        const float sg = (d > 0.f) ? g : ((d < 0.f) ? -g : ((d == d) ? 0.f : d));  // g*sign(d), sign(0)=0, sign(NaN)=NaN (tf.sign) ; g carries the minus
         ds[0] = sg; dp[0] = sg; dd[0] = -sg;
     } else if constexpr (MODEL == AMDKGE_DISTMULT) {
         ds[0] = g * (p[0] * o[0]); dp[0] = g * (s[0] * o[0]); dd[0] = g * (s[0] * p[0]);

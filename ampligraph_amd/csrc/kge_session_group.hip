@@ -22,6 +22,7 @@
 #include <thread>
 #include <vector>
 
+#include "kge_group_staging.h"
 #include "kge_session_impl.h"
 
 using namespace kge;
@@ -107,6 +108,8 @@ struct amdkge_session_group {
     // ---- AMDKGE_GROUP_COLS: every table COLUMN-sharded over the replicas (see the COLS section below) ----
     bool cols = false;
     int k_full = 0;                 // units per half of the whole model; replica d holds units [d k_full / W, (d + 1) k_full / W)
+    bool poisoned = false;          // a column-sharded step failed after some slices had applied their update: the slices of ONE model
+                                    // have parted (see cols_train_step); every later step is refused until the whole entity table is written again (set_rows)
 };
 
 extern "C" void amdkge_session_group_destroy(amdkge_session_group* g) {
@@ -182,7 +185,7 @@ static int group_create(const amdkge_session_config* cfg, const int32_t* devices
 extern "C" int amdkge_session_group_create_ex(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
                                               amdkge_session_group** out) try {
     if (!cfg || !out || n_gpus < 1 || n_gpus > 16) return set_error(AMDKGE_EINVAL, "session_group_create: bad arguments (1 <= n_gpus <= 16)");
-    if (flags & ~AMDKGE_GROUP_FORCE_RCCL) return set_error(AMDKGE_EINVAL, "session_group_create_ex: unknown flag (row sharding: amdkge_session_group_create_rows)");
+    if (flags & ~(AMDKGE_GROUP_FORCE_RCCL | AMDKGE_GROUP_FORCE_THREADS)) return set_error(AMDKGE_EINVAL, "session_group_create_ex: unknown flag (row sharding: amdkge_session_group_create_rows)");
     *out = nullptr;
     return group_create(cfg, devices, n_gpus, flags, cfg->model.n_ents, out);
 } KGE_CATCH("session_group_create_ex")
@@ -376,7 +379,7 @@ int exchange(amdkge_session_group* g, FS send, FR recv, int64_t elems, int bytes
 extern "C" int amdkge_session_group_create_rows(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
                                                 int64_t max_batch, amdkge_session_group** out) try {
     if (!cfg || !out || n_gpus < 1 || n_gpus > 16) return set_error(AMDKGE_EINVAL, "session_group_create_rows: bad arguments (1 <= n_gpus <= 16)");
-    if (flags & ~(AMDKGE_GROUP_FORCE_RCCL | AMDKGE_GROUP_ROWS | AMDKGE_GROUP_GLOBAL_NEGATIVES)) return set_error(AMDKGE_EINVAL, "session_group_create_rows: unknown flag");
+    if (flags & ~(AMDKGE_GROUP_FORCE_RCCL | AMDKGE_GROUP_ROWS | AMDKGE_GROUP_GLOBAL_NEGATIVES | AMDKGE_GROUP_FORCE_THREADS)) return set_error(AMDKGE_EINVAL, "session_group_create_rows: unknown flag");
     if (max_batch < 1) return set_error(AMDKGE_EINVAL, "session_group_create_rows: max_batch must be >= 1");
     if (cfg->model.n_ents < n_gpus) return set_error(AMDKGE_EINVAL, "session_group_create_rows: fewer entities than replicas");
     if (cfg->flags & AMDKGE_TILED_DETERMINISTIC) return set_error(AMDKGE_EUNSUPPORTED, "session_group_create_rows: deterministic mode is not offered for row-sharded groups");
@@ -702,6 +705,39 @@ int group_isum(amdkge_session_group* g, FS src, FD dst, int64_t len) {
     return AMDKGE_OK;
 }
 
+// fn(d) for every replica d: ONE HOST THREAD PER REPLICA when the replicas sit on distinct devices (or AMDKGE_GROUP_FORCE_THREADS asks
+// for it on one device: what a one-GPU box can test) -- the calls fn makes (staging copies, launches, the 8-byte read-back of the
+// distance models' early-exit probe, stream synchronisation) then overlap across the devices instead of queueing behind one host
+// thread; sequential otherwise.  fn touches only replica d's session, stream and staging.  The first failing replica's code and
+// message are reported (error messages are thread-local).
+template <class F>
+int for_each_replica(amdkge_session_group* g, F&& fn) {
+    const int W = (int)g->rep.size();
+    if (W == 1 || (g->same_device && !(g->flags & AMDKGE_GROUP_FORCE_THREADS))) {
+        for (int d = 0; d < W; ++d) KGE_RC(fn(d));
+        return AMDKGE_OK;
+    }
+    std::vector<int> rcs((size_t)W, AMDKGE_OK);
+    std::vector<std::string> msgs((size_t)W);
+    std::vector<std::thread> th;
+    th.reserve((size_t)W);
+    for (int d = 0; d < W; ++d)
+        th.emplace_back([&, d]() {
+            try {
+                rcs[(size_t)d] = fn(d);
+            } catch (const std::bad_alloc&) {
+                rcs[(size_t)d] = set_error(AMDKGE_ENOMEM, "session_group: out of host memory in a replica's thread");
+            } catch (...) {
+                rcs[(size_t)d] = set_error(AMDKGE_EINVAL, "session_group: unexpected C++ exception in a replica's thread");
+            }
+            if (rcs[(size_t)d] != AMDKGE_OK) msgs[(size_t)d] = amdkge_last_error();   // (the message is thread-local)
+        });
+    for (std::thread& t : th) t.join();
+    for (int d = 0; d < W; ++d)
+        if (rcs[(size_t)d] != AMDKGE_OK) return set_error(rcs[(size_t)d], msgs[(size_t)d].c_str());
+    return AMDKGE_OK;
+}
+
 struct DevBuf {   // a per-call device allocation, freed on every path out
     void* p = nullptr; int dev = 0;
     ~DevBuf() { if (p) { (void)hipSetDevice(dev); (void)hipFree(p); } }
@@ -749,44 +785,37 @@ int rows_rank(amdkge_session_group* g, const int32_t* triples, int64_t n, const 
     }
     const bool two_cols = corrupt_side == AMDKGE_CORRUPT_S_O;
     const int ncols = (corrupt_side == AMDKGE_CORRUPT_S || corrupt_side == AMDKGE_CORRUPT_O) ? 1 : 2;
-    std::vector<int32_t> U, idx, hr;
-    std::vector<std::vector<int32_t>> xl((size_t)W);
+    // Host staging: everything a replica's copies read is PER REPLICA (xl, idxl) or read-only during the parallel phases (U, the CSR
+    // slices), and lives until the chunk's closing synchronisation -- no synchronisation inside a phase (round 5 shared one `idx` and
+    // synchronised every replica's stream before moving to the next: on distinct devices the shards' passes ran one after the other).
+    // Per chunk the replicas meet exactly at the two kinds of exchange: the bit-wise sum of the gathered query rows and, per side, the
+    // int32 sum of the counts (group_isum: one grouped ncclAllReduce, or the local kernel); everything else of a replica -- staging,
+    // gather, prep, probe read-back, count and filter passes -- runs in its own host thread (for_each_replica).
+    std::vector<int32_t> U, hr;
+    std::vector<std::vector<int32_t>> xl((size_t)W), idxl((size_t)W);
     std::vector<int64_t> offs, offo;
     for (int64_t q0 = 0; q0 < n; q0 += chunk) {
         const int64_t nq = (n - q0) < chunk ? (n - q0) : chunk;
         const int32_t* tq = triples + 3 * q0;
         // ---- the distinct entity rows of the chunk, their slots behind the shards ----
-        U.resize((size_t)(2 * nq));
-        for (int64_t i = 0; i < nq; ++i) { U[(size_t)(2 * i)] = tq[3 * i]; U[(size_t)(2 * i + 1)] = tq[3 * i + 2]; }
-        std::sort(U.begin(), U.end());
-        U.erase(std::unique(U.begin(), U.end()), U.end());
+        stage_distinct_rows(tq, nq, U);
         const int64_t nu = (int64_t)U.size();
-        auto slot_of = [&](int32_t id) { return (int64_t)(std::lower_bound(U.begin(), U.end(), id) - U.begin()); };
         std::vector<const int32_t*> d_tri((size_t)W, nullptr);
-        for (int d = 0; d < W; ++d) {
+        KGE_RC(for_each_replica(g, [&](int d) -> int {
             amdkge_session* s = g->rep[d];
             Shard& h = g->sh[(size_t)d];
             KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
             std::vector<int32_t>& x = xl[(size_t)d];
-            x.resize((size_t)(3 * nq));
-            for (int64_t i = 0; i < nq; ++i) {
-                x[(size_t)(3 * i)] = (int32_t)(h.n_local + slot_of(tq[3 * i]));
-                x[(size_t)(3 * i + 1)] = tq[3 * i + 1];
-                x[(size_t)(3 * i + 2)] = (int32_t)(h.n_local + slot_of(tq[3 * i + 2]));
-            }
+            std::vector<int32_t>& idx = idxl[(size_t)d];
+            stage_replica(tq, nq, U, h.lo, h.n_local, x, idx);   // (kge_group_staging.h: CPU-tested)
             void* dt = nullptr;
             KGE_RC(amdkge_session_scratch(s, 0, nq * 12, &dt));
             KGE_HIP(hipMemcpyAsync(dt, x.data(), (size_t)nq * 12, hipMemcpyHostToDevice, s->st), "hipMemcpyAsync(H2D)");
             d_tri[(size_t)d] = (const int32_t*)dt;
-            idx.resize((size_t)nu);
-            for (int64_t j = 0; j < nu; ++j) {
-                const int64_t v = (int64_t)U[(size_t)j] - h.lo;
-                idx[(size_t)j] = (v >= 0 && v < h.n_local) ? (int32_t)v : -1;
-            }
             KGE_HIP(hipMemcpyAsync(h.recv, idx.data(), (size_t)nu * 4, hipMemcpyHostToDevice, s->st), "hipMemcpyAsync(H2D)");
-            KGE_HIP(hipStreamSynchronize(s->st), "hipStreamSynchronize");   // `idx` is rewritten for the next replica
             KGE_RC(amdkge_gather_rows(s->tab[AMDKGE_TABLE_ENT], Ks, h.recv, nu, h.rows_out, s->st));
-        }
+            return AMDKGE_OK;
+        }));
         KGE_RC(group_isum(g, [&](int d) { return (const int32_t*)g->sh[(size_t)d].rows_out; },
                           [&](int d) { return (int32_t*)(g->rep[d]->tab[AMDKGE_TABLE_ENT] + g->sh[(size_t)d].n_local * (int64_t)Ks); }, nu * (int64_t)Ks));
         // ---- every wanted side: per-shard counts, summed over the replicas, composed on replica 0 ----
@@ -800,12 +829,9 @@ int rows_rank(amdkge_session_group* g, const int32_t* triples, int64_t n, const 
             const int64_t* off = (side == AMDKGE_SIDE_S) ? fs_off : fo_off;
             const int32_t* ids = (side == AMDKGE_SIDE_S) ? fs_ids : fo_ids;
             std::vector<int64_t>& lo = (side == AMDKGE_SIDE_S) ? offs : offo;
-            if (off) {   // the chunk's slice of the CSR, zero-based
-                lo.resize((size_t)(nq + 1));
-                for (int64_t i = 0; i <= nq; ++i) lo[(size_t)i] = off[q0 + i] - off[q0];
-            }
+            if (off) stage_csr_slice(off, q0, nq, lo);   // the chunk's slice of the CSR, zero-based
             std::vector<int32_t*> c3((size_t)W, nullptr);
-            for (int d = 0; d < W; ++d) {
+            KGE_RC(for_each_replica(g, [&](int d) -> int {
                 amdkge_session* s = g->rep[d];
                 Shard& h = g->sh[(size_t)d];
                 KGE_HIP(hipSetDevice(s->cfg.device), "hipSetDevice");
@@ -817,13 +843,15 @@ int rows_rank(amdkge_session_group* g, const int32_t* triples, int64_t n, const 
                     KGE_RC(amdkge_session_scratch(s, 2, nq * 3 * (int64_t)sizeof(int32_t), &z));
                     KGE_HIP(hipMemsetAsync(z, 0, (size_t)nq * 3 * sizeof(int32_t), s->st), "hipMemsetAsync");
                     c3[(size_t)d] = (int32_t*)z;
-                    continue;
+                    return AMDKGE_OK;
                 }
                 const int32_t* e_ids = n_subset > 0 ? (const int32_t*)sel[(size_t)d].p : nullptr;
                 const int32_t* e_pos = n_subset > 0 ? (const int32_t*)sel[(size_t)d].p + nsel[(size_t)d] : nullptr;
                 KGE_RC(amdkge_session_count_side(s, &m, d_tri[(size_t)d], nq, side, off ? lo.data() : nullptr, off ? ids + off[q0] : nullptr, h.lo, h.n_local,
                                                  e_ids, e_pos, 0, ncand, &c3[(size_t)d]));
-            }
+                return AMDKGE_OK;
+            }));
+            KGE_HIP(hipSetDevice(g->rep[0]->cfg.device), "hipSetDevice");
             KGE_RC(group_isum(g, [&](int d) { return (const int32_t*)c3[(size_t)d]; }, [&](int d) { return c3[(size_t)d]; }, nq * 3));
             KGE_HIP(hipSetDevice(g->rep[0]->cfg.device), "hipSetDevice");
             KGE_RC(amdkge_rank_compose(c3[0], off ? c3[0] + 2 * nq : nullptr, nq, strategy, (int32_t*)d_ranks + (two_cols ? col : col * nq), two_cols ? 2 : 1, g->rep[0]->st));
@@ -865,22 +893,7 @@ extern "C" int amdkge_session_group_rank(amdkge_session_group* g, const int32_t*
         return amdkge_session_rank(g->rep[(size_t)d], triples + 3 * lo, hi - lo, fs_off ? fs_off + lo : nullptr, fs_ids, fo_off ? fo_off + lo : nullptr, fo_ids,
                                    ent_subset, n_subset, corrupt_side, strategy, ranks_out + lo * ncols);
     };
-    if (W == 1 || g->same_device) {
-        for (int d = 0; d < W; ++d) KGE_RC(share(d));
-        return AMDKGE_OK;
-    }
-    std::vector<int> rcs((size_t)W, AMDKGE_OK);
-    std::vector<std::string> msgs((size_t)W);
-    std::vector<std::thread> th;
-    for (int d = 0; d < W; ++d)
-        th.emplace_back([&, d]() {
-            rcs[(size_t)d] = share(d);
-            if (rcs[(size_t)d] != AMDKGE_OK) msgs[(size_t)d] = amdkge_last_error();   // (the message is thread-local)
-        });
-    for (std::thread& t : th) t.join();
-    for (int d = 0; d < W; ++d)
-        if (rcs[(size_t)d] != AMDKGE_OK) return set_error(rcs[(size_t)d], msgs[(size_t)d].c_str());
-    return AMDKGE_OK;
+    return for_each_replica(g, share);   // (one host thread per device)
 } KGE_CATCH("session_group_rank")
 
 
@@ -945,6 +958,9 @@ static int cols_set_rows(amdkge_session_group* g, int32_t table, int64_t row0, i
         col_slice(host, nrows, model, g->k_full, W, d, tmp.data());
         KGE_RC(amdkge_session_set_rows(g->rep[d], table, row0, nrows, tmp.data()));   // (validates table / rows; synchronises)
     }
+    // a poisoned group (cols_train_step) is usable again once the whole entity table has been written: the caller reloading a
+    // checkpoint writes every table, and this is the one it cannot leave out
+    if (table == 0 && row0 == 0 && nrows == g->N) g->poisoned = false;
     return AMDKGE_OK;
 }
 
@@ -958,7 +974,34 @@ static int cols_get_rows(amdkge_session_group* g, int32_t table, const int32_t* 
     return AMDKGE_OK;
 }
 
+static int cols_train_step_body(amdkge_session_group* g, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out, int* applied);
+
+//  A column-sharded step that fails part-way.  Before any slice has applied its update (phase A, the exchange) nothing of the
+// model has moved: gradients are cleared, workspaces dropped (their bookkeeping may be dirty) and the step can be retried.  Once SOME
+// slices have run their optimizer (phase B + C is one fused launch sequence per slice) the columns of one model are at different steps,
+// and the step / iteration counters -- bumped by finish_step only -- would let a retried step update the applied slices twice with the same
+// Philox draws: there is nothing to roll back to, so the group is POISONED: train_step refuses until the tables have been written
+// again through amdkge_session_group_set_rows (a checkpoint: the whole entity table clears the state), or the group is rebuilt.  The failed call's message is kept.
 static int cols_train_step(amdkge_session_group* g, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out) {
+    if (g->poisoned)
+        return set_error(AMDKGE_EINVAL, "session_group_train_step: an earlier column-sharded step failed after some slices had been updated; "
+                                        "reload the tables (amdkge_session_group_set_rows) or rebuild the group");
+    int applied = 0;
+    const int rc = cols_train_step_body(g, triples, B, focus_w, loss_out, &applied);
+    if (rc == AMDKGE_OK) return rc;
+    for (amdkge_session* s : g->rep) {
+        (void)hipSetDevice(s->cfg.device);
+        (void)hipStreamSynchronize(s->st);
+        (void)hipMemsetAsync(s->g_ent, 0, (size_t)s->cfg.model.n_ents * s->Ks * sizeof(float), s->st);
+        (void)hipMemsetAsync(s->g_rel, 0, (size_t)s->cfg.model.n_rels * s->Ks * sizeof(float), s->st);
+        if (s->twork) { (void)hipFree(s->twork); s->twork = nullptr; s->twork_bytes = 0; }
+        (void)hipStreamSynchronize(s->st);
+    }
+    if (applied > 0) g->poisoned = true;
+    return rc;
+}
+
+static int cols_train_step_body(amdkge_session_group* g, const int32_t* triples, int64_t B, const float* focus_w, double* loss_out, int* applied) {
     const int W = (int)g->rep.size();
     if (loss_out) *loss_out = 0.0;
     if (B == 0) return AMDKGE_OK;
@@ -970,7 +1013,10 @@ static int cols_train_step(amdkge_session_group* g, const int32_t* triples, int6
     // ---- the one exchange of the step: the partial sums meet (ncclAllReduce over xGMI / the local kernel) ----
     KGE_RC(group_sum(g, [](amdkge_session* s) { return (float*)s->buf[2]; }, B * (int64_t)(1 + g->rep[0]->cfg.eta)));
     // ---- B + C: loss on the complete scores (the same values on every replica), backward / merge / optimizer on the slice ----
-    for (int d = 0; d < W; ++d) KGE_RC(amdkge_session_cols_apply(g->rep[d], B));
+    for (int d = 0; d < W; ++d) {
+        *applied = d + 1;   // (a slice whose apply fails may have launched part of its sequence: it counts)
+        KGE_RC(amdkge_session_cols_apply(g->rep[d], B));
+    }
     double data = 0.0, reg = 0.0;
     for (int d = 0; d < W; ++d) {
         double h[2];

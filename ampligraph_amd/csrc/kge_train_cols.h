@@ -150,9 +150,9 @@ __global__ __launch_bounds__(256) void cols_loss_kernel(float* __restrict__ scor
                 for (int j = 0; j < eta; ++j) {
                     const float h = L.margin - P + sgn_scale * nj[(int64_t)j * B];
                     const bool act = h >= 0.f;
-                    acc += fmaxf(h, 0.f);
+                    acc += hinge_nan(h);
                     cnt += act ? 1.f : 0.f;
-                    nj[(int64_t)j * B] = act ? 1.f / red : 0.f;
+                    nj[(int64_t)j * B] = act ? 1.f / red : masked_zero(h);
                 }
                 per = acc / red;
                 dP = -cnt / red;
@@ -160,14 +160,14 @@ __global__ __launch_bounds__(256) void cols_loss_kernel(float* __restrict__ scor
             case AMDKGE_LOSS_NLL: {
                 if (L.reduction_mean) red = 2.f * feta;
                 const bool inP = (P >= -75.f) && (P <= 75.f);
-                const float Pc = fminf(fmaxf(P, -75.f), 75.f);
+                const float Pc = clip_exp(P);
                 float acc = 0.f;
                 for (int j = 0; j < eta; ++j) {
                     const float n = sgn_scale * nj[(int64_t)j * B];
                     const bool in = (n >= -75.f) && (n <= 75.f);
-                    const float nc = fminf(fmaxf(n, -75.f), 75.f);
+                    const float nc = clip_exp(n);
                     acc += logf(1.f + expf(nc));
-                    nj[(int64_t)j * B] = in ? sigmoidf(nc) / red : 0.f;
+                    nj[(int64_t)j * B] = in ? sigmoidf(nc) / red : masked_zero(n);
                 }
                 per = (feta * logf(1.f + expf(-Pc)) + acc) / red;
                 dP = inP ? -feta * sigmoidf(-Pc) / red : 0.f;
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void cols_loss_kernel(float* __restrict__ scor
                 float acc = 0.f;
                 for (int j = 0; j < eta; ++j) {
                     const float h = L.margin + sgn_scale * nj[(int64_t)j * B];
-                    acc += fmaxf(h, 0.f);
-                    nj[(int64_t)j * B] = (h >= 0.f) ? 1.f / red : 0.f;
+                    acc += hinge_nan(h);
+                    nj[(int64_t)j * B] = (h >= 0.f) ? 1.f / red : masked_zero(h);
                 }
                 per = (acc - feta * P) / red;
                 dP = -feta / red;
@@ -203,14 +203,14 @@ __global__ __launch_bounds__(256) void cols_loss_kernel(float* __restrict__ scor
             } break;
             default: {   // AMDKGE_LOSS_MULTICLASS_NLL
                 const bool inP = (P >= -75.f) && (P <= 75.f);
-                const float eP = expf(fminf(fmaxf(P, -75.f), 75.f));
+                const float eP = expf(clip_exp(P));
                 float acc = 0.f;
-                for (int j = 0; j < eta; ++j) acc += expf(fminf(fmaxf(sgn_scale * nj[(int64_t)j * B], -75.f), 75.f));
+                for (int j = 0; j < eta; ++j) acc += expf(clip_exp(sgn_scale * nj[(int64_t)j * B]));
                 const float Z = acc / red + eP;
                 for (int j = 0; j < eta; ++j) {
                     const float n = sgn_scale * nj[(int64_t)j * B];
                     const bool in = (n >= -75.f) && (n <= 75.f);
-                    nj[(int64_t)j * B] = in ? expf(fminf(fmaxf(n, -75.f), 75.f)) / Z / red : 0.f;
+                    nj[(int64_t)j * B] = in ? expf(clip_exp(n)) / Z / red : masked_zero(n);
                 }
                 per = -logf(eP / Z);
                 dP = inP ? -1.f + eP / Z : 0.f;
@@ -332,10 +332,10 @@ __global__ __launch_bounds__(256) void cols_stage_kernel(ColsArgs ca) {
     if (active)
         for (int j = gl; j < eta + 2; j += G) {
             uint32_t dest, role;
-            float g;
-            if (j < eta) { dest = (uint32_t)sh_repl[j]; role = sh_keep[j] ? 0u : 1u; g = cneg[(int64_t)j * a.B + i] * sgn_scale; }
+            float g, coeff = 1.f;
+            if (j < eta) { dest = (uint32_t)sh_repl[j]; role = sh_keep[j] ? 0u : 1u; coeff = cneg[(int64_t)j * a.B + i]; g = coeff * sgn_scale; }
             else { dest = (uint32_t)(j == eta ? ps : po); role = (j == eta) ? 2u : 3u; g = 1.f; }
-            if (fabsf(g) < 1.17549435e-38f) continue;   // (no entry below the smallest normal number: see the forward kernel)
+            if (!entry_wanted(coeff, g)) continue;   // (no entry below the smallest normal number, masked zeros of non-finite scores kept: see the forward kernel)
             uint32_t tile, local;
             tile_of_row(dest, (uint32_t)a.st_n_tiles, (uint32_t)a.st_rb, tile, local);
             StageEntry en{(uint32_t)i, role | (local << 2), g, dest};

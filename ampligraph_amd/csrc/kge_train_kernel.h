@@ -125,6 +125,31 @@ __device__ __forceinline__ float sigmoidf(float x) {
     return 1.f / (1.f + expf(-x));
 }
 
+// clip_before_exp (loss_functions.py:60-66) = tf.clip_by_value = maximum(minimum(x, 75), -75) built from TensorFlow's NaN-PROPAGATING
+// minimum / maximum: a NaN score stays NaN in the loss VALUE.  C's fminf / fmaxf return the other operand instead, which made a NaN
+// positive cost a finite eta * log(1 + e^75) = 375 eta.  The GRADIENT through the clip is the exact zero of the
+// minimum / maximum masks (less_equal / greater_equal are false for NaN) -- what the `in` range tests beside every clip give.
+__device__ __forceinline__ float clip_exp(float x) {
+    return (x != x) ? x : fminf(fmaxf(x, -75.f), 75.f);
+}
+// tf.maximum(h, 0) of the two margin losses (:302-308, :458-464): NaN in the value, zero gradient (greater_equal(NaN, 0) is false)
+__device__ __forceinline__ float hinge_nan(float h) {
+    return (h != h) ? h : fmaxf(h, 0.f);
+}
+// A coefficient dL/dscore that a clip or hinge MASK sets to zero.  "Zero coefficient -> no bucket entry for the replaced row" (below,
+// STAGE) is valid only while the score's Jacobian is finite: TensorFlow multiplies the exact zero by it, so a positive whose own rows
+// hold a NaN hands 0 * NaN = NaN to the replacement rows of its corruptions.  The masked coefficient of a NON-FINITE score (x: the score,
+// or the hinge argument it enters) is therefore written as -0.0f: the entry test keeps it (entry_wanted), the tile pass adds (-0) * A --
+// NaN exactly where the side row is NaN, nothing elsewhere.  No loss produces -0.0f as a live coefficient.
+__device__ __forceinline__ float masked_zero(float x) {
+    return (fabsf(x) < INFINITY) ? 0.f : -0.f;
+}
+// coeff: dL/dscore as the loss code left it; g = coeff * score_sign * score_scale.  No entry below fp32's smallest NORMAL number
+// (see the forward kernel) unless the coefficient is masked_zero's marker; a NaN coefficient is an entry.
+__device__ __forceinline__ bool entry_wanted(float coeff, float g) {
+    return !(fabsf(g) < 1.17549435e-38f) || __float_as_uint(coeff) == 0x80000000u;
+}
+
 // FocusE (ScoringBasedEmbeddingModel.py:396-406,492-513): y = f(x) * wgt, dfac = f'(x) * wgt.  The reference's
 // "softplus" is log(1 + 9999 e^x) with the custom gradient 1 - 1/(1 + 9999 e^x) (:499-510).
 __device__ __forceinline__ void focus_apply(int nl, float x, float wgt, float& y, float& dfac) {
@@ -151,9 +176,9 @@ __device__ __forceinline__ void loss_and_dscore(const amdkge_loss& L, float P, f
             for (int j = lane; j < eta; j += KGE_WAVE) {
                 const float h = L.margin - P + sn[j];
                 const bool act = h >= 0.f;
-                acc += fmaxf(h, 0.f);
+                acc += hinge_nan(h);
                 cnt += act ? 1.f : 0.f;
-                sn[j] = act ? 1.f / red : 0.f;
+                sn[j] = act ? 1.f / red : masked_zero(h);
             }
             per = wave_sum(acc) / red;
             dP = -wave_sum(cnt) / red;
@@ -161,14 +186,14 @@ __device__ __forceinline__ void loss_and_dscore(const amdkge_loss& L, float P, f
         case AMDKGE_LOSS_NLL: {  // :376-382 (clip at :60-66)
             if (L.reduction_mean) red = 2.f * feta;
             const bool inP = (P >= -75.f) && (P <= 75.f);
-            const float Pc = fminf(fmaxf(P, -75.f), 75.f);
+            const float Pc = clip_exp(P);
             float acc = 0.f;
             for (int j = lane; j < eta; j += KGE_WAVE) {
                 const float n = sn[j];
                 const bool in = (n >= -75.f) && (n <= 75.f);
-                const float nc = fminf(fmaxf(n, -75.f), 75.f);
+                const float nc = clip_exp(n);
                 acc += logf(1.f + expf(nc));
-                sn[j] = in ? sigmoidf(nc) / red : 0.f;
+                sn[j] = in ? sigmoidf(nc) / red : masked_zero(n);
             }
             per = (feta * logf(1.f + expf(-Pc)) + wave_sum(acc)) / red;
             dP = inP ? -feta * sigmoidf(-Pc) / red : 0.f;
@@ -177,8 +202,8 @@ __device__ __forceinline__ void loss_and_dscore(const amdkge_loss& L, float P, f
             float acc = 0.f;
             for (int j = lane; j < eta; j += KGE_WAVE) {
                 const float h = L.margin + sn[j];
-                acc += fmaxf(h, 0.f);
-                sn[j] = (h >= 0.f) ? 1.f / red : 0.f;
+                acc += hinge_nan(h);
+                sn[j] = (h >= 0.f) ? 1.f / red : masked_zero(h);
             }
             per = (wave_sum(acc) - feta * P) / red;
             dP = -feta / red;
@@ -207,14 +232,14 @@ __device__ __forceinline__ void loss_and_dscore(const amdkge_loss& L, float P, f
         } break;
         default: {  // AMDKGE_LOSS_MULTICLASS_NLL :647-654
             const bool inP = (P >= -75.f) && (P <= 75.f);
-            const float eP = expf(fminf(fmaxf(P, -75.f), 75.f));
+            const float eP = expf(clip_exp(P));
             float acc = 0.f;
-            for (int j = lane; j < eta; j += KGE_WAVE) acc += expf(fminf(fmaxf(sn[j], -75.f), 75.f));
+            for (int j = lane; j < eta; j += KGE_WAVE) acc += expf(clip_exp(sn[j]));
             const float Z = wave_sum(acc) / red + eP;
             for (int j = lane; j < eta; j += KGE_WAVE) {
                 const float n = sn[j];
                 const bool in = (n >= -75.f) && (n <= 75.f);
-                sn[j] = in ? expf(fminf(fmaxf(n, -75.f), 75.f)) / Z / red : 0.f;
+                sn[j] = in ? expf(clip_exp(n)) / Z / red : masked_zero(n);
             }
             per = -logf(eP / Z);
             dP = inP ? -1.f + eP / Z : 0.f;
@@ -266,7 +291,7 @@ __device__ __forceinline__ void fast_sig_logsig(float y, float& sig, float& logs
 __device__ __forceinline__ float det_exp(float x) {
     // e^x for |x| <= 80 (clamped): n = rint(x log2 e); r = (x - n ln2_hi) - n ln2_lo (Cody-Waite: ln2_hi = 355/512 has 9 bits, so
     // n ln2_hi is exact for |n| < 2^15); e^r by its Taylor polynomial of degree 7 in Horner form; scaled by 2^n exactly
-    x = fminf(fmaxf(x, -80.f), 80.f);
+    x = (x != x) ? x : fminf(fmaxf(x, -80.f), 80.f);   // (NaN stays NaN, as np.clip keeps it in oracle/train_ordered.py)
     const float n = rintf(x * 1.4426950216293335f);
     const float r = (x - n * 0.693359375f) - n * -2.12194440e-4f;
     float p = 1.f / 5040.f;
@@ -320,7 +345,7 @@ __device__ __forceinline__ float onepass_coeff(const amdkge_loss& L, float P, fl
         case AMDKGE_LOSS_NLL: {
             const bool in = valid && (n >= -75.f) && (n <= 75.f);
             float sg, lsn;
-            sig_logsig(det, fminf(fmaxf(n, -75.f), 75.f), sg, lsn);
+            sig_logsig(det, clip_exp(n), sg, lsn);
             st.Lw += valid ? -lsn : 0.f;   // softplus(clip n) = log(1 + exp(clip n))
             c1 = in ? sg : 0.f;
         } break;
@@ -341,7 +366,7 @@ __device__ __forceinline__ float onepass_coeff(const amdkge_loss& L, float P, fl
         } break;
         default: {
             const bool in = valid && (n >= -75.f) && (n <= 75.f);
-            const float ex = valid ? exp_any(det, fminf(fmaxf(n, -75.f), 75.f)) : 0.f;
+            const float ex = valid ? exp_any(det, clip_exp(n)) : 0.f;
             st.Zs += ex;
             c1 = in ? ex : 0.f;
         } break;
@@ -358,7 +383,7 @@ __device__ __forceinline__ void onepass_kappa(const amdkge_loss& L, float P, int
         case AMDKGE_LOSS_NLL: if (L.reduction_mean) red = 2.f * feta; k1 = 1.f / red; break;
         case AMDKGE_LOSS_SELF_ADVERSARIAL: k1 = 1.f / (st.S * red); k2 = L.alpha * (st.Lw / st.S) / (st.S * red); break;
         case AMDKGE_LOSS_MULTICLASS_NLL: {
-            const float eP = exp_any(det, fminf(fmaxf(P, -75.f), 75.f));
+            const float eP = exp_any(det, clip_exp(P));
             k1 = 1.f / ((st.Zs / red + eP) * red);
         } break;
         default: k1 = 1.f / red; break;
@@ -376,12 +401,12 @@ __device__ __forceinline__ void onepass_finish(const amdkge_loss& L, float P, fl
             if (L.reduction_mean) red = 2.f * feta;
             const bool inP = (P >= -75.f) && (P <= 75.f);
             float sgP, lsP;
-            sig_logsig(det, -fminf(fmaxf(P, -75.f), 75.f), sgP, lsP);   // sigma(-Pc), log sigma(Pc)
+            sig_logsig(det, -clip_exp(P), sgP, lsP);   // sigma(-Pc), log sigma(Pc)
             for (int j = lane; j < eta; j += KGE_WAVE) {
                 const float n = sn[j];
                 float sg, ls;
-                sig_logsig(det, fminf(fmaxf(n, -75.f), 75.f), sg, ls);
-                sn[j] = ((n >= -75.f) && (n <= 75.f)) ? sg / red : 0.f;
+                sig_logsig(det, clip_exp(n), sg, ls);
+                sn[j] = ((n >= -75.f) && (n <= 75.f)) ? sg / red : masked_zero(n);
             }
             per = (feta * -lsP + st.Lw) / red;   // log(1+exp(-Pc)) = -log sigma(Pc)
             dP = inP ? -feta * sgP / red : 0.f;
@@ -402,12 +427,12 @@ __device__ __forceinline__ void onepass_finish(const amdkge_loss& L, float P, fl
         } break;
         default: {   // AMDKGE_LOSS_MULTICLASS_NLL :647-654
             const bool inP = (P >= -75.f) && (P <= 75.f);
-            const float Pc = fminf(fmaxf(P, -75.f), 75.f);
+            const float Pc = clip_exp(P);
             const float eP = exp_any(det, Pc);
             const float Z = st.Zs / red + eP;
             for (int j = lane; j < eta; j += KGE_WAVE) {
                 const float n = sn[j];
-                sn[j] = ((n >= -75.f) && (n <= 75.f)) ? exp_any(det, fminf(fmaxf(n, -75.f), 75.f)) / Z / red : 0.f;
+                sn[j] = ((n >= -75.f) && (n <= 75.f)) ? exp_any(det, clip_exp(n)) / Z / red : masked_zero(n);
             }
             per = (det ? logf(Z) : __builtin_amdgcn_logf(Z) * 0.6931471805599453f) - Pc;   // -log(eP / Z)  (the loss VALUE only: nothing feeds back)
             dP = inP ? -1.f + eP / Z : 0.f;
@@ -816,6 +841,9 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                     // the PF row sums in one transposing reduction (same additions as wave_sum: kge_device.h)
                     nv = sgn_scale * wave_sum_multi<PF>(accv, msel);
                 }
+                // TransE: a NaN unit of d makes its row's score NaN (a sum of |d|), and c * sign(NaN) must be NaN as tf.sign gives it:
+                // such a group takes the select form too, which hands a NaN d through
+                if constexpr (MODEL == AMDKGE_TRANSE) zero_m |= __ballot(nv != nv);
                 if constexpr (W > 1) {
                     __syncthreads();   // (the other buffer is free again: every wave passed the previous group's barrier after reading it)
                     if (lane < PF) {
@@ -870,7 +898,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
                                 for (int u = 0; u < VEC; ++u) {
                                     const float dj = e[f][c][u][0];
-                                    const float sg = (dj > 0.f) ? 1.f : ((dj < 0.f) ? -1.f : 0.f);
+                                    const float sg = (dj > 0.f) ? 1.f : ((dj < 0.f) ? -1.f : dj);   // (+-0 or NaN)
                                     av1[d][c][u][0] += c1 * sg;
                                     if (two) av2[d][c][u][0] += c2 * sg;
                                 }
@@ -939,7 +967,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
                         const float d = keepv[f] ? (s[c][u][0] + p[c][u][0] - e[f][c][u][0]) : (e[f][c][u][0] + p[c][u][0] - o[c][u][0]);
                         dv[u] = d;
                         acc += fabsf(d);
-                        code |= ((d > 0.f) ? 1u : ((d < 0.f) ? 2u : 0u)) << (2 * u);
+                        code |= ((d > 0.f) ? 1u : ((d < 0.f) ? 2u : ((d == d) ? 0u : 3u))) << (2 * u);   // 3: NaN
                     }
                     if (j >= 0) sh_sign[((size_t)j * CH + c) * 256 + tid] = (unsigned char)code;
                     if constexpr (STAGE && VEC == 4) {   // the tile pass's copy of the signs (see ENTRY_J_SHIFT)
@@ -1021,16 +1049,17 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
         if (active && !KGE_DBG(a, 32))
             for (int j = ts; j < eta + (a.pos_atomic ? 0 : 2); j += TS) {
                 uint32_t dest, role;
-                float g;
+                float g, coeff = 1.f;
                 if (j < eta) {
-                    dest = (uint32_t)sh_repl[j]; role = sh_keep[j] ? 0u : 1u; g = sh_neg[j] * sgn_scale;
+                    dest = (uint32_t)sh_repl[j]; role = sh_keep[j] ? 0u : 1u; coeff = sh_neg[j]; g = coeff * sgn_scale;
                     if (a.sign_codes) role |= (uint32_t)j << ENTRY_J_SHIFT;   // (bits above the local row)
                 }
                 else { dest = (uint32_t)(j == eta ? ps : po); role = (j == eta) ? 2u : 3u; g = 1.f; }
                 // inactive margin / clipped corruption / a coefficient that underflows fp32: no entry.  The threshold is the smallest
                 // NORMAL number, not zero: what the hardware transcendentals leave in the denormal range depends on the instruction
-                // sequence, and touched-rows mode (amdkge_opt.lazy) defines "touched" through this line (oracle touched_rows)
-                if (fabsf(g) < 1.17549435e-38f) continue;
+                // sequence, and touched-rows mode (amdkge_opt.lazy) defines "touched" through this line (oracle touched_rows).
+                // Kept: NaN coefficients and the masked zeros of non-finite scores (masked_zero above).
+                if (!entry_wanted(coeff, g)) continue;
                 if (j >= eta && a.hot_map && a.hot_map[dest]) continue;   // hot row: went to its replicas (below), no entry
                 uint32_t tile, local;
                 tile_of_row(dest, (uint32_t)a.st_n_tiles, (uint32_t)a.st_rb, tile, local);   // block-interleaved ownership, see tile_backward_kernel
@@ -1155,7 +1184,7 @@ __global__ __launch_bounds__(256) void train_fwdbwd_kernel(TrainArgs a) {
 #pragma unroll
                 for (int u = 0; u < VEC; ++u) {
                     const unsigned b = (code >> (2 * u)) & 3u;
-                    const float sg = (b == 1u) ? g : ((b == 2u) ? -g : 0.f);   // g * sign(d)
+                    const float sg = (b == 1u) ? g : ((b == 2u) ? -g : ((b == 3u) ? __builtin_nanf("") : 0.f));   // g * sign(d); sign(NaN) = NaN
                     if (keep) { gs[c][u][0] += sg; gp[c][u][0] += sg; gr[c][u][0] = -sg; }
                     else { go[c][u][0] += -sg; gp[c][u][0] += sg; gr[c][u][0] = sg; }
                 }

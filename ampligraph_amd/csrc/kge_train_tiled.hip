@@ -378,11 +378,17 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
             __shared__ int s_qovf;
             if (tid == 0) s_qovf = 0;
             __syncthreads();
-            const int QC = min(256, a.sort_cap / 8);   // indices per wave: the 4 sort_cap bytes behind the entries, dealt to 16 waves
-            uint16_t* qix = reinterpret_cast<uint16_t*>(sbuf + a.sort_cap) + (size_t)wv * (a.sort_cap / 8);
+            // indices per wave: the 4 sort_cap bytes behind the entries, dealt to 16 waves (stride sort_cap / 8 uint16).  The bitonic
+            // network below pads a queue to a power of two >= 64, so the queue's capacity is the largest power of two inside the
+            // stride (sort_cap is a multiple of 64, not a power of two: with QC = the stride itself a wave holding 129 .. 208 of
+            // 208 slots padded into its neighbour's queue); a stride below 64 cannot hold a network at all: fall-back.
+            const int qstride = a.sort_cap / 8;
+            int QC = 64;
+            while (QC * 2 <= min(256, qstride)) QC *= 2;
+            uint16_t* qix = reinterpret_cast<uint16_t*>(sbuf + a.sort_cap) + (size_t)wv * qstride;
             int qn = 0;
-            bool over = false;
-            for (int base = 0; base < total; base += 64) {
+            bool over = qstride < 64;
+            for (int base = 0; base < total && !over; base += 64) {
                 const bool in = base + lane < total;
                 const uint32_t meta = in ? sbuf[base + lane].y : 0u;
                 const bool mineq = in && (int)(entry_local(meta) % G) == grp;
@@ -633,12 +639,15 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_backward_kernel(TileArgs a)
                 for (int u = 0; u < FAST_U; ++u) {
                     if (i0 + u < qf) {
                         // a unit of the model whose byte shows |d| < 2^-125 (a zero byte once the sign bit is masked; padding
-                        // units are made non-zero): sign(0) = 0 must hold exactly -> the entry is redone in the three-row form
+                        // units are made non-zero): sign(0) = 0 must hold exactly -> the entry is redone in the three-row form.
+                        // So is one whose byte shows an all-ones exponent top (0x7f: |d| >= 2^127, inf or NaN): sign(NaN) must be NaN,
+                        // which grad_unit gives and a sign bit cannot (round 6).
                         bool tiny = false;
 #pragma unroll
                         for (int c = 0; c < CH; ++c) {
                             const uint32_t t = (cw[u][c] & 0x7f7f7f7fu) | padfill[c];
-                            tiny |= qok[c] && (((t - 0x01010101u) & ~t & 0x80808080u) != 0u);
+                            const uint32_t t7 = t ^ 0x7f7f7f7fu;
+                            tiny |= qok[c] && ((((t - 0x01010101u) & ~t) | ((t7 - 0x01010101u) & ~t7)) & 0x80808080u) != 0u;
                         }
                         if (__ballot(tiny)) {   // rare: noted, redone behind the batch (keeps the three-row code out of this unrolled loop)
                             redo |= 1u << u;
@@ -974,6 +983,9 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
         // bucket capacity: twice the mean + slack (Poisson tail; anything beyond goes to the overflow list)
         const int64_t mean = (entries + p.n_tiles - 1) / p.n_tiles;
         p.cap = (int)(2 * mean + (mean >= 224 ? 256 : 32 + mean));
+        // development aid (scripts/nan_hunt.py): a tiny bucket capacity sends most entries through the shared overflow list
+        static const int dbg_cap = [] { const char* e = getenv("AMDKGE_DEBUG_BUCKET_CAP"); return e ? atoi(e) : 0; }();
+        if (dbg_cap > 0 && p.cap > dbg_cap) p.cap = dbg_cap;
         if (!det) break;
         // the sort buffer holds a whole bucket + slack for overflow entries.  (Rounds 2 - 4 sorted the bucket with a bitonic network
         // and needed a POWER OF TWO here: 4 096 entries = 64 KB for C2's buckets of 2 330, which did not fit beside 57-row tiles --

@@ -592,9 +592,9 @@ class KgeEngine:
         per_lane = 2 * int(self.lib.amdkge_rank_workspace_bytes(C.byref(self.model), n)) + \
             min(max(int(self.lib.amdkge_rank_screen_workspace_bytes(C.byref(self.model), n, m)), 0), self.SCREEN_MAX_BYTES)
         extra = per_lane * (len(jobs) - 1)
-        have = sum(int(t.numel()) for k_, t in self._bufs.items() if "_lane" in k_)   # (what earlier calls already hold)
-        free = torch.cuda.mem_get_info(self.device)[0]
-        if extra > have and extra - have > free // 4:
+        have = sum(int(t.numel()) * int(t.element_size()) for k_, t in self._bufs.items() if "_lane" in k_)   # BYTES earlier calls already hold
+        # (the driver query costs ~10 us and is only made when the lanes' workspaces still have to grow)
+        if extra > have and extra - have > torch.cuda.mem_get_info(self.device)[0] // 4:
             return [self.rank_side(triples, side, strategy, flt, ent_ids, subset_pos, out=out, out_stride=stride) for side, flt, out, stride in jobs]
         main = torch.cuda.current_stream()
         res, lanes = [], []

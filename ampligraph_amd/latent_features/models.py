@@ -116,10 +116,12 @@ class ScoringBasedEmbeddingModel:
         Extra keywords of this engine: optimizer_mode="dense" (default, the reference's semantics) | "lazy" (touched rows
         only; see amdkge_opt.lazy); deterministic=True: bitwise reproducible training (AMDKGE_TILED_DETERMINISTIC).  Multi-GPU, one process per GPU under torch.distributed:
         entity_sharding="replicated" (default: tables replicated, gradient all-reduce) | "rows" (entity table
-        row-sharded over the ranks, ampligraph_amd/sharded.py); sharded_negatives="local" | "global" | "columns" (tables that fit
-        every GPU: rank r TRAINS on k / W units of every row and the whole batch, one all-reduce of the partial scores per step --
-        ampligraph_amd/colsharded.py; every rank also keeps the whole tables, refreshed from the slices after each fit() and
-        before each validation pass, which predict / evaluate / save_weights read)."""
+        row-sharded over the ranks, ampligraph_amd/sharded.py; sharded_negatives="local" | "global" chooses where its corruptions
+        are drawn from) | "columns" (tables that fit every GPU: rank r TRAINS on k / W units of every row and the whole batch, one
+        all-reduce of the partial scores per step -- ampligraph_amd/colsharded.py.  Memory and host cost of that mode: every rank
+        keeps the WHOLE tables and their whole optimizer slots next to its slice -- predict / evaluate / save_weights / callbacks
+        read them -- and they are refreshed from the slices through host numpy (all_gather + column merge) after each fit(),
+        before each validation pass and, when callbacks are given, before the callbacks of every epoch)."""
         optimizer_mode = kwargs.pop("optimizer_mode", "dense")
         if optimizer_mode not in ("dense", "lazy"):
             raise ValueError("optimizer_mode must be 'dense' (the reference's behaviour) or 'lazy' (touched rows only)")
@@ -429,6 +431,8 @@ class ScoringBasedEmbeddingModel:
         self.stop_training = False
         if isinstance(validation_entities_subset, str) and validation_entities_subset == "all":
             validation_entities_subset = None
+        # column-sharded training: are the whole tables (what evaluate / callbacks / checkpoints read) current with the slices?
+        cols_current = False
         for epoch in range(int(initial_epoch), int(epochs)):
             self.current_epoch = epoch
             loop.reset_loss()
@@ -453,12 +457,14 @@ class ScoringBasedEmbeddingModel:
                     loop.step(train[b0:b0 + batch_size], rng_base + (epoch - int(initial_epoch)) * steps + step, focus)
                 else:
                     loop.step(train[b0:b0 + batch_size], rng_base + (epoch - int(initial_epoch)) * steps + step)
+            cols_current = cols_current and steps <= first
             logs = {"loss": loop.mean_batch_loss()}
             validate = (epoch >= (validation_burn_in - 1) and validation_data is not None
                         and (epoch + 1) % int(validation_freq) == 0)
             if validate:
                 self.is_fitted = True
                 self._cols_push()   # (column-sharded training: refresh the whole tables the evaluation reads)
+                cols_current = True
                 ranks = self.evaluate(validation_data, batch_size=validation_batch_size or batch_size,
                                       use_filter=validation_filter, dataset_type="valid",
                                       corrupt_side=validation_corrupt_side,
@@ -469,12 +475,18 @@ class ScoringBasedEmbeddingModel:
             self.history._log(epoch, logs)
             if verbose:
                 print(f"Epoch {epoch + 1}/{epochs} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()))
+            if cbs and not cols_current:
+                # callbacks read AND write the whole tables (EarlyStopping snapshots them, and restores the best ones just before it
+                # stops the run): they must see this epoch's, and a push after them would overwrite what they restored
+                self._cols_push()
+                cols_current = True
             for cb in cbs:
                 if hasattr(cb, "on_epoch_end"):
                     cb.on_epoch_end(epoch, logs)
             if self.stop_training:
                 break
-        self._cols_push()
+        if not cols_current:
+            self._cols_push()
         for cb in cbs:
             if hasattr(cb, "on_train_end"):
                 cb.on_train_end()

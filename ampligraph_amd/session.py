@@ -147,14 +147,15 @@ class SessionGroup:
 
     def __init__(self, devices, scoring_type, k, n_ents, n_rels, eta, loss, optimizer, regularizer=None, rel_regularizer=None, seed=0,
                  pos_atomic=False, focus_nonlinearity=None, deterministic=False, force_rccl=False, rows=False, max_batch=None,
-                 global_negatives=False, cols=False):
+                 global_negatives=False, cols=False, force_threads=False):
         """force_rccl: AMDKGE_GROUP_FORCE_RCCL -- a group of one replica still binds librccl and sums its gradients through a
         one-rank ncclAllReduce (first contact with RCCL on a one-GPU box).  rows=True: the entity table ROW-SHARDED over the
         replicas (amdkge_session_group_create_rows; n_ents is the global count, max_batch the largest batch of a step,
         global_negatives reproduces one GPU's corruptions instead of drawing shard-local ones); set_rows / get_rows then speak
         global row numbers.  cols=True: every table COLUMN-sharded over the replicas (amdkge_session_group_create_cols: replica d
         holds k / W units of every row and processes the whole batch on them; one all-reduce of the partial scores per step);
-        set_rows / get_rows take and return whole rows."""
+        set_rows / get_rows take and return whole rows.  force_threads: AMDKGE_GROUP_FORCE_THREADS -- rank() drives every replica
+        from a host thread of its own although the replicas share a device (replicas on distinct devices always get one)."""
         self.lib = _ffi.lib()
         self._args = (scoring_type, int(k), int(n_ents), int(n_rels), int(eta), loss, optimizer)
         self.K = int(self.lib.amdkge_internal_k(_ffi.SCORING_TYPES[scoring_type], int(k)))
@@ -169,10 +170,11 @@ class SessionGroup:
         elif rows:
             if max_batch is None:
                 raise ValueError("rows=True needs max_batch (the largest batch a step will be given)")
-            check(self.lib.amdkge_session_group_create_rows(C.byref(cfg), _p(dev), int(dev.shape[0]), (1 if force_rccl else 0) | (4 if global_negatives else 0),
+            check(self.lib.amdkge_session_group_create_rows(C.byref(cfg), _p(dev), int(dev.shape[0]), (1 if force_rccl else 0) | (4 if global_negatives else 0) | (16 if force_threads else 0),
                                                             int(max_batch), C.byref(self._g)))
         else:
-            check(self.lib.amdkge_session_group_create_ex(C.byref(cfg), _p(dev), int(dev.shape[0]), 1 if force_rccl else 0, C.byref(self._g)))
+            check(self.lib.amdkge_session_group_create_ex(C.byref(cfg), _p(dev), int(dev.shape[0]), (1 if force_rccl else 0) | (16 if force_threads else 0),
+                                                          C.byref(self._g)))
         self.size = int(self.lib.amdkge_session_group_size(self._g))
 
     def info(self):

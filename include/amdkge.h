@@ -550,7 +550,10 @@ int amdkge_session_group_create(const amdkge_session_config* cfg, const int32_t*
  * the one device, gradient-only kernels, grouped ncclAllReduce of both gradient tables, dense sweeps): every RCCL call of the
  * group step is exercised on a one-GPU box.  amdkge_session_group_info: whether the group sums through RCCL, and ncclGetVersion. */
 enum { AMDKGE_GROUP_FORCE_RCCL = 1, AMDKGE_GROUP_ROWS = 2 /* set by amdkge_session_group_create_rows */, AMDKGE_GROUP_GLOBAL_NEGATIVES = 4,
-       AMDKGE_GROUP_COLS = 8 /* set by amdkge_session_group_create_cols */ };
+       AMDKGE_GROUP_COLS = 8 /* set by amdkge_session_group_create_cols */,
+       /* one host thread per replica in amdkge_session_group_rank even when the replicas share a device (replicas on distinct devices
+        * always get one): the path a multi-GPU node takes, testable on one GPU */
+       AMDKGE_GROUP_FORCE_THREADS = 16 };
 int amdkge_session_group_create_ex(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
                                    amdkge_session_group** out);
 int amdkge_session_group_info(const amdkge_session_group* g, int32_t* uses_rccl, int32_t* rccl_version);
@@ -584,7 +587,11 @@ int amdkge_session_group_create_rows(const amdkge_session_config* cfg, const int
  * AMDKGE_TILED_GIVEN_COEFFS): W replicas compute one GPU's step (the same Philox corruptions) up to fp32 summation order.
  * amdkge_session_group_set_rows / _get_rows take and return WHOLE rows (columns scattered to / gathered from the replicas);
  * evaluation: gather the rows into one session of its own -- amdkge_session_group_rank returns AMDKGE_EUNSUPPORTED for such a group.  Not offered:
- * FocusE, DETERMINISTIC, POS_ATOMIC, hot rows; slices of more than 256 stored units per half. */
+ * FocusE, DETERMINISTIC, POS_ATOMIC, hot rows; slices of more than 256 stored units per half.
+ * A step that FAILS: before any slice has applied its update the group is left as it was (gradients cleared, workspaces dropped) and the
+ * step may be retried; once some slices have been updated the columns of the one model have parted and the group refuses further steps
+ * (AMDKGE_EINVAL) until the tables are written again with amdkge_session_group_set_rows -- the whole entity table clears the state --
+ * or the group is destroyed and rebuilt. */
 int amdkge_session_group_create_cols(const amdkge_session_config* cfg, const int32_t* devices, int32_t n_gpus, int32_t flags,
                                      amdkge_session_group** out);
 int amdkge_session_group_get_rows(amdkge_session_group* g, int32_t table, const int32_t* ids, int64_t row0, int64_t nrows, float* host);

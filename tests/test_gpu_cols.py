@@ -239,3 +239,51 @@ def test_drop_in_class_column_sharded_fit_equals_single_gpu(gpu_lib, tmp_path):
     m2.load_weights(ck)
     h3 = m2.fit(X, batch_size=256, epochs=4, initial_epoch=2, verbose=False)
     assert np.allclose(h3.history["loss"], h1b.history["loss"], rtol=2e-4)
+
+
+def test_column_sharded_fit_keeps_what_early_stopping_restored(gpu_lib):
+    """EarlyStopping(restore_best_weights=True) puts the best tables back into the model's whole-table engine just
+    before it stops the run; the column-sharded fit() used to push its slices over them afterwards (and callbacks on non-validation
+    epochs saw stale whole tables).  Now the whole tables are refreshed BEFORE the callbacks of every epoch and nothing is pushed after a
+    callback: the tables a stopped run ends with are the best epoch's -- on two ranks as on one GPU."""
+    from test_gpu_model import toy_graph
+    from threaded_dist import ThreadedWorld
+
+    from ampligraph_amd.callbacks import EarlyStopping
+    from ampligraph_amd.latent_features import ScoringBasedEmbeddingModel, optimizers
+
+    X = toy_graph(n=900, N=70, R=4)
+    ents = np.array([f"e{i}" for i in range(70)])
+
+    class Snapshots:   # what a callback SEES at the end of every epoch (whole tables, read through the public surface)
+        def __init__(self):
+            self.seen = []
+
+        def set_model(self, m):
+            self.m = m
+
+        def on_epoch_end(self, epoch, logs=None):
+            self.m.is_fitted = True
+            self.seen.append(self.m.get_embeddings(ents).copy())
+            logs["scripted"] = [5.0, 4.0, 3.0, 6.0, 7.0, 8.0, 9.0][epoch]   # best at epoch 2; patience 2 stops the run at epoch 4
+
+    def run(dist=None, **kw):
+        m = ScoringBasedEmbeddingModel(eta=4, k=24, scoring_type="ComplEx", seed=3)
+        m._dist_override = dist
+        m.compile(optimizer=optimizers.get("adam", {"learning_rate": 1e-2}), loss="self_adversarial", **kw)
+        snap, es = Snapshots(), EarlyStopping(monitor="scripted", mode="min", patience=2, restore_best_weights=True)
+        h = m.fit(X, batch_size=256, epochs=7, verbose=False, callbacks=[snap, es])
+        return h.history["loss"], es.best_epoch, es.stopped_epoch, snap.seen, m.get_embeddings(ents)
+
+    one = run()
+    res = ThreadedWorld(2).run(lambda dist: run(dist, entity_sharding="columns"))
+    hist1, best1, stop1, seen1, final1 = one
+    assert (best1, stop1) == (2, 4) and len(hist1) == 5, (hist1, best1, stop1)   # the run stopped early, two epochs after its best
+    assert np.array_equal(final1, seen1[best1])                              # single GPU: the restored tables are the best epoch's
+    for hist, best, stop, seen, final in res:
+        assert (best, stop) == (best1, stop1), (hist, hist1)
+        assert np.array_equal(final, seen[best])                             # columns: what EarlyStopping restored survives fit()
+        assert not np.array_equal(final, seen[stop])
+        for a, b in zip(seen, seen1):                                        # every epoch's callback saw THAT epoch's tables
+            assert (np.abs(a - b) <= 1e-4 + 2e-2 * np.abs(b)).mean() > 0.97
+    assert np.array_equal(res[0][4], res[1][4])

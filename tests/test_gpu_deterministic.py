@@ -130,3 +130,79 @@ def test_deterministic_steps_bitwise_in_every_launch_geometry(gpu_lib, model, k,
     assert np.array_equal(e, st.ent) and np.array_equal(r, st.rel), (int((e != st.ent).sum()), int((r != st.rel).sum()), float(np.abs(e - st.ent).max()))
     assert np.array_equal(eng.unpack(eng.slots["m_e"]).cpu().numpy(), st.s0[0]) and np.array_equal(eng.unpack(eng.slots["v_e"]).cpu().numpy(), st.s1[0])
     assert within(f"det/geometry_vs_ordered_oracle/{loss}", rel_gap(got, ref), 5e-6 if loss == "multiclass_nll" else 1e-12), (got, ref)
+
+
+def _det_plan_mirror(N, K, B, eta):
+    """make_plan's deterministic-mode sizing (kge_train_tiled.hip) restated: -> (tile_rows, n_tiles, cap, sort_cap)."""
+    entries, row_bytes, budget = B * (eta + 2), K * 4, 96 * 1024
+    while True:
+        fit = budget // row_bytes
+        best, sel, rb = -1.0, None, 8
+        while rb >= 1:
+            if rb <= fit:
+                blocks, mm = (N + rb - 1) // rb, 1
+                while True:
+                    per = (blocks + 256 * mm - 1) // (256 * mm)
+                    if per * rb <= fit and per * rb <= 4096:
+                        break
+                    mm += 1
+                nt = (blocks + per - 1) // per
+                eff = N / (per * rb) / (((nt + 255) // 256) * 256)
+                if eff > best + 0.03 or best < 0:
+                    best, sel = eff, (per * rb, nt)
+                if eff >= 0.97:
+                    break
+            rb >>= 1
+        tile_rows, n_tiles = sel
+        mean = (entries + n_tiles - 1) // n_tiles
+        cap = 2 * mean + (256 if mean >= 224 else 32 + mean)
+        sc = (cap + 64 + 63) & ~63
+        fixed = tile_rows * K * 4 + 4096 + 16 + 1024
+        if sc <= 8192 and fixed + sc * 20 <= 158 * 1024:
+            while sc * 2 <= 8192 and fixed + sc * 2 * 20 <= 158 * 1024:
+                sc *= 2
+            return tile_rows, n_tiles, cap, sc
+        budget = budget * 3 // 4
+
+
+def test_deterministic_hub_row_with_a_sort_queue_stride_that_is_no_power_of_two(gpu_lib):
+    """the wave-local index sort of the deterministic tile pass pads a wave's queue to a power of two; the queues
+    are sort_cap / 8 indices apart and sort_cap is only a multiple of 64.  On the FB15K-237 shape with a short batch (ComplEx k = 200,
+    B = 1 250, eta = 20: sort_cap 1 792, stride 224) a hub row with 129 .. 224 entries made its wave pad to 256 -- into the next wave's
+    queue.  A wave's capacity is now the largest power of two inside the stride and such a tile takes the block-wide fall-back.
+    Two steps against oracle/train_ordered, bit for bit, and three runs equal."""
+    from oracle import train_ordered as TO
+
+    from ampligraph_amd.engine import KgeEngine
+    from ampligraph_amd.latent_features import loss_functions, optimizers
+    from ampligraph_amd.trainer import StepLoop
+
+    model, k, N, R, B, eta = "ComplEx", 200, 14505, 7, 1250, 20
+    tile_rows, n_tiles, cap, sort_cap = _det_plan_mirror(N, 2 * k, B, eta)
+    stride = sort_cap // 8
+    assert stride < 256 and stride & (stride - 1), (sort_cap, "the shape no longer has the stride this test is about")
+    rng = np.random.default_rng(11)
+    ent = rng.uniform(-0.2, 0.2, size=(N, 2 * k)).astype(np.float32)
+    rel = rng.uniform(-0.2, 0.2, size=(R, 2 * k)).astype(np.float32)
+    X = np.stack([rng.integers(0, N, 2 * B), rng.integers(0, R, 2 * B), rng.integers(0, N, 2 * B)], 1).astype(np.int32)
+    for step in range(2):   # 190 positives of each batch point at one hub: its owner wave holds > 128 and <= stride entries
+        X[step * B:step * B + 190, 2] = 4321
+    outs = []
+    for rep in range(3):
+        eng = KgeEngine(model, k, N, R, max_rel_size=R)
+        eng.set_tables(ent, rel)
+        loop = StepLoop(eng, eta, loss_functions.get("self_adversarial"), optimizers.get("adam", {"learning_rate": 1e-2}), None, seed=6, dist=None)
+        loop.deterministic = True
+        Xd = torch.as_tensor(X).cuda()
+        loop.reset_loss()
+        for step in range(2):
+            loop.step(Xd[step * B:(step + 1) * B], step)
+        torch.cuda.synchronize()
+        assert eng.tiled_status() == 0
+        outs.append(eng.get_tables())
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[1][1])
+    st = TO.OptState(ent.copy(), rel.copy(), "adam", 1e-2)
+    for step in range(2):
+        TO.trilinear_step_det(model, st, X[step * B:(step + 1) * B], eta, 6, step, "self_adversarial")
+    e, r = outs[0]
+    assert np.array_equal(e, st.ent) and np.array_equal(r, st.rel), (int((e != st.ent).sum()), float(np.abs(e - st.ent).max()))

@@ -359,10 +359,13 @@ def cs_head(csr, n):
     return off[:n + 1], ids[:off[n]]
 
 
-@pytest.mark.parametrize("model,k,W,max_batch,force_rccl", [("ComplEx", 100, 2, 4000, False), ("DistMult", 200, 4, 4000, False), ("HolE", 64, 3, 120, False),
-                                                            ("TransE", 64, 2, 4000, False), ("RotatE", 40, 3, 4000, False), ("ComplEx", 100, 1, 4000, True),
-                                                            ("TransE", 50, 4, 90, False)])
-def test_session_group_rank_row_sharded_is_bit_identical(gpu_lib, model, k, W, max_batch, force_rccl):
+@pytest.mark.parametrize("model,k,W,max_batch,force_rccl,threads", [
+    ("ComplEx", 100, 2, 4000, False, False), ("DistMult", 200, 4, 4000, False, False), ("HolE", 64, 3, 120, False, False),
+    ("TransE", 64, 2, 4000, False, False), ("RotatE", 40, 3, 4000, False, False), ("ComplEx", 100, 1, 4000, True, False), ("TransE", 50, 4, 90, False, False),
+    # round 6: one host thread per replica (AMDKGE_GROUP_FORCE_THREADS: the path replicas on distinct devices take), per-replica staging
+    ("ComplEx", 100, 2, 4000, False, True), ("DistMult", 200, 4, 4000, False, True), ("TransE", 64, 3, 120, False, True), ("RotatE", 40, 2, 4000, False, True),
+    ("HolE", 64, 4, 90, False, True)])
+def test_session_group_rank_row_sharded_is_bit_identical(gpu_lib, model, k, W, max_batch, force_rccl, threads):
     """amdkge_session_group_rank: evaluation through a ROW-SHARDED group, numpy only.  Every replica counts all
     queries against its own rows (filter ids restricted to the shard), the query rows are gathered from their owners into the scratch
     rows, counts and filter subtractions are summed over the replicas, +1 once -- the reference's partition loop
@@ -388,7 +391,7 @@ def test_session_group_rank_row_sharded_is_bit_identical(gpu_lib, model, k, W, m
     fs, fo = O.filter_sets(T, [F])
     mk = lambda: (loss_functions.get("nll"), optimizers.get("adam"))   # noqa: E731
     single = Session(model, k, N, R, 2, *mk(), seed=0)
-    group = SessionGroup([0] * W, model, k, N, R, 2, *mk(), seed=0, rows=True, max_batch=max_batch, force_rccl=force_rccl)
+    group = SessionGroup([0] * W, model, k, N, R, 2, *mk(), seed=0, rows=True, max_batch=max_batch, force_rccl=force_rccl, force_threads=threads)
     if force_rccl:
         assert group.info()[0]
     for s in (single, group):
@@ -425,8 +428,10 @@ def test_session_group_rank_row_sharded_is_bit_identical(gpu_lib, model, k, W, m
     group.close()
 
 
-def test_session_group_rank_replicated(gpu_lib):
-    """A replicated group splits the queries over its replicas (slices of the filter offsets index the whole id arrays)."""
+@pytest.mark.parametrize("threads", [False, True])
+def test_session_group_rank_replicated(gpu_lib, threads):
+    """A replicated group splits the queries over its replicas (slices of the filter offsets index the whole id arrays); with
+    `threads` every replica is driven from a host thread of its own, as replicas on distinct devices are."""
     from ampligraph_amd.latent_features import loss_functions, optimizers
     from ampligraph_amd.session import Session, SessionGroup
 
@@ -439,7 +444,7 @@ def test_session_group_rank_replicated(gpu_lib):
     fs, fo = O.filter_sets(T, [np.concatenate([T, np.stack([rng.integers(0, N, 3000), rng.integers(0, R, 3000), rng.integers(0, N, 3000)], 1).astype(np.int32)])])
     mk = lambda: (loss_functions.get("nll"), optimizers.get("adam"))   # noqa: E731
     single = Session(model, k, N, R, 2, *mk(), seed=0)
-    group = SessionGroup([0, 0, 0], model, k, N, R, 2, *mk(), seed=0)
+    group = SessionGroup([0, 0, 0], model, k, N, R, 2, *mk(), seed=0, force_threads=threads)
     for s in (single, group):
         s.set_rows("ent", ent)
         s.set_rows("rel", rel)
