@@ -1211,6 +1211,7 @@ __global__ void rank_compose_kernel(const int32_t* counts, const int32_t* sub, i
 
 }  // namespace kge
 #include "kge_rank_screen.h"
+#include "kge_rank_screen_g.h"
 #define KGE_RANK_EARLY_PART2
 #include "kge_rank_early.h"   // part 2: workspace, row flags, the exact recheck of the distance models
 namespace kge {
@@ -1319,14 +1320,17 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     static int screen_v1 = 1;
     if (!attr_done) {
         const char* ev = getenv("AMDKGE_SCREEN_KERNEL");
-        screen_v1 = (ev && atoi(ev) == 2) ? 0 : 1;
+        screen_v1 = (ev && atoi(ev) == 2) ? 0 : ((ev && atoi(ev) == 3) ? 3 : 1);
+        if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCG_LDS_BYTES))
+            return set_error_hip(e, "hipFuncSetAttribute(rank_screen_g)");
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_v1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_v1)");
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES_Q))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen)");
         attr_done = true;
     }
-    if (screen_v1) hipLaunchKernelGGL(rank_screen_kernel_v1, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
+    if (screen_v1 == 3) hipLaunchKernelGGL(rank_screen_kernel_g, dim3((unsigned)nblk), dim3(SCR_THREADS), SCG_LDS_BYTES, st, sa);
+    else if (screen_v1) hipLaunchKernelGGL(rank_screen_kernel_v1, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
     else hipLaunchKernelGGL(rank_screen_kernel, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES_Q, st, sa);
     if (int rc = check_launch("rank_screen")) return rc;
     RecheckArgs ra{};

@@ -105,13 +105,30 @@ def test_mean_mrr_over_seeds_matches_oracle(gpu_lib, model, loss):
     gold = G[f"{model}/{loss}"]   # columns: oracle MRR, hits@10, first-epoch loss, last-epoch loss
 
     histories = {}
+    # Round 6: the one-in-25 000 excursion of round 5 was a NaN, and its birth is named (scripts/nan_hunt.py,
+    # profiles/r06a_nan_hunt_*: 4 of 19 000 RotatE fits).  RotatE's modulus has no epsilon (RotatE.py:102-104): a corruption (e, p, e)
+    # -- the sampler redrew the entity that is already on the other side, one corruption in N -- whose relation has a unit with a phase
+    # so close to 0 that cos rounds to 1 and e sin(phi) falls under the ulp of e evaluates to z = (0, 0) EXACTLY in fp32, sqrt(0) = 0,
+    # and the gradient is 0 / 0: NaN in the tables from that step on -- in the reference's own arithmetic as here (tf.sqrt's gradient at
+    # 0 is inf, times 2 z = 0).  The loss kernels now report it as the NaN it is (clip_exp, kge_train_kernel.h) instead of 375 per
+    # positive.  The oracle replays in fp64 and never meets the exact zero, so a fit that does is re-drawn here (the default mode's
+    # arrival-order rounding differs from run to run: the same seed does not meet it twice) and COUNTED: more than two per case would
+    # be another mechanism.
+    nan_fits = []
 
-    def fit_one(seed):
+    def fit_one(seed, retries=2):
         d = planted_kg(model, seed=seed)
         train, test = d["train"].astype(str), d["test"].astype(str)
         m = ScoringBasedEmbeddingModel(eta=ETA, k=K, scoring_type=model, seed=seed)
         m.compile(optimizer=optimizers.get("adam", {"learning_rate": LR}), loss=loss)
         h = m.fit(train, batch_size=BATCH, epochs=EPOCHS, verbose=False).history["loss"]
+        if not np.isfinite(h).all():
+            nan_fits.append(dict(seed=int(seed), first_nonfinite_epoch=int(np.nonzero(~np.isfinite(h))[0][0])))
+            assert model == "RotatE", ("a non-finite loss outside RotatE's modulus-zero case", nan_fits)
+            assert retries > 0, ("the same seed met the modulus-zero case three times", nan_fits)
+            return fit_one(seed, retries - 1)
+        e_, r_ = m._engine.get_tables()
+        assert np.isfinite(e_).all() and np.isfinite(r_).all(), ("non-finite tables behind a finite loss history", seed)
         ranks = m.evaluate(test, use_filter={"train": train, "test": test}, corrupt_side="s,o", verbose=False)
         return (O.mrr_score(ranks), O.hits_at_n_score(ranks, 10), h[0], h[-1]), h
 
@@ -148,9 +165,10 @@ def test_mean_mrr_over_seeds_matches_oracle(gpu_lib, model, loss):
                   standard_error=float(dm.std() / np.sqrt(n)), hits10_mean_distance=float((got[:, 1] - gold[:, 1]).mean()),
                   first_epoch_loss_max_rel=float(np.max(np.abs(got[:, 2] - gold[:, 2]) / np.abs(gold[:, 2]))),
                   last_epoch_loss_mean_rel=float(np.mean(rel_last)), last_epoch_loss_max_rel=float(np.max(np.abs(rel_last))),
-                  fits_beyond_5_percent_in_the_last_epoch_loss=excursions)
+                  fits_beyond_5_percent_in_the_last_epoch_loss=excursions, fits_redrawn_after_a_modulus_zero_nan=nan_fits)
     print("mean MRR over seeds", model, loss, report)
     assert report["first_epoch_loss_max_rel"] <= {"nll": 5e-5, "pairwise": 4e-4, "self_adversarial": 1e-5}[loss], report   # before any drift: every seed (measured max over 512 / 2 048 seeds: 1.3e-5 / 2.2e-5 / 1.9e-7)
+    assert len(nan_fits) <= 2, report
     assert abs(report["mean_distance"]) <= 2e-3, report                       # the north_star's bar, on the mean
     assert abs(report["hits10_mean_distance"]) <= 4e-3, report
     # no bias in the loss either (per seed the pairwise hinge parts by 0.5 .. 0.8 %, the others by <= 0.3 %: CASES above)
