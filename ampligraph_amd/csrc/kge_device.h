@@ -63,9 +63,6 @@ __device__ __forceinline__ float wave_sum_shfl(float v) {
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
-#ifdef KGE_NO_DPP
-    return wave_sum_shfl(v);
-#else
     v += dpp_mov0<0x111>(v);        // row_shr:1
     v += dpp_mov0<0x112>(v);        // row_shr:2
     v += dpp_mov0<0x114>(v);        // row_shr:4
@@ -73,7 +70,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov0<0x142, 0xA>(v);   // row_bcast:15 into rows 1,3
     v += dpp_mov0<0x143, 0xC>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-#endif
 }
 
 // The wave totals of N <= 8 per-lane values AT ONCE (a transposing reduction): at each of the first three levels a lane keeps

@@ -17,6 +17,19 @@ int set_error(int code, const char* msg);            // stores a thread-local me
 int set_error_hip(hipError_t e, const char* where);  // AMDKGE_EHIP with hipGetErrorString
 int check_launch(const char* kernel_name);           // hipGetLastError() after a launch
 
+// "Once" for hipFuncSetAttribute-style set-up: a function's attributes belong to (function, DEVICE), and a process may drive several
+// devices (session groups: one replica and one host thread per GPU), so a process-wide `static bool` would set up device 0 only.
+// One bit per device ordinal (mod 64); racing threads at worst both do the idempotent set-up.
+struct PerDeviceOnce {
+    unsigned long long mask = 0ull;
+    int dev = 0;
+    bool need() {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        return !((__atomic_load_n(&mask, __ATOMIC_RELAXED) >> (dev & 63)) & 1ull);
+    }
+    void done() { __atomic_fetch_or(&mask, 1ull << (dev & 63), __ATOMIC_RELAXED); }
+};
+
 // The session layers allocate on the host (staging vectors, the per-device threads of a group, the registries): those can throw,
 // the C ABI cannot.  Their entry points are function-try-blocks closed by KGE_CATCH("name").
 #define KGE_CATCH(NAME)                                                                                              \

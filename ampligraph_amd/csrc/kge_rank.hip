@@ -1212,6 +1212,7 @@ __global__ void rank_compose_kernel(const int32_t* counts, const int32_t* sub, i
 }  // namespace kge
 #include "kge_rank_screen.h"
 #include "kge_rank_screen_g.h"
+constexpr int SCREEN_KERNEL_DEFAULT = 1;   // (see run_screen)
 #define KGE_RANK_EARLY_PART2
 #include "kge_rank_early.h"   // part 2: workspace, row flags, the exact recheck of the distance models
 namespace kge {
@@ -1313,34 +1314,30 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     sa.ent_per_block = (int)(tiles_per * SCR_ET); sa.qtiles = (int)qtiles; sa.splits = (int)splits;
     const int64_t nblk = 8 * ((qtiles + 7) / 8) * splits;
     if (nblk > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
-    static bool attr_done = false;
-    // Round 5 built a second form of the kernel (both operands through LDS, two stages ahead: rank_screen_kernel in
-    // kge_rank_screen.h) -- MEASURED SLOWER than round 4's (C2 both sides 2.53 vs 2.33 ms, C3 1.15 vs 1.08; SQ_WAVE_CYCLES 980 M vs
-    // 862 M per launch, profiles/r05d_*), so round 4's stays the default; AMDKGE_SCREEN_KERNEL=2 selects the other for A/B runs.
-    static int screen_v1 = 1;
-    if (!attr_done) {
-        const char* ev = getenv("AMDKGE_SCREEN_KERNEL");
-        screen_v1 = (ev && atoi(ev) == 2) ? 0 : ((ev && atoi(ev) == 3) ? 3 : 1);
-        if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCG_LDS_BYTES))
-            return set_error_hip(e, "hipFuncSetAttribute(rank_screen_g)");
+    // Which screening kernel: rank_screen_kernel_v1 (rounds 3 - 5: query fragments L2 -> registers, entity slab register-staged through
+    // LDS) or rank_screen_kernel_g (round 6, kge_rank_screen_g.h: both operands by LDS-DMA into a ring of stage buffers).  The same
+    // counts either way; AMDKGE_SCREEN_KERNEL=1 / 3 pins one for A/B runs (read once).  Round 5's register-staged "both operands
+    // through LDS" form measured slower and lives in scripts/experiments/rank_screen_kernel_qlds_r05.h.
+    static PerDeviceOnce attr_done;
+    static const int screen_kernel = [] { const char* ev = getenv("AMDKGE_SCREEN_KERNEL"); const int v = ev ? atoi(ev) : 0; return (v == 1 || v == 3) ? v : SCREEN_KERNEL_DEFAULT; }();
+    if (attr_done.need()) {
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_v1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_v1)");
-        if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES_Q))
-            return set_error_hip(e, "hipFuncSetAttribute(rank_screen)");
-        attr_done = true;
+        if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCG_LDS_BYTES))
+            return set_error_hip(e, "hipFuncSetAttribute(rank_screen_g)");
+        attr_done.done();
     }
-    if (screen_v1 == 3) hipLaunchKernelGGL(rank_screen_kernel_g, dim3((unsigned)nblk), dim3(SCR_THREADS), SCG_LDS_BYTES, st, sa);
-    else if (screen_v1) hipLaunchKernelGGL(rank_screen_kernel_v1, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
-    else hipLaunchKernelGGL(rank_screen_kernel, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES_Q, st, sa);
+    if (screen_kernel == 3) hipLaunchKernelGGL(rank_screen_kernel_g, dim3((unsigned)nblk), dim3(SCR_THREADS), SCG_LDS_BYTES, st, sa);
+    else hipLaunchKernelGGL(rank_screen_kernel_v1, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
     if (int rc = check_launch("rank_screen")) return rc;
     RecheckArgs ra{};
     ra.ent = d_ent; ra.Q = w.Q; ra.qpos = w.qpos; ra.ent_ids = d_ent_ids; ra.ent_lo = ent_lo; ra.U = g.U; ra.K = g.K; ra.QW = g.QW;
     ra.sgn_scale = sgn_scale; ra.b = b;
-    static bool rck_attr = false;
-    if (!rck_attr) {
+    static PerDeviceOnce rck_attr;
+    if (rck_attr.need()) {
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_recheck_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCK_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_recheck)");
-        rck_attr = true;
+        rck_attr.done();
     }
     hipLaunchKernelGGL(rank_recheck_kernel<false>, dim3(1024), dim3(256), RCK_LDS_BYTES, st, ra);
     if (int rc = check_launch("rank_recheck")) return rc;
@@ -1416,11 +1413,11 @@ static int run_early(int mode, const amdkge_model* m, const float* d_ent, const 
     RecheckDistArgs ra{};
     ra.ent = d_ent; ra.Q = w.Q; ra.qpos = w.qpos; ra.ent_ids = d_ent_ids; ra.ent_lo = ent_lo; ra.g = g; ra.sgn_scale = a.sgn_scale; ra.b = eb.b;
 #define KGE_RD(MODE) do { \
-        static bool attr = false; \
-        if (!attr) { \
+        static PerDeviceOnce attr; \
+        if (attr.need()) { \
             if (hipError_t e = hipFuncSetAttribute((const void*)rank_recheck_dist_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rd_lds_bytes<MODE>())) \
                 return set_error_hip(e, "hipFuncSetAttribute(rank_recheck_dist)"); \
-            attr = true; \
+            attr.done(); \
         } \
         hipLaunchKernelGGL(rank_recheck_dist_kernel<MODE>, dim3(1024), dim3(256), rd_lds_bytes<MODE>(), st, ra); } while (0)
     switch (mode) {
@@ -1589,13 +1586,13 @@ static int rank_counts_impl(const amdkge_model* m, const float* d_ent, const flo
     splits = (etiles + tiles_per - 1) / tiles_per;
     const dim3 grid((unsigned)qtiles, (unsigned)splits);
     if (mfma) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static PerDeviceOnce attr_done;
+        if (attr_done.need()) {
             hipError_t e1 = hipFuncSetAttribute((const void*)rank_count_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_BYTES);
             hipError_t e2 = hipFuncSetAttribute((const void*)rank_count_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_BYTES);
             if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)rank_count_mfma_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_BYTES);
             if (e1 != hipSuccess || e2 != hipSuccess) return set_error_hip(e1 != hipSuccess ? e1 : e2, "hipFuncSetAttribute(rank_count_mfma)");
-            attr_done = true;
+            attr_done.done();
         }
         a.qtiles = (int)qtiles; a.splits = (int)splits;
         const int64_t nblk = 8 * ((qtiles + 7) / 8) * splits;
@@ -1709,11 +1706,11 @@ extern "C" int amdkge_rank_filter(const amdkge_model* m, const float* d_ent, con
         ra.ent = d_ent; ra.Q = w.Q; ra.qpos = w.qpos; ra.ent_ids = nullptr; ra.ent_lo = 0; ra.U = g.U; ra.K = g.K; ra.QW = g.QW;
         ra.sgn_scale = a.sgn_scale;
         ra.b.counter = w.flt_counter; ra.b.pairs = w.flt_pairs; ra.b.cap = w.flt_cap; ra.b.counts = d_sub;
-        static bool flt_attr = false;
-        if (!flt_attr) {
+        static PerDeviceOnce flt_attr;
+        if (flt_attr.need()) {
             if (hipError_t e = hipFuncSetAttribute((const void*)rank_recheck_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCK_LDS_BYTES))
                 return set_error_hip(e, "hipFuncSetAttribute(rank_recheck<filter>)");
-            flt_attr = true;
+            flt_attr.done();
         }
         const int64_t groups = (w.flt_cap + 63) / 64;
         hipLaunchKernelGGL(rank_recheck_kernel<true>, dim3((unsigned)(groups / 4 < 1024 ? (groups + 3) / 4 : 1024)), dim3(256), RCK_LDS_BYTES, st, ra);

@@ -918,14 +918,11 @@ struct TiledPlan {
     bool direct;        // long rows (> 128 quads per half): the row-direct tile pass (kge_tile_direct.h)
 };
 
-static int g_tile_direct = 1;   // amdkge_set_tile_direct (A/B measurements, tests): 0 keeps long rows on tile_backward_kernel, 2 adds the short-row form
-// The row-direct pass for SHORTER rows (32 .. 128 quads per half; BASELINE configs[3]: ComplEx k = 200 = 50 quads, 1.6 KB rows, on
-// 123 182 rows) of the trilinear models -- one wave per row up to 64 quads, two beyond --, offered while a table row sees <= 2 entries
-// per step.  MEASURED SLOWER than the LDS-accumulator tiles where it was meant to help and therefore OFF by default
-// (amdkge_set_tile_direct(2) switches it on: tests, A/B runs): C4 tile pass 339 us (LDS tiles) vs 476 us (32-row direct tiles;
-// whole step 0.393 vs 0.551 ms, 16 rows 0.701, 64 rows 0.437 -- profiles/r05b_c4_direct_short_rows.txt).  One wave per row is a
-// serial chain of row round trips; the LDS tiles keep 16 waves of a CU on 16 different rows.
-constexpr int DIRECT_SHORT_ROWS = 64;
+static int g_tile_direct = 1;   // amdkge_set_tile_direct (A/B measurements, tests): 0 keeps long rows on tile_backward_kernel
+// (Round 5 also offered the row-direct pass to SHORTER rows -- 32 .. 128 quads per half, BASELINE configs[3]'s 1.6 KB rows, one or two
+// waves per row.  MEASURED SLOWER than the LDS-accumulator tiles where it was meant to help: C4 tile pass 339 us vs 476 us, whole step
+// 0.393 vs 0.551 ms, profiles/r05b_c4_direct_short_rows_and_splits.txt -- one wave per row is a serial chain of row round trips, the
+// LDS tiles keep 16 waves of a CU on 16 different rows.  Removed from the product in round 6: `git show db3a690` has it.)
 
 static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& p, bool det = false, bool det_wide = false) {
     const int ks = stored_k(m), K = row_floats(m);
@@ -951,9 +948,7 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
     // batch: 4.3 -- 21.8 vs 26.2 ms); where rows collect many (ComplEx k = 1000 on 14 505 entities: 15 -- 0.88 vs 0.72 ms) the
     // LDS accumulators win, so the form is chosen by the batch's mean entries per row.
     const bool direct_long = g_tile_direct && !det && ks / 4 > 128 && B * (int64_t)(eta + 2) <= 8 * m->n_ents;
-    const bool direct_short = g_tile_direct == 2 && !det && ks / 4 >= 32 && ks / 4 <= 128 && B * (int64_t)(eta + 2) <= 2 * m->n_ents &&
-                              (model_t == AMDKGE_DISTMULT || model_t == AMDKGE_COMPLEX);
-    const bool direct_shape = direct_long || direct_short;
+    const bool direct_shape = direct_long;
     const size_t nodet_budget = direct_shape ? (size_t)KGE_DIRECT_BUDGET_KB * 1024 : 150 * 1024 - queue_bytes;
     for (size_t budget = det ? 96 * 1024 : nodet_budget;; budget = budget * 3 / 4) {
         // Whole ownership blocks per tile (block-interleaved ownership, see tile_backward_kernel).  The block size is the largest
@@ -961,7 +956,6 @@ static bool make_plan(const amdkge_model* m, int64_t B, int32_t eta, TiledPlan& 
         // block, and at C2 (14 505 rows, ~57 per tile) blocks of 8 would leave 11 % of the CUs without a tile.
         int fit = (int)(budget / row_bytes);
         if (direct_shape && fit > 160) fit = 160;   // (<= 8 entries per row: a bucket of at most 2 * 1 280 + 256 entries -- the row-direct pass's LDS list)
-        if (direct_short && fit > DIRECT_SHORT_ROWS) fit = DIRECT_SHORT_ROWS;   // (one- / two-wave workgroups: many small tiles fill the chip)
         if (fit < 1) return false;
         double best_eff = -1.0;
         for (int rb = (int)TILE_RB; rb >= 1; rb >>= 1) {
@@ -1076,11 +1070,11 @@ static int plan_guard(const void* d_work, const TiledPlan& p, char* w, hipStream
 
 template <int MODEL, int CH, int UNROLL, bool DET = false>
 static int launch_tile(const TileArgs& a, size_t shmem, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.need()) {
         if (hipError_t e = hipFuncSetAttribute((const void*)tile_backward_kernel<MODEL, CH, UNROLL, DET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))   // (the kernel has a few bytes of static LDS)
             return set_error_hip(e, "hipFuncSetAttribute(tile_backward)");
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL((tile_backward_kernel<MODEL, CH, UNROLL, DET>), dim3(a.n_tiles + a.rel_blocks), dim3(TILE_THREADS), shmem, st, a);
     return check_launch("tile_backward");
@@ -1095,11 +1089,11 @@ static int launch_forward_v(TrainArgs& f, hipStream_t st) {
     f.sign_off = (int)shmem;
     if (W != 1 || CHF != 1) shmem += sign_stash_bytes(MODEL, f.eta, CHF);   // (one wave per positive, one quad per lane: TransE takes the single-pass form, no stash)
     if (shmem > 64 * 1024) {
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce attr;
+        if (attr.need()) {
             if (hipError_t e = hipFuncSetAttribute((const void*)train_fwdbwd_kernel<MODEL, 4, W, CHF, true, DET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
                 return set_error_hip(e, "hipFuncSetAttribute(train_forward_stage)");
-            attr = true;
+            attr.done();
         }
     }
     const unsigned grid = KGE_DBG(f, 8192) ? 0u : (unsigned)((f.B + slots - 1) / slots);   // (ablation 8192: no forward launch)
@@ -1142,14 +1136,8 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st, float* given = 
     te.gw = f.nq <= 128 ? 1 : (f.nq <= 256 ? 4 : 8);
     if (te.direct) {
         const size_t sh = direct_lds_bytes(te.cap, te.tile_rows);
-        if (f.nq <= 128) {   // (make_plan offers this form to the trilinear models only)
-            if constexpr (TRILINEAR) {
-                if (f.nq <= 64) hipLaunchKernelGGL((tile_direct_kernel<MODEL, 1>), dim3(te.n_tiles + te.rel_blocks), dim3(64), sh, st, te);
-                else hipLaunchKernelGGL((tile_direct_kernel<MODEL, 2>), dim3(te.n_tiles + te.rel_blocks), dim3(128), sh, st, te);
-            }
-            else return set_error(AMDKGE_EUNSUPPORTED, "tile_direct: short rows are offered to the trilinear models only");
-        }
-        else if (te.gw == 4) hipLaunchKernelGGL((tile_direct_kernel<MODEL, 4>), dim3(te.n_tiles + te.rel_blocks), dim3(256), sh, st, te);
+        if (f.nq <= 128) return set_error(AMDKGE_EUNSUPPORTED, "tile_direct: rows of up to 128 quads per half take the LDS-accumulator tiles");
+        if (te.gw == 4) hipLaunchKernelGGL((tile_direct_kernel<MODEL, 4>), dim3(te.n_tiles + te.rel_blocks), dim3(256), sh, st, te);
         else hipLaunchKernelGGL((tile_direct_kernel<MODEL, 8>), dim3(te.n_tiles + te.rel_blocks), dim3(512), sh, st, te);
         return check_launch("tile_direct");
     }
@@ -1175,7 +1163,7 @@ static int run_tiled(TrainArgs& f, TileArgs& te, hipStream_t st, float* given = 
 using namespace kge;
 
 extern "C" int amdkge_set_tile_direct(int on) {
-    g_tile_direct = on == 2 ? 2 : (on ? 1 : 0);
+    g_tile_direct = on ? 1 : 0;   // (2 selected round 5's short-row form, since removed: it now means 1)
     return AMDKGE_OK;
 }
 

@@ -268,9 +268,8 @@ int64_t amdkge_train_tiled_workspace_bytes(const amdkge_model* m, int64_t B, int
  * default (kge_tile_direct.h: one wave group per tile, its bucket sorted in LDS, every row folded in registers and updated in
  * one go -- x read once, several tiles resident per CU).  0 keeps them on the LDS-accumulator kernel (A/B measurements, tests);
  * process-wide, both forms compute the same step up to fp32 summation order.  A tile whose entries outgrow the direct form's LDS
- * list rescans the spill in memory (slower, complete): no status is raised for it.  2 = additionally offer the form to 32 .. 128-quad
- * rows of the trilinear models while a row sees <= 2 entries per step (one / two waves per row; measured slower than the LDS tiles
- * at BASELINE configs[3], hence not the default: kept for tests and A/B runs). */
+ * list rescans the spill in memory (slower, complete): no status is raised for it.  (Any non-zero value means 1: round 5's value 2,
+ * a one- / two-wave form for 32 .. 128-quad rows, measured slower than the LDS tiles at BASELINE configs[3] and left the library.) */
 int amdkge_set_tile_direct(int on);
 /* status != 0 after a DETERMINISTIC step: some tile fell back to unsorted accumulation since the last query (flag is cleared).
  * Synchronises the stream. */

@@ -12,22 +12,19 @@ from test_gpu_kernels import assert_grads_close, dense, dev, loss_desc, make_eng
 pytestmark = pytest.mark.gpu
 
 WIDE = [("RotatE", 1000), ("ComplEx", 600), ("DistMult", 2048), ("TransE", 600), ("HolE", 516), ("RotatE", 1001), ("TransE", 2044)]
-# round 5: the one- / two-wave form for 32 .. 128-quad rows of the trilinear models (BASELINE configs[3]'s row width: 50 quads per
-# half), taken while a row sees <= 2 entries per step (make_plan)
-SHORT = [("ComplEx", 200), ("DistMult", 400), ("HolE", 130), ("DistMult", 512), ("ComplEx", 131), ("ComplEx", 400), ("DistMult", 128)]
+# (round 5's one- / two-wave form for 32 .. 128-quad rows measured slower than the LDS tiles and left the library in round 6; rows of
+# that width are covered, on the LDS-accumulator kernel, by tests/test_gpu_kernels.py::test_tiled_*)
 
 
 @pytest.fixture
 def direct_switch(gpu_lib):
-    yield lambda on: gpu_lib.amdkge_set_tile_direct(int(on))   # (2: also the short-row form, off by default)
+    yield lambda on: gpu_lib.amdkge_set_tile_direct(int(on))
     gpu_lib.amdkge_set_tile_direct(1)
 
 
-@pytest.mark.parametrize("model,k", WIDE + SHORT)
+@pytest.mark.parametrize("model,k", WIDE)
 def test_direct_gradients_match_oracle_and_lds_kernel(gpu_lib, direct_switch, model, k):
     N, R, B, eta = 400, 4, 300, 6   # B (eta + 2) = 2 400 entries <= 8 N: the shape gate of the row-direct pass (make_plan)
-    if (model, k) in SHORT:
-        B = 95                      # (760 entries <= 2 N)
     eng, ent, rel = make_engine(model, k, N, R, scale=0.08)
     rng = np.random.default_rng(2)
     X = rand_triples(rng, B, N, R)
@@ -35,7 +32,7 @@ def test_direct_gradients_match_oracle_and_lds_kernel(gpu_lib, direct_switch, mo
     total, Te, Tr, _ = O.dense_gradients(model, ent, rel, X, negs, eta, "self_adversarial", None, "sum", R)
     out = {}
     for on in (True, False):
-        direct_switch((2 if (model, k) in SHORT else 1) if on else 0)
+        direct_switch(1 if on else 0)
         for pa in (False, True):
             L, Ge, Gr, ps, ns = run_tiled_grads(eng, X, eta, "self_adversarial", "sum", 3, 1, pos_atomic=pa)
             assert abs(L - float(total)) <= 2e-5 * max(1.0, abs(L)), (on, pa)
@@ -53,9 +50,7 @@ def test_direct_step_in_place_parity(gpu_lib, direct_switch, opt, model, k, reg,
     """Whole steps (tables + slots updated row by row from registers) == oracle train_step, 3 steps, dense and touched-rows mode;
     direct=False runs the same steps on the LDS-accumulator kernel (same bars: the two forms are interchangeable)."""
     N, R, B, eta = 120, 4, 60, 3   # B * (eta + 2) = 300 entries on 120 rows: some rows stay untouched
-    if k <= 512 and model != "TransE":
-        N = 170                    # (the one- / two-wave form for shorter rows, off by default: entries <= 2 N)
-    direct_switch((2 if N == 170 else 1) if direct else 0)
+    direct_switch(1 if direct else 0)
     # RotatE x {sgd+momentum, rmsprop, rmsprop+momentum} on 1 000-unit rows: rules that turn a gradient g into a step ~ lr g / |g|
     # with no damping.  Rounds 3-4 asserted their touched-rows mode at 0.85 of the elements ("not understood further"); round 5
     # found the cause (scripts/diag_rotate_rules2.py, profiles/r05a_diag_rotate_rules2.jsonl): at the third step these rules have
