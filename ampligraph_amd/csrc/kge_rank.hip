@@ -1212,6 +1212,7 @@ __global__ void rank_compose_kernel(const int32_t* counts, const int32_t* sub, i
 }  // namespace kge
 #include "kge_rank_screen.h"
 #include "kge_rank_screen_g.h"
+#include "kge_rank_screen_r.h"
 constexpr int SCREEN_KERNEL_DEFAULT = 1;   // (see run_screen)
 #define KGE_RANK_EARLY_PART2
 #include "kge_rank_early.h"   // part 2: workspace, row flags, the exact recheck of the distance models
@@ -1295,13 +1296,26 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     // 256 CUs.  The run length is the one with the shortest schedule: rounds of 512 co-resident blocks x (tiles + ~0.35 of a
     // tile for a block's start-up) -- at C2 (160 x 227 tiles) runs of 9 gave 8.1 rounds, i.e. a ninth round for an eighth of the
     // chip; runs of 4 give 17.8 -> 18 rounds of 4: 78 tile-times instead of 84.
+    // Which screening kernel: rank_screen_kernel_v1 (rounds 3 - 5: query fragments L2 -> registers, entity slab register-staged through
+    // LDS), rank_screen_kernel_g (round 6, kge_rank_screen_g.h: both operands by LDS-DMA into a ring of stage buffers) or
+    // rank_screen_kernel_r (round 6, kge_rank_screen_r.h: one wave per SIMD, the query limbs resident in registers -- rows of 13 slabs,
+    // i.e. 385 .. 416 int8 units: ComplEx k = 200, DistMult k = 400).  The same counts every way; AMDKGE_SCREEN_KERNEL=1 / 3 / 4 pins
+    // one for A/B runs (read once).  Round 5's register-staged "both operands through LDS" form measured slower and lives in
+    // scripts/experiments/rank_screen_kernel_qlds_r05.h.
+    static const int screen_kernel_env = [] { const char* ev = getenv("AMDKGE_SCREEN_KERNEL"); const int v = ev ? atoi(ev) : 0; return (v == 1 || v == 3 || v == 4) ? v : SCREEN_KERNEL_DEFAULT; }();
+    int screen_kernel = screen_kernel_env;
+    if (screen_kernel == 4 && b.S != 13) screen_kernel = 1;
+    // co-resident workgroups and a block's start-up in tile-times: v1 / g two per CU, ~0.35; r one per CU, and its 39 KB of query limbs
+    // come first (~1 tile-time)
+    const int64_t slots = screen_kernel == 4 ? 256 : 512;
+    const double startup = screen_kernel == 4 ? 1.0 : 0.35;
     int64_t tiles_per = 1;
     {
         const int64_t qt8 = 8 * ((qtiles + 7) / 8), lim = etiles < 64 ? etiles : 64;
         double best = 1e300;
         for (int64_t tp = 1; tp <= lim; ++tp) {
             const int64_t blocks = qt8 * ((etiles + tp - 1) / tp);
-            const double cost = (double)((blocks + 511) / 512) * ((double)tp + 0.35);
+            const double cost = (double)((blocks + slots - 1) / slots) * ((double)tp + startup);
             if (cost <= best) { best = cost; tiles_per = tp; }   // (ties: the longer run)
         }
         // very large problems: keep the launch below 2^31 blocks and a lane's packed 16-bit counters (2 candidates per tile) in range
@@ -1314,20 +1328,18 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     sa.ent_per_block = (int)(tiles_per * SCR_ET); sa.qtiles = (int)qtiles; sa.splits = (int)splits;
     const int64_t nblk = 8 * ((qtiles + 7) / 8) * splits;
     if (nblk > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
-    // Which screening kernel: rank_screen_kernel_v1 (rounds 3 - 5: query fragments L2 -> registers, entity slab register-staged through
-    // LDS) or rank_screen_kernel_g (round 6, kge_rank_screen_g.h: both operands by LDS-DMA into a ring of stage buffers).  The same
-    // counts either way; AMDKGE_SCREEN_KERNEL=1 / 3 pins one for A/B runs (read once).  Round 5's register-staged "both operands
-    // through LDS" form measured slower and lives in scripts/experiments/rank_screen_kernel_qlds_r05.h.
     static PerDeviceOnce attr_done;
-    static const int screen_kernel = [] { const char* ev = getenv("AMDKGE_SCREEN_KERNEL"); const int v = ev ? atoi(ev) : 0; return (v == 1 || v == 3) ? v : SCREEN_KERNEL_DEFAULT; }();
     if (attr_done.need()) {
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_v1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_v1)");
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCG_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_g)");
+        if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_r<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCRR_LDS_BYTES))
+            return set_error_hip(e, "hipFuncSetAttribute(rank_screen_r)");
         attr_done.done();
     }
-    if (screen_kernel == 3) hipLaunchKernelGGL(rank_screen_kernel_g, dim3((unsigned)nblk), dim3(SCR_THREADS), SCG_LDS_BYTES, st, sa);
+    if (screen_kernel == 4) hipLaunchKernelGGL(rank_screen_kernel_r<13>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sa);
+    else if (screen_kernel == 3) hipLaunchKernelGGL(rank_screen_kernel_g, dim3((unsigned)nblk), dim3(SCR_THREADS), SCG_LDS_BYTES, st, sa);
     else hipLaunchKernelGGL(rank_screen_kernel_v1, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
     if (int rc = check_launch("rank_screen")) return rc;
     RecheckArgs ra{};

@@ -1,0 +1,366 @@
+// Round 6: the screening kernel restructured around ONE wave per SIMD with the QUERY operand resident in registers.
+// Included by kge_rank.hip behind kge_rank_screen.h, whose limbs / thresholds / recheck / merge kernels, ScreenArgs and error bound it
+// shares: the matrix work (six limb products in three exact int32 accumulator levels per output) and the decision arithmetic of the
+// epilogue are those of rank_screen_kernel_v1 -- the counts are the same integers.
+//
+// Why.  rank_screen_kernel_v1 (two 256-thread workgroups per CU, 233 registers) re-reads a wave's query fragments from L2 for every
+// entity tile -- 12 KB of the 18 KB a workgroup-stage moves -- and a wave-stage lasts ~1 900 cycles for 384 cycles of matrix work
+// (MfmaUtil 0.38-0.39 for three rounds; every ablation of one instruction class, the register-staged LDS form of round 5 and the LDS-DMA
+// ring of this round left it there: profiles/r06b_pmc_screen_v1.json / _g.json).  At the BASELINE widths (ComplEx k = 200, DistMult k =
+// 400: U = 400 int8 units = S = 13 slabs of 32) the three limbs of a wave's 32 query rows are 13 x 3 x 4 = 156 registers: with ONE wave
+// per SIMD gfx950's unified file gives a wave 512, so they are loaded ONCE per workgroup and stay.  What a stage then needs is the
+// entity slab only (6 KB per workgroup-stage instead of 18, L2 traffic a third), which arrives by LDS-DMA into a ring of eight 6 KB
+// buffers, SIX positions ahead (counted vmcnt; one raw s_barrier per stage), and whose fragments are read from LDS one stage ahead of
+// the matrix instructions that consume them.  Between two matrix instructions the wave issues ~2 other instructions instead of ~9.
+// The tile loop is unrolled over the S slabs (the query registers are indexed statically): one instantiation per S.
+#pragma once
+
+#ifndef SCRR_ABLATE
+#define SCRR_ABLATE 0   // development (scripts/build_variant.sh with EXTRA=-DSCRR_ABLATE=n): 1 no epilogue slices, 2 no matrix instructions, 4 no stage barrier, 8 no fold of the accumulators, 16 no DMA, 32 no fragment reads -- wrong counts, timing only
+#endif
+
+namespace kge {
+
+constexpr int SCRR_D = 6;                          // positions in flight ahead of the one being multiplied
+constexpr int SCRR_NB = 8;                         // ring buffers (>= D + 1; a power of two)
+constexpr int SCRR_PIECE = 1024;                   // bytes per DMA instruction: 64 lanes x 16
+constexpr int SCRR_STAGE = 6 * SCRR_PIECE;         // entity blocks 0, 1 x 3 limbs, as they lie in memory
+constexpr int SCRR_PEND = 256;                     // undecided pairs a wave parks in LDS before they go to the list
+constexpr int SCRR_EMB = 4;                        // candidate-meta buffers (by tile & 3)
+constexpr size_t SCRR_LDS_BYTES = (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + (size_t)SCRR_EMB * SCR_ET * 16 + 4 * (size_t)SCRR_PEND * 8;   // 65 536
+
+// One LDS-DMA instruction, scalar base + per-lane 32-bit offset: 64 lanes x 16 bytes to LDS bytes [lds, lds + 1 024) (M0 = the
+// wave-uniform LDS byte address; the hardware adds lane x 16).  Inline assembly on purpose (see kge_rank_screen_g.h): the compiler must
+// not know an LDS write is pending, the pieces are counted by hand.
+__device__ __forceinline__ void scrr_dma16(const char* sbase, uint32_t voff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
+
+// Scalar fp32 arithmetic the SLP vectoriser cannot pair into v_pk_*_f32 (see the epilogue slices): same IEEE operations, one result each.
+__device__ __forceinline__ float scrr_mul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float scrr_add(float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float scrr_sub(float a, float b) { float d; asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float scrr_fma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
+template <int N, typename F>
+__device__ __forceinline__ void scrr_static_for(F&& f) {
+    if constexpr (N > 0) {
+        scrr_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void rank_screen_kernel_r(ScreenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_scr[];   // (the ONE LDS object of the kernel)
+    float4* const qm_s = reinterpret_cast<float4*>(smem_scr + (size_t)SCRR_NB * SCRR_STAGE);
+    float4* const qt_s = qm_s + 128;
+    float4* const em_s = qt_s + 128;   // [SCRR_EMB][SCR_ET]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wq = wv * 32;
+    int bx, by;   // XCD-aware work order, as rank_screen_kernel_v1
+    {
+        const int xcd = blockIdx.x & 7;
+        const int64_t i = blockIdx.x >> 3;
+        const int qlo = (int)(((int64_t)a.qtiles * xcd) / 8), qhi = (int)(((int64_t)a.qtiles * (xcd + 1)) / 8);
+        const int nq = qhi - qlo;
+        if (i >= (int64_t)nq * a.splits) return;
+        const int full = nq / 8;
+        const int64_t per_group = (int64_t)8 * a.splits;
+        if (i < full * per_group) {
+            const int64_t r = i % per_group;
+            bx = qlo + (int)(i / per_group) * 8 + (int)(r & 7);
+            by = (int)(r >> 3);
+        } else {
+            const int rem = nq - full * 8;
+            const int64_t r = i - full * per_group;
+            bx = qlo + full * 8 + (int)(r % rem);
+            by = (int)(r / rem);
+        }
+    }
+    const int64_t q0 = (int64_t)bx * SCR_Q;
+    const int64_t e_begin = (int64_t)by * a.ent_per_block;
+    const int64_t e_end = min(a.m, e_begin + a.ent_per_block);
+    const int64_t ntile = (e_end - e_begin + SCR_ET - 1) / SCR_ET;
+
+    if (tid < 128) {   // per query row: the bound's constants and the four decision thresholds (see rank_screen_kernel_v1)
+        const bool okq = q0 + tid < a.n;
+        const float4 m4 = a.b.qm[okq ? q0 + tid : a.n - 1];
+        const float c = 1.f + 0x1p-10f;
+        qm_s[tid] = make_float4(m4.x * 65536.f, m4.y * c, m4.x * c, fmaf(a.drop, m4.x, m4.z) * c);
+        const float2 t2 = a.b.qt[okq ? q0 + tid : a.n - 1];
+        const float s1 = isfinite(t2.x) ? 0x1p-20f * fabsf(t2.x) : 0.f, s2 = isfinite(t2.y) ? 0x1p-20f * fabsf(t2.y) : 0.f;
+        qt_s[tid] = make_float4(t2.y + s2, t2.x - s1, t2.x + s1, t2.y - s2);
+    }
+    uint32_t rowmask = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowmask |= (q0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.n) ? (3u << (2 * r)) : 0u;
+
+    // ---- this wave's query fragments, all S slabs x 3 limbs: 39 coalesced 1 KB reads, once (rows beyond n: the stale tail of the last
+    // block -- finite integers; their outputs are masked)
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    const uint32_t blk_stride = (uint32_t)S * SCR_BLK_SLAB;   // bytes between consecutive 32-row blocks
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    v4i32 qf[S][3];
+    {
+        const char* const qsrc = reinterpret_cast<const char*>(a.b.qlimbs) + ((q0 + 32 * wv_s) >> 5) * (int64_t)blk_stride;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int lb = 0; lb < 3; ++lb) {
+                const uint4 u = *reinterpret_cast<const uint4*>(qsrc + ((size_t)s * SCR_BLK_SLAB + 1024u * lb + lane16));
+                qf[s][lb] = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w};
+            }
+    }
+    __syncthreads();   // (the last ordinary loads of the kernel are behind this barrier: from here on every VM operation is a DMA piece)
+
+    // ---- the DMA schedule.  Piece p of a stage image: entity block p / 3, limb p % 3.  Wave w issues piece w and a second one: waves
+    // 0, 1 the pieces 4, 5, waves 2, 3 the tile's 64 candidate metas (1 KB; both write the same bytes) -- two DMA instructions per
+    // wave and stage, all unconditional, so the counted wait is exact.
+    auto piece_off = [&](int p) -> uint32_t { return (uint32_t)(p / 3) * blk_stride + (uint32_t)(p % 3) * 1024u; };
+    const bool low = wv_s < 2;
+    const uint32_t vo0 = piece_off(wv_s) + lane16;
+    const uint32_t vo1 = (low ? piece_off(4 + wv_s) : 0u) + lane16;
+    const char* ebase = nullptr;   // slab ld_s of the loading tile's first block
+    const char* embase = nullptr;  // the loading tile's candidate metas
+    int ld_s = 0, ld_buf = 0;
+    int64_t ld_tile = 0;
+    auto set_src = [&](int64_t tile) {
+        const int64_t et = e_begin + tile * SCR_ET;
+        ebase = reinterpret_cast<const char*>(a.b.elimbs) + (et >> 5) * (int64_t)blk_stride;
+        embase = reinterpret_cast<const char*>(a.b.em + et);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_scr;
+    const uint32_t lds_em = lds0 + (uint32_t)(SCRR_NB * SCRR_STAGE + 2 * 128 * 16);
+    auto issue = [&]() {   // this wave's two pieces of the next position into ring buffer ld_buf
+        const uint32_t dst = lds0 + (uint32_t)ld_buf * SCRR_STAGE;
+        scrr_dma16(ebase, vo0, dst + (uint32_t)wv_s * SCRR_PIECE);
+        scrr_dma16(low ? ebase : embase, vo1, low ? dst + (uint32_t)(4 + wv_s) * SCRR_PIECE : lds_em + (uint32_t)(ld_tile & (SCRR_EMB - 1)) * (SCR_ET * 16));
+        ld_buf = (ld_buf + 1) & (SCRR_NB - 1);
+        ebase += SCR_BLK_SLAB;
+        if (++ld_s == S) {
+            ld_s = 0;
+            ld_tile = ld_tile + 1 < ntile ? ld_tile + 1 : ntile - 1;   // (past the end: harmless re-reads of the last tile)
+            set_src(ld_tile);
+        }
+    };
+
+    int cnt[16];   // per accumulator register (= query row of this lane): greater | equal << 16
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cnt[r] = 0;
+    v16i32 acc[3][2];   // [level][entity block]: level 0 = l0 l0', 1 = l0 l1' + l1 l0', 2 = l0 l2' + l1 l1' + l2 l0'
+
+    int npend = 0;   // pairs parked in this wave's LDS buffer (wave-uniform)
+    int2* const pend = reinterpret_cast<int2*>(em_s + SCRR_EMB * SCR_ET) + wv * SCRR_PEND;
+    auto flush = [&]() {   // (inline assembly with its own vmcnt(0): it also drains this wave's DMA pieces -- rare, and only stricter)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int b0 = 0;
+        if (lane == 63) asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(b0) : "v"(a.b.counter), "v"(npend) : "memory");
+        const int64_t base = __shfl(b0, 63, 64);
+        for (int i = lane; i < npend; i += 64) {
+            if (base + i < a.b.cap) {
+                const uint64_t v = *reinterpret_cast<const uint64_t*>(pend + i);
+                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(a.b.pairs + base + i), "v"(v) : "memory");
+            } else {   // the list is full: the call falls back to the exact kernel
+                const int one = 1;
+                asm volatile("global_store_dword %0, %1, off" :: "v"(a.b.counter + 1), "v"(one) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        npend = 0;
+    };
+    auto append = [&](uint32_t msk, int64_t et) {   // park the marked outputs (bit 2 r + ni of a lane) of this wave; <= SCRR_PEND of them
+        const int mine = __popc(msk);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
+        const int total = __shfl(incl, 63, 64);
+        if (!total) return;
+        if (npend + total > SCRR_PEND) flush();
+        int at = npend + incl - mine;
+        while (msk) {
+            const int bit = __builtin_ctz(msk);
+            msk &= msk - 1;
+            const int r = bit >> 1, ni = bit & 1;
+            pend[at++] = make_int2((int)(q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh), (int)(et + ni * 32 + l31));
+        }
+        npend += total;
+    };
+
+    // this lane's 16 bytes inside a 1 KB piece: [half][row]
+    const char* const frag_ptr = smem_scr + (lh * 512 + l31 * 16);
+    v4i32 eb[2][2][3];   // [stage parity][entity block][limb]: the fragments of the NEXT stage are read while this one multiplies
+    int rbuf = 0;        // ring buffer of the next fragment read
+    auto read_frag = [&](const char* sb, int piece, v4i32& f) __attribute__((always_inline)) {
+        const uint4 u = *reinterpret_cast<const uint4*>(sb + (size_t)piece * SCRR_PIECE);
+        f = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w};
+    };
+
+    set_src(0);
+#pragma unroll
+    for (int i = 0; i < SCRR_D; ++i) issue();   // positions 0 .. D - 1
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * (SCRR_D - 1)) : "memory");   // position 0 has landed: this wave's pieces, and everyone's
+#pragma unroll
+    for (int p = 0; p < 6; ++p) read_frag(frag_ptr, p, eb[0][p / 3][p % 3]);
+    rbuf = 1;
+    // the query fragments live in the accumulation half of the register file from here on (the matrix instruction reads its A operand
+    // there directly): the other half holds the accumulators, the entity fragments and the epilogue
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int lb = 0; lb < 3; ++lb) asm volatile("" : "+a"(qf[s][lb]));
+
+    // ---- the software pipeline.  Iteration t issues the matrix instructions of tile t and, BETWEEN them, the epilogue of tile t - 1
+    // in slices of a few instructions (one wave per SIMD: nobody else fills the 32 cycles a matrix instruction occupies the pipe; a
+    // wave that issues 156 of them back to back and its 700 epilogue instructions afterwards leaves the pipe idle half the time --
+    // measured: MfmaUtil 0.39 with the stages written out but the epilogue behind them).  At the end of a tile its three integer
+    // accumulator levels are folded into ONE fp32 value per output (F: 32 registers), which frees the accumulators for the next tile;
+    // everything else of the epilogue works on F.  Iteration 0 runs the slices on NaNs (nothing counted, the undecided marks dropped),
+    // iteration ntile runs the matrix instructions on a re-read tile (results unused).
+    // Every matrix instruction is its own inline-assembly statement (operand classes pinned: A in the accumulation file, B / C / D
+    // in the vector file -- no copies between the files), separated from the slice behind it by scheduling barriers.
+    // (scalar fp32 on purpose: a packed v_pk_*_f32 next to matrix instructions costs ~22 cycles more than the two scalar operations it
+    // replaces -- /opt/skills/guides/MI355X_MICROARCH.md, per-instruction constants; nine of them per row were ~3 000 cycles a tile)
+    float F0[16], F1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { F0[r] = __builtin_nanf(""); F1[r] = __builtin_nanf(""); }
+    float B20 = 0.f, B21 = 0.f, Y20 = 0.f, Y21 = 0.f, Z20 = 0.f, Z21 = 0.f;   // the previous tile's candidate constants
+    int64_t et_prev = e_begin;
+    const int row0 = wq + 4 * lh;
+    float4 qm = qm_s[row0], qt = qt_s[row0], qm_n = qm, qt_n = qt;
+    const float k65536 = 65536.f, k256 = 256.f;
+    float s00 = 0.f, s01 = 0.f, e0 = 0.f, e1 = 0.f, lo0 = 0.f, lo1 = 0.f, hi0 = 0.f, hi1 = 0.f;
+    uint32_t undm = 0u;
+
+    for (int t = 0; t <= (int)ntile; ++t) {
+        scrr_static_for<S>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int P = s & 1;
+            const char* sb = nullptr;
+            scrr_static_for<12>([&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int k = s * 12 + m;   // slot of the tile: 0 .. 12 S - 1
+                // (acc level, entity block, query limb, entity limb) of the stage's m-th matrix instruction: two on the SAME accumulator
+                // are never adjacent
+                constexpr int LV[12] = {0, 0, 2, 2, 1, 1, 2, 2, 1, 1, 2, 2};
+                constexpr int NI[12] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1};
+                constexpr int QL[12] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2};
+                constexpr int EL[12] = {0, 0, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0};
+                {
+                    v16i32& C = acc[LV[m]][NI[m]];
+                    const v4i32& A = qf[s][QL[m]];
+                    const v4i32& Bm = eb[P][NI[m]][EL[m]];
+                    if constexpr (SCRR_ABLATE & 2) asm volatile("" : "+v"(C) : "a"(A), "v"(Bm));
+                    else if constexpr (s == 0 && m < 6) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(C) : "a"(A), "v"(Bm));
+                    else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(C) : "a"(A), "v"(Bm));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- the stage's own work, spread over its first slots
+                if constexpr (m == 1) {
+                    // this wave's pieces of position g + 1 have landed (the D - 2 positions behind it stay in flight) and so have the
+                    // other waves'; everyone is past the matrix instructions that consumed position g - 2, whose buffer the DMA reuses
+                    if constexpr (SCRR_ABLATE & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (SCRR_D - 2)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * (SCRR_D - 2)) : "memory");
+                } else if constexpr (m == 2) {
+                    if constexpr (!(SCRR_ABLATE & 16)) issue();   // position g + D
+                    sb = frag_ptr + (size_t)rbuf * SCRR_STAGE;   // position g + 1
+                    rbuf = (rbuf + 1) & (SCRR_NB - 1);
+                } else if constexpr (m >= 3 && m <= 8) {
+                    if constexpr (!(SCRR_ABLATE & 32)) read_frag(sb, m - 3, eb[P ^ 1][(m - 3) / 3][(m - 3) % 3]);
+                }
+                // ---- slice k of the previous tile's epilogue: row k / 8 (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4
+                // (lane >> 5)), step k % 8; the arithmetic is rank_screen_kernel_v1's
+                if constexpr (k < 128 && !(SCRR_ABLATE & 1)) {
+                    constexpr int r = k >> 3, j = k & 7;
+                    if constexpr (j == 0) {
+                        if constexpr (r < 15) { constexpr int rn = ((r + 1) & 3) + 8 * ((r + 1) >> 2); qm_n = qm_s[row0 + rn]; qt_n = qt_s[row0 + rn]; }
+                    } else if constexpr (j == 1) {
+                        s00 = scrr_mul(F0[r], scrr_mul(qm.x, B20)); s01 = scrr_mul(F1[r], scrr_mul(qm.x, B21));   // S~ = f 2^16 A B
+                    } else if constexpr (j == 2) {
+                        // E' = c (gamma |W q|_2 |W e|_2 + A |e|_1 / 2 + B (|q|_1 / 2 + drop A)); the term relative to |S~| sits in the thresholds
+                        e0 = scrr_fma(qm.y, Y20, scrr_fma(qm.z, Z20, scrr_mul(qm.w, B20)));
+                        e1 = scrr_fma(qm.y, Y21, scrr_fma(qm.z, Z21, scrr_mul(qm.w, B21)));
+                    } else if constexpr (j == 3) {
+                        lo0 = scrr_sub(s00, e0); hi0 = scrr_add(s00, e0); lo1 = scrr_sub(s01, e1); hi1 = scrr_add(s01, e1);
+                    } else if constexpr (j == 4 || j == 6) {
+                        // greater: lo >= G; equal after quantisation: lo >= EL and hi < EH
+                        const float lo_ = j == 4 ? lo0 : lo1, hi_ = j == 4 ? hi0 : hi1;
+                        const bool gt = lo_ >= qt.x, eq = (lo_ >= qt.z) && (hi_ < qt.w);
+                        cnt[r] += gt ? 1 : 0;
+                        cnt[r] += eq ? 0x10000 : 0;
+                        asm volatile("" : "+v"(cnt[r]));
+                    } else if constexpr (j == 5 || j == 7) {
+                        // smaller: hi < L; neither of the three: undecided (NaN / infinite bounds compare false everywhere)
+                        constexpr int ni = (j - 5) >> 1;
+                        const float lo_ = j == 5 ? lo0 : lo1, hi_ = j == 5 ? hi0 : hi1;
+                        const bool gt = lo_ >= qt.x, lt = hi_ < qt.y, eq = (lo_ >= qt.z) && (hi_ < qt.w);
+                        undm |= !(gt || lt || eq) ? (1u << (2 * r + ni)) : 0u;
+                        asm volatile("" : "+v"(undm));
+                        if constexpr (j == 7) { qm = qm_n; qt = qt_n; }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        // A VALU read of a matrix instruction's result wants up to 19 wait states behind it (8 / 16 passes), and the compiler cannot see
+        // into the statements above.  The accumulators and the fragment set the copies below overwrite are operands of the pad: nothing
+        // that reads or rewrites them moves in front of it.
+        asm volatile("s_nop 15\n\ts_nop 7"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
+                       "+v"(eb[0][0][0]), "+v"(eb[0][0][1]), "+v"(eb[0][0][2]), "+v"(eb[0][1][0]), "+v"(eb[0][1][1]), "+v"(eb[0][1][2])
+                     :: "memory");
+        if constexpr (S & 1) {   // (an odd number of stages: the next tile's first fragments sit in the other parity)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int lb = 0; lb < 3; ++lb) eb[0][ni][lb] = eb[1][ni][lb];
+        }
+        // ---- the previous tile's undecided outputs go to the list
+        if (t >= 1) {
+            undm &= rowmask;
+            if (et_prev + l31 >= e_end) undm &= 0xAAAAAAAAu;        // candidate of block 0 beyond the range
+            if (et_prev + 32 + l31 >= e_end) undm &= 0x55555555u;   // candidate of block 1 beyond the range
+            if (__popcll(__ballot(undm != 0u)) <= SCRR_PEND / 32) append(undm, et_prev);   // (<= 32 outputs per lane)
+            else for (int ps = 0; ps < 8; ++ps) append(undm & (0xFu << (4 * ps)), et_prev);   // (<= 4 per lane: 256 per wave)
+        }
+        undm = 0u;
+        // ---- this tile's accumulators -> F = L0 2^16 + L1 2^8 + L2 (fp32), its candidates' constants -> B2, Y2, Z2
+        {
+            const int64_t et = e_begin + (int64_t)t * SCR_ET;
+            // the tile's candidate metas arrived with its first position (a DMA piece of waves 2, 3, behind that stage's barrier);
+            // candidates beyond the range get an infinite bound here: never decided, never counted
+            float4 E0 = em_s[(t & (SCRR_EMB - 1)) * SCR_ET + l31], E1 = em_s[(t & (SCRR_EMB - 1)) * SCR_ET + 32 + l31];
+            if (et + l31 >= e_end) E0.y = INFINITY;
+            if (et + 32 + l31 >= e_end) E1.y = INFINITY;
+            B20 = E0.x; B21 = E1.x; Y20 = E0.y; Y21 = E1.y; Z20 = E0.z; Z21 = E1.z;
+#pragma unroll
+            for (int r = 0; r < ((SCRR_ABLATE & 8) ? 1 : 16); ++r) {
+                F0[r] = scrr_fma((float)acc[0][0][r], k65536, scrr_fma((float)acc[1][0][r], k256, (float)acc[2][0][r]));
+                F1[r] = scrr_fma((float)acc[0][1][r], k65536, scrr_fma((float)acc[1][1][r], k256, (float)acc[2][1][r]));
+            }
+            et_prev = et;
+            qm = qm_s[row0]; qt = qt_s[row0];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the positions requested past the end: their DMA must not outlive the workgroup's LDS
+    if (npend) flush();
+    // ---- per query row: sum over the 32 lanes that share it ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int g = cnt[r] & 0xFFFF, e = cnt[r] >> 16;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); e += __shfl_xor(e, o, 64); }
+        const int64_t qi = q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (l31 == 0 && qi < a.n) {
+            if (g) atomicAdd(&a.b.counts[2 * qi + 0], g);
+            if (e) atomicAdd(&a.b.counts[2 * qi + 1], e);
+        }
+    }
+}
+
+}  // namespace kge

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void cols_loss_kernel(float* __restrict__ scor
                     const float n = sgn_scale * nj[(int64_t)j * B];
                     const float w = expf(L.alpha * n - mx) / se;
                     const float ell = log_sigmoid(-n - L.margin);
-                    nj[(int64_t)j * B] = (w * sigmoidf(n + L.margin) - L.alpha * w * (ell - lbar)) / red;
+                    nj[(int64_t)j * B] = computed_zero((w * sigmoidf(n + L.margin) - L.alpha * w * (ell - lbar)) / red, n);
                 }
                 per = -log_sigmoid(L.margin + P) - lbar / red;
                 dP = -sigmoidf(-(L.margin + P));

@@ -144,6 +144,11 @@ __device__ __forceinline__ float hinge_nan(float h) {
 __device__ __forceinline__ float masked_zero(float x) {
     return (fabsf(x) < INFINITY) ? 0.f : -0.f;
 }
+// The self-adversarial loss has no mask: its coefficient is COMPUTED, and for a score of -inf (a distance model's corruption that keeps a
+// row holding an inf) it is an exact zero -- softmax weight 0 times sigma(-inf) = 0 -- which TensorFlow again multiplies by the Jacobian.
+__device__ __forceinline__ float computed_zero(float c, float x) {
+    return (c == 0.f) ? masked_zero(x) : c;
+}
 // coeff: dL/dscore as the loss code left it; g = coeff * score_sign * score_scale.  No entry below fp32's smallest NORMAL number
 // (see the forward kernel) unless the coefficient is masked_zero's marker; a NaN coefficient is an entry.
 __device__ __forceinline__ bool entry_wanted(float coeff, float g) {
@@ -225,7 +230,7 @@ __device__ __forceinline__ void loss_and_dscore(const amdkge_loss& L, float P, f
                 const float n = sn[j];
                 const float w = expf(L.alpha * n - mx) / se;
                 const float ell = log_sigmoid(-n - L.margin);
-                sn[j] = (w * sigmoidf(n + L.margin) - L.alpha * w * (ell - lbar)) / red;
+                sn[j] = computed_zero((w * sigmoidf(n + L.margin) - L.alpha * w * (ell - lbar)) / red, n);
             }
             per = -log_sigmoid(L.margin + P) - lbar / red;
             dP = -sigmoidf(-(L.margin + P));
@@ -422,7 +427,7 @@ __device__ __forceinline__ void onepass_finish(const amdkge_loss& L, float P, fl
                 const float w = exp_any(det, L.alpha * n - st.m) / st.S;
                 float sg, ell;
                 sig_logsig(det, n + L.margin, sg, ell);
-                sn[j] = (w * sg - L.alpha * w * (ell - lbar)) / red;
+                sn[j] = computed_zero((w * sg - L.alpha * w * (ell - lbar)) / red, n);
             }
             float sgP, lsP;
             sig_logsig(det, -(L.margin + P), sgP, lsP);   // sigma(-(gamma+P)), log sigma(gamma+P)
