@@ -1213,7 +1213,7 @@ __global__ void rank_compose_kernel(const int32_t* counts, const int32_t* sub, i
 #include "kge_rank_screen.h"
 #include "kge_rank_screen_g.h"
 #include "kge_rank_screen_r.h"
-constexpr int SCREEN_KERNEL_DEFAULT = 1;   // (see run_screen)
+constexpr int SCREEN_KERNEL_DEFAULT = 4;   // (see run_screen: rank_screen_kernel_r where it applies -- 13-slab rows --, rank_screen_kernel_v1 elsewhere)
 #define KGE_RANK_EARLY_PART2
 #include "kge_rank_early.h"   // part 2: workspace, row flags, the exact recheck of the distance models
 namespace kge {
@@ -1275,10 +1275,26 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     if (hipError_t e = hipMemsetAsync(b.counter, 0, 256 + scr_up((size_t)n * 8), st)) return set_error_hip(e, "hipMemsetAsync(screen counters)");
     const double u = ldexp(1.0, -24), gam = u * (1.0 + 2.0 * (double)g.U * u);   // x |W q|_2 |W e|_2: the chain's rounding bound
     hipLaunchKernelGGL(rank_limbs_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.Q, (int64_t)g.QW, (const int32_t*)nullptr, (int64_t)0, n, g.U, b.S,
-                       (float)(gam * (1.0 + 1e-6)), b.qlimbs, b.qm);
+                       (float)(gam * (1.0 + 1e-6)), b.qlimbs, b.qm, (const int*)nullptr);
     if (int rc = check_launch("rank_limbs(Q)")) return rc;
-    hipLaunchKernelGGL(rank_limbs_kernel, dim3((unsigned)((mcand + 3) / 4)), dim3(256), 0, st, d_ent, (int64_t)g.K, d_ent_ids, ent_lo, mcand, g.U, b.S, 1.f,
-                       b.elimbs, b.em);
+    // (which screening kernel: see below; kernel r wants the candidates on one scale per tile of 64)
+    static const int screen_kernel_env = [] { const char* ev = getenv("AMDKGE_SCREEN_KERNEL"); const int v = ev ? atoi(ev) : 0; return (v == 1 || v == 3 || v == 4) ? v : SCREEN_KERNEL_DEFAULT; }();
+    int screen_kernel = screen_kernel_env;
+    if (screen_kernel == 4 && (b.S != 13 || b.cap * 8 < mcand * 16)) screen_kernel = 1;   // (13-slab rows; room for the row records)
+    if (screen_kernel == 4) {
+        // (the row records of the first pass live in the head of the pair list, unused until the screening kernel)
+        float4* const stats = reinterpret_cast<float4*>(b.pairs);
+        hipLaunchKernelGGL(rank_rowstats_kernel, dim3((unsigned)((mcand + 3) / 4)), dim3(256), 0, st, d_ent, (int64_t)g.K, d_ent_ids, ent_lo, mcand, g.U, stats);
+        if (int rc = check_launch("rank_rowstats(E)")) return rc;
+        hipLaunchKernelGGL(rank_limbs_tile_kernel, dim3((unsigned)(16 * ((mcand + 63) / 64))), dim3(256), 0, st, d_ent, (int64_t)g.K, d_ent_ids, ent_lo, mcand, g.U, b.S,
+                           (const float4*)stats, b.elimbs, b.em, b.tm, b.counter);
+        if (int rc = check_launch("rank_limbs_tile(E)")) return rc;
+        // (a wild table -- see screen_wild -- is redone on per-row scales for rank_screen_kernel_v1; otherwise this launch returns at once)
+        hipLaunchKernelGGL(rank_limbs_kernel, dim3((unsigned)std::min<int64_t>((mcand + 3) / 4, 512)), dim3(256), 0, st, d_ent, (int64_t)g.K, d_ent_ids, ent_lo, mcand, g.U, b.S, 1.f,
+                           b.elimbs, b.em, (const int*)b.counter);
+    } else
+        hipLaunchKernelGGL(rank_limbs_kernel, dim3((unsigned)((mcand + 3) / 4)), dim3(256), 0, st, d_ent, (int64_t)g.K, d_ent_ids, ent_lo, mcand, g.U, b.S, 1.f,
+                           b.elimbs, b.em, (const int*)nullptr);
     if (int rc = check_launch("rank_limbs(E)")) return rc;
     hipLaunchKernelGGL(rank_thresholds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.qpos, n, sgn_scale, b.qt);
     if (int rc = check_launch("rank_thresholds")) return rc;
@@ -1292,53 +1308,60 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     // U <= 2048; the outer fma's rounding is relative to |f| and sits in the thresholds)
     sa.drop = (float)(((double)g.U * (8388608.0 + 16384.0 + 0.25) + 134217728.0) * (1.0 + 1e-6));
     const int64_t qtiles = (n + SCR_Q - 1) / SCR_Q, etiles = (mcand + SCR_ET - 1) / SCR_ET;
-    // Each block takes a run of entity tiles of one 128-query block (its query fragments stay in L1 / L2); two workgroups per CU,
-    // 256 CUs.  The run length is the one with the shortest schedule: rounds of 512 co-resident blocks x (tiles + ~0.35 of a
-    // tile for a block's start-up) -- at C2 (160 x 227 tiles) runs of 9 gave 8.1 rounds, i.e. a ninth round for an eighth of the
-    // chip; runs of 4 give 17.8 -> 18 rounds of 4: 78 tile-times instead of 84.
     // Which screening kernel: rank_screen_kernel_v1 (rounds 3 - 5: query fragments L2 -> registers, entity slab register-staged through
     // LDS), rank_screen_kernel_g (round 6, kge_rank_screen_g.h: both operands by LDS-DMA into a ring of stage buffers) or
     // rank_screen_kernel_r (round 6, kge_rank_screen_r.h: one wave per SIMD, the query limbs resident in registers -- rows of 13 slabs,
     // i.e. 385 .. 416 int8 units: ComplEx k = 200, DistMult k = 400).  The same counts every way; AMDKGE_SCREEN_KERNEL=1 / 3 / 4 pins
     // one for A/B runs (read once).  Round 5's register-staged "both operands through LDS" form measured slower and lives in
     // scripts/experiments/rank_screen_kernel_qlds_r05.h.
-    static const int screen_kernel_env = [] { const char* ev = getenv("AMDKGE_SCREEN_KERNEL"); const int v = ev ? atoi(ev) : 0; return (v == 1 || v == 3 || v == 4) ? v : SCREEN_KERNEL_DEFAULT; }();
-    int screen_kernel = screen_kernel_env;
-    if (screen_kernel == 4 && b.S != 13) screen_kernel = 1;
-    // co-resident workgroups and a block's start-up in tile-times: v1 / g two per CU, ~0.35; r one per CU, and its 39 KB of query limbs
-    // come first (~1 tile-time)
-    const int64_t slots = screen_kernel == 4 ? 256 : 512;
-    const double startup = screen_kernel == 4 ? 1.0 : 0.35;
-    int64_t tiles_per = 1;
-    {
-        const int64_t qt8 = 8 * ((qtiles + 7) / 8), lim = etiles < 64 ? etiles : 64;
+    // Each block takes a run of entity tiles of one 128-query block.  The run length is the one with the shortest schedule: rounds of
+    // `slots` co-resident blocks x (tiles + a block's start-up in tile-times) -- v1 / g: two workgroups per CU, ~0.35 (at C2, 160 x 227
+    // tiles, runs of 4 give 18 rounds of 4: 78 tile-times instead of 84 with runs of 9); r: one per CU, and its 39 KB of query limbs come
+    // first (~1 tile-time).
+    static const int64_t run_cap = [] { const char* ev = getenv("AMDKGE_SCREEN_RUN"); const int v = ev ? atoi(ev) : 0; return (int64_t)(v > 0 ? v : 64); }();   // (A/B runs: longest run of tiles per block)
+    auto schedule = [&](ScreenArgs& x, int64_t slots, double startup, int64_t& nblk) -> bool {
+        int64_t tiles_per = 1;
+        const int64_t qt8 = 8 * ((qtiles + 7) / 8), lim = etiles < run_cap ? etiles : run_cap;
         double best = 1e300;
         for (int64_t tp = 1; tp <= lim; ++tp) {
             const int64_t blocks = qt8 * ((etiles + tp - 1) / tp);
             const double cost = (double)((blocks + slots - 1) / slots) * ((double)tp + startup);
             if (cost <= best) { best = cost; tiles_per = tp; }   // (ties: the longer run)
         }
-        // very large problems: keep the launch below 2^31 blocks and a lane's packed 16-bit counters (2 candidates per tile) in range
+        // very large problems: keep the launch below 2^31 blocks and a lane's 16-bit counters (2 candidates per tile) in range
         while (tiles_per < etiles && tiles_per < 16384 && qt8 * ((etiles + tiles_per - 1) / tiles_per) > (1ll << 24)) tiles_per *= 2;
         if (tiles_per > 16384) tiles_per = 16384;
         if (tiles_per > etiles) tiles_per = etiles;
         if (tiles_per < 1) tiles_per = 1;
-    }
-    const int64_t splits = (etiles + tiles_per - 1) / tiles_per;
-    sa.ent_per_block = (int)(tiles_per * SCR_ET); sa.qtiles = (int)qtiles; sa.splits = (int)splits;
-    const int64_t nblk = 8 * ((qtiles + 7) / 8) * splits;
-    if (nblk > 0x7FFFFFFFll) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
+        const int64_t splits = (etiles + tiles_per - 1) / tiles_per;
+        x.ent_per_block = (int)(tiles_per * SCR_ET); x.qtiles = (int)qtiles; x.splits = (int)splits;
+        nblk = qt8 * splits;
+        return nblk <= 0x7FFFFFFFll;
+    };
     static PerDeviceOnce attr_done;
     if (attr_done.need()) {
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_v1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_v1)");
+        if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_v1_wild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES))
+            return set_error_hip(e, "hipFuncSetAttribute(rank_screen_v1_wild)");
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCG_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_g)");
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_r<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCRR_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_r)");
         attr_done.done();
     }
-    if (screen_kernel == 4) hipLaunchKernelGGL(rank_screen_kernel_r<13>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sa);
+    int64_t nblk = 0;
+    if (screen_kernel == 4) {
+        ScreenArgs sr = sa;
+        sr.wild_mode = 2;
+        if (!schedule(sr, 256, 1.0, nblk)) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
+        hipLaunchKernelGGL(rank_screen_kernel_r<13>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sr);
+        if (int rc = check_launch("rank_screen_r")) return rc;
+    }
+    if (!schedule(sa, 512, 0.35, nblk)) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
+    sa.nblk = (int)nblk;
+    if (screen_kernel == 4)   // (the per-row-scale kernel behind rank_screen_kernel_r: a wild table only)
+        hipLaunchKernelGGL(rank_screen_kernel_v1_wild, dim3((unsigned)std::min<int64_t>(nblk, 512)), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
     else if (screen_kernel == 3) hipLaunchKernelGGL(rank_screen_kernel_g, dim3((unsigned)nblk), dim3(SCR_THREADS), SCG_LDS_BYTES, st, sa);
     else hipLaunchKernelGGL(rank_screen_kernel_v1, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
     if (int rc = check_launch("rank_screen")) return rc;

@@ -41,13 +41,14 @@ constexpr int SCR_ROW_SLAB = 96;                       // bytes of one row per K
 constexpr int SCR_BLK_SLAB = 32 * SCR_ROW_SLAB;        // bytes of one 32-row block per K slab (3 072)
 
 struct ScreenBufs {
-    int* counter;        // [0] undecided pairs appended, [1] overflow flag
+    int* counter;        // [0] undecided pairs appended, [1] overflow flag, [2] candidate rows > 4 bits below their tile's scale (rank_limbs_tile_kernel)
     int32_t* counts;     // [n][2] this call's (greater, equal) counts (merged into the caller's unless the call fell back)
     int8_t* qlimbs;      // [ceil(n / 32)][S][3][2][32][16]
     float4* qm;          // [n] {A = 2^-a, u (1 + 2 U u) |W q|_2, |q|_1 / 2, 0}, all rounded up
     float2* qt;          // [n] {T_ge, T_gt}
     int8_t* elimbs;      // [ceil(m / 32)][S][3][2][32][16]
     float4* em;          // [m] {B, |W e|_2, |e|_1 / 2, 0}
+    float4* tm;          // [ceil(m / 64)] per tile of 64 candidates {B_t, max |W e|_2, max |e|_1 / 2, 1 / B_t}: rank_limbs_tile_kernel (kernel r)
     int2* pairs;         // [cap] (query, candidate position)
     int64_t cap;
     int S;               // K slabs per row
@@ -60,7 +61,7 @@ static inline size_t screen_fixed_bytes(int64_t n, int64_t m, int U) {
     const size_t S = (size_t)(U + SCR_K - 1) / SCR_K;
     const size_t nb = (size_t)(n + 31) / 32 + 4, mb = (size_t)(m + 31) / 32 + 4;   // (+ a tile of slack: loaders read whole 128-row tiles)
     return 256 + scr_up((size_t)n * 8) + scr_up(nb * S * SCR_BLK_SLAB) + scr_up((size_t)n * 16) + scr_up((size_t)n * 8) +
-           scr_up(mb * S * SCR_BLK_SLAB) + scr_up((size_t)m * 16);
+           scr_up(mb * S * SCR_BLK_SLAB) + scr_up((size_t)m * 16) + scr_up(((size_t)(m + 63) / 64 + 4) * 16);
 }
 
 static inline ScreenBufs carve_screen(void* d_screen, size_t bytes, int64_t n, int64_t m, int U) {
@@ -75,6 +76,7 @@ static inline ScreenBufs carve_screen(void* d_screen, size_t bytes, int64_t n, i
     b.qt = (float2*)p; p += scr_up((size_t)n * 8);
     b.elimbs = (int8_t*)p; p += scr_up(((size_t)(m + 31) / 32 + 4) * b.S * SCR_BLK_SLAB);
     b.em = (float4*)p; p += scr_up((size_t)m * 16);
+    b.tm = (float4*)p; p += scr_up(((size_t)(m + 63) / 64 + 4) * 16);
     b.pairs = (int2*)p;
     b.cap = end > p ? (int64_t)((end - p) / 8) : 0;
     return b;
@@ -83,11 +85,19 @@ static inline ScreenBufs carve_screen(void* d_screen, size_t bytes, int64_t n, i
 // ---- 1. rows -> fixed point limbs + norms: one wave per row --------------------------------------------------------------------
 // src row r: table[ids ? ids[lo + r] : lo + r] (stride K floats), U units walked (whole float4s: U % 4 == 0).
 // out: limbs in the fragment-major layout (units beyond U are zero), meta[r] = {scale, n2 * gamma (gamma = 1 for the entity side), n1 / 2, 0}.
+// "Wild" candidate table: more than 1 / 64 of its rows lie > 4 bits below the scale of their tile of 64 (rank_limbs_tile_kernel counts
+// them).  rank_screen_kernel_r's tile-wide scale would leave such rows without significant bits and send their outputs to the recheck
+// list; the per-row scales of rank_limbs_kernel + rank_screen_kernel_v1 take the call instead.  Decided on the device: the kernels of
+// both paths are launched, the ones of the path not taken return at once.
+__device__ __forceinline__ bool screen_wild(const int* counter, int64_t m) { return (int64_t)counter[2] * 64 > m; }
+
 __global__ __launch_bounds__(256) void rank_limbs_kernel(const float* __restrict__ table, int64_t stride, const int32_t* __restrict__ ids, int64_t lo,
-                                                         int64_t nrows, int U, int S, float gamma, int8_t* __restrict__ limbs, float4* __restrict__ meta) {
+                                                         int64_t nrows, int U, int S, float gamma, int8_t* __restrict__ limbs, float4* __restrict__ meta,
+                                                         const int* __restrict__ only_if_wild = nullptr) {
+    // (only_if_wild: the fall-back behind rank_limbs_tile_kernel -- a small persistent grid that walks the rows only for a wild table)
+    if (only_if_wild && !screen_wild(only_if_wild, nrows)) return;
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= nrows) return;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < nrows; r += (int64_t)gridDim.x * 4) {
     const int64_t id = ids ? (int64_t)ids[lo + r] : lo + r;
     const float4* row = reinterpret_cast<const float4*>(table + id * stride);
     const int nq = U >> 2;
@@ -141,6 +151,104 @@ __global__ __launch_bounds__(256) void rank_limbs_kernel(const float* __restrict
         uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)slab * SCR_BLK_SLAB + (w >> 2) * 512) + (w & 3);
         o[0] = p0; o[256] = p1; o[512] = p2;
     }
+    }
+}
+
+// ---- 1b. the candidate rows with ONE scale per tile of 64 candidate positions (rank_screen_kernel_r: a tile's outputs then share
+// their scale with their query row only, and the decision thresholds of a (query row, tile) can be put into the accumulators' own
+// integer units once instead of scaling every output).  Two passes, one wave per row each: rank_rowstats_kernel (largest magnitude,
+// norms, "holds inf / NaN"), then rank_limbs_tile_kernel: every wave reads the 64 row records of its tile (lane = row), derives the
+// tile's scale from its largest finite row and puts its own row on that grid.  Row metas as rank_limbs_kernel's (meta.x = the TILE's
+// scale), limbs POSITION-major: [tile][slab][block of the tile][limb][half][row % 32][16 bytes] (6 144 bytes per (tile, slab): what
+// rank_screen_kernel_r's loader moves per stage); tmeta[tile] = {B_t, max |W e|_2, max |e|_1 / 2, 1 / B_t} over the tile's rows (an
+// inf / NaN row: infinite maxima -- the tile's outputs all go to the exact recheck); counter[2] += rows > 4 bits below their tile's
+// scale (screen_wild).
+__global__ __launch_bounds__(256) void rank_rowstats_kernel(const float* __restrict__ table, int64_t stride, const int32_t* __restrict__ ids, int64_t lo,
+                                                            int64_t nrows, int U, float4* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int64_t id = ids ? (int64_t)ids[lo + r] : lo + r;
+    const float4* row = reinterpret_cast<const float4*>(table + id * stride);
+    const int nq = U >> 2;
+    float mx = 0.f, n1 = 0.f, n2 = 0.f;
+    bool bad = false;
+    for (int q = lane; q < nq; q += 64) {
+        const float4 t = row[q];
+        const float a0 = fabsf(t.x), a1 = fabsf(t.y), a2 = fabsf(t.z), a3 = fabsf(t.w);
+        bad |= !(a0 < INFINITY) || !(a1 < INFINITY) || !(a2 < INFINITY) || !(a3 < INFINITY);
+        mx = fmaxf(fmaxf(mx, fmaxf(a0, a1)), fmaxf(a2, a3));
+        n1 += (a0 + a1) + (a2 + a3);
+        const float w = (float)(U - 4 * q);   // (position-weighted square norm: see rank_limbs_kernel)
+        n2 = fmaf(w * a0, a0, fmaf((w - 1.f) * a1, a1, fmaf((w - 2.f) * a2, a2, fmaf((w - 3.f) * a3, a3, n2))));
+    }
+    mx = wave_max(mx);
+    n1 = wave_sum_shfl(n1);
+    n2 = wave_sum_shfl(n2);
+    bad = __ballot(bad) != 0ull;
+    if (lane == 0) stats[r] = make_float4(bad ? 0.f : mx, n1, n2, bad ? 1.f : 0.f);
+}
+
+__global__ __launch_bounds__(256) void rank_limbs_tile_kernel(const float* __restrict__ table, int64_t stride, const int32_t* __restrict__ ids, int64_t lo,
+                                                              int64_t nrows, int U, int S, const float4* __restrict__ stats, int8_t* __restrict__ limbs,
+                                                              float4* __restrict__ meta, float4* __restrict__ tmeta, int* __restrict__ counter) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (rows up to the end of the last tile: zero limbs beyond the range)
+    const int64_t tile = r >> 6;
+    if (tile * 64 >= nrows) return;
+    // the tile's 64 row records, one per lane
+    const int64_t lr_row = tile * 64 + lane;
+    const bool have = lr_row < nrows;
+    const float4 st = have ? stats[lr_row] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool lbad = st.w != 0.f;
+    // the tile's scale: |x| * 2^a <= 2^22 for every unit of every finite row (limb l0 within +-65); all-zero tile: a = 0
+    const float tmx = wave_max(st.x);
+    int ex = 0;
+    if (tmx > 0.f) (void)frexpf(tmx, &ex);
+    int a = 22 - ex;
+    a = a > 120 ? 120 : (a < -100 ? -100 : a);
+    const float up = ldexpf(1.f, a), A = ldexpf(1.f, -a);
+    const bool tile_bad = tmx * up > 4194304.f;   // (the clamp of `a` bit: nothing of this tile is representable)
+    const float infl = 1.f + 0x1p-10f;
+    float m_n2 = sqrtf(st.z) * infl * infl, m_n1 = 0.5f * st.y * infl;
+    if (lbad || tile_bad) { m_n2 = INFINITY; m_n1 = INFINITY; }
+    const int mine = (int)(r & 63);   // this wave's row inside the tile
+    if (mine == 0) {   // the tile's first wave writes the row metas and the tile record
+        if (have) meta[lr_row] = make_float4(A, m_n2, m_n1, 0.f);
+        const float t2 = wave_max(have ? m_n2 : 0.f), t1 = wave_max(have ? m_n1 : 0.f);
+        int exr = 0;
+        if (st.x > 0.f) (void)frexpf(st.x, &exr);
+        const bool far = have && !lbad && !tile_bad && st.x > 0.f && (ex - exr) > 4;   // own scale > 4 bits finer than the tile's (see screen_wild)
+        const int nfar = __popcll(__ballot(far));
+        if (lane == 0) {
+            tmeta[tile] = make_float4(A, t2, t1, up);
+            if (nfar) atomicAdd(counter + 2, nfar);
+        }
+    }
+    const bool rbad = __shfl(lbad ? 1 : 0, mine, 64) != 0;
+    const bool live = r < nrows && !rbad && !tile_bad;
+    const int64_t id = r < nrows ? (ids ? (int64_t)ids[lo + r] : lo + r) : 0;
+    const float4* row = reinterpret_cast<const float4*>(table + id * stride);
+    const int nq = U >> 2;
+    int8_t* out = limbs + tile * (int64_t)S * (2 * SCR_BLK_SLAB) + (mine >> 5) * SCR_BLK_SLAB + (mine & 31) * 16;
+    for (int q = lane; q < S * 8; q += 64) {   // 4 units per step, 8 steps per slab (rows beyond the range / non-finite rows: zeros)
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq && live) t = row[q];
+        int v[4] = {(int)rintf(t.x * up), (int)rintf(t.y * up), (int)rintf(t.z * up), (int)rintf(t.w * up)};
+        uint32_t p0 = 0, p1 = 0, p2 = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // balanced base-256 digits: v = l0 2^16 + l1 2^8 + l2, l1, l2 in [-128, 127], |l0| <= 65
+            const int l2 = ((v[c] + 128) & 255) - 128;
+            const int v1 = (v[c] - l2) >> 8;
+            const int l1 = ((v1 + 128) & 255) - 128;
+            const int l0 = (v1 - l1) >> 8;
+            p0 |= (uint32_t)(l0 & 255) << (8 * c); p1 |= (uint32_t)(l1 & 255) << (8 * c); p2 |= (uint32_t)(l2 & 255) << (8 * c);
+        }
+        const int slab = q >> 3, w = q & 7;
+        uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)slab * (2 * SCR_BLK_SLAB) + (w >> 2) * 512) + (w & 3);
+        o[0] = p0; o[256] = p1; o[512] = p2;
+    }
 }
 
 // ---- thresholds: smallest fp32 S with quantise(sgn_scale * S) >= target, by bisection over the ordered bit patterns ----------
@@ -171,6 +279,8 @@ struct ScreenArgs {
     int qtiles, splits;
     int U;
     float drop;            // U * (2^23 + 2^14 + 1/4)
+    int wild_mode;         // 0: run; 2: run only if the tile-scale pass found the candidate table NOT wild (screen_wild; rank_screen_kernel_r)
+    int nblk;              // rank_screen_kernel_v1_wild: virtual blocks of the ordinary launch
 };
 
 constexpr int SCR_THREADS = 256;   // 4 waves, each a 32-query block against the workgroup's 64-entity tile; TWO workgroups per CU
@@ -184,7 +294,9 @@ constexpr size_t SCR_LDS_BYTES = (size_t)2 * 3 * 2 * SCR_ET * 16 + 128 * 16 + 12
 // ENTITY slab, shared by the workgroup's four query blocks, is staged through LDS in the same order (a fragment read is 512
 // contiguous bytes per half-wave).  Two 256-thread workgroups share a CU (2 waves per SIMD, 256 registers each) and run out of
 // phase: one's epilogue (VALU) under the other's matrix work.
-__global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel_v1(ScreenArgs a) {
+// (the kernel's body, for one workgroup's share `vblock` of the launch: rank_screen_kernel_v1 runs it once per workgroup,
+// rank_screen_kernel_v1_wild -- the fall-back behind rank_screen_kernel_r -- in a loop over a small persistent grid)
+__device__ __forceinline__ void rank_screen_v1_body(const ScreenArgs& a, const int vblock) {
     extern __shared__ __attribute__((aligned(16))) char smem_scr[];
     typedef uint4 (*slab_t)[2][3][2][32];   // [buffer][entity block][limb][half][row]: a buffer is the two blocks' slabs back to back
     slab_t Es = reinterpret_cast<slab_t>(smem_scr);
@@ -197,8 +309,8 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel_v1(ScreenAr
     const int wq = wv * 32;
     int bx, by;   // XCD-aware work order, as rank_count_mfma_kernel
     {
-        const int xcd = blockIdx.x & 7;
-        const int64_t i = blockIdx.x >> 3;
+        const int xcd = vblock & 7;
+        const int64_t i = vblock >> 3;
         const int qlo = (int)(((int64_t)a.qtiles * xcd) / 8), qhi = (int)(((int64_t)a.qtiles * (xcd + 1)) / 8);
         const int nq = qhi - qlo;
         if (i >= (int64_t)nq * a.splits) return;
@@ -467,6 +579,22 @@ __global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel_v1(ScreenAr
             if (g) atomicAdd(&a.b.counts[2 * qi + 0], g);
             if (e) atomicAdd(&a.b.counts[2 * qi + 1], e);
         }
+    }
+}
+
+__global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel_v1(ScreenArgs a) {
+    rank_screen_v1_body(a, (int)blockIdx.x);
+}
+
+// The per-row-scale path behind rank_screen_kernel_r (a.wild_mode == 1): it has work only when the tile-scale pass found the candidate
+// table wild (screen_wild) -- decided on the device, so the launch always happens.  A launch of thousands of workgroups that each read
+// a flag and leave still costs ~100 us on a busy device (every workgroup waits for a slot): this one is a few hundred persistent
+// workgroups that walk the virtual blocks a.nblk of the ordinary launch.
+__global__ __launch_bounds__(SCR_THREADS, 2) void rank_screen_kernel_v1_wild(ScreenArgs a) {
+    if (!screen_wild(a.b.counter, a.m)) return;
+    for (int vb = (int)blockIdx.x; vb < a.nblk; vb += (int)gridDim.x) {
+        rank_screen_v1_body(a, vb);
+        __syncthreads();   // (the next share rewrites the workgroup's LDS tables)
     }
 }
 

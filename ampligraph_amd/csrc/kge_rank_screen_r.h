@@ -21,13 +21,16 @@
 
 namespace kge {
 
-constexpr int SCRR_D = 6;                          // positions in flight ahead of the one being multiplied
-constexpr int SCRR_NB = 8;                         // ring buffers (>= D + 1; a power of two)
+#ifndef SCRR_DEPTH
+#define SCRR_DEPTH 6
+#endif
+constexpr int SCRR_D = SCRR_DEPTH;                 // positions in flight ahead of the one being multiplied (even)
+constexpr int SCRR_NB = SCRR_DEPTH <= 6 ? 8 : 16;  // ring buffers (>= D + 2; a power of two)
 constexpr int SCRR_PIECE = 1024;                   // bytes per DMA instruction: 64 lanes x 16
 constexpr int SCRR_STAGE = 6 * SCRR_PIECE;         // entity blocks 0, 1 x 3 limbs, as they lie in memory
+constexpr int SCRR_NONE = -(1 << 30);               // "no output here" in the folded accumulators' units (|g| < 2^29.1 for S <= 13; thresholds live in (-2^30, 2^30])
 constexpr int SCRR_PEND = 256;                     // undecided pairs a wave parks in LDS before they go to the list
-constexpr int SCRR_EMB = 4;                        // candidate-meta buffers (by tile & 3)
-constexpr size_t SCRR_LDS_BYTES = (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + (size_t)SCRR_EMB * SCR_ET * 16 + 4 * (size_t)SCRR_PEND * 8;   // 65 536
+constexpr size_t SCRR_LDS_BYTES = (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + 4 * (size_t)SCRR_PEND * 8;   // 61 440: ring, thresholds, parked pairs
 
 // One LDS-DMA instruction, scalar base + per-lane 32-bit offset: 64 lanes x 16 bytes to LDS bytes [lds, lds + 1 024) (M0 = the
 // wave-uniform LDS byte address; the hardware adds lane x 16).  Inline assembly on purpose (see kge_rank_screen_g.h): the compiler must
@@ -53,10 +56,9 @@ __device__ __forceinline__ void scrr_static_for(F&& f) {
 template <int S>
 __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void rank_screen_kernel_r(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_scr[];   // (the ONE LDS object of the kernel)
-    float4* const qm_s = reinterpret_cast<float4*>(smem_scr + (size_t)SCRR_NB * SCRR_STAGE);
-    float4* const qt_s = qm_s + 128;
-    float4* const em_s = qt_s + 128;   // [SCRR_EMB][SCR_ET]
+    int4* const thr_s = reinterpret_cast<int4*>(smem_scr + (size_t)SCRR_NB * SCRR_STAGE);   // [2][128]: (query row, tile)'s integer thresholds, by tile parity
 
+    if (a.wild_mode == 2 && screen_wild(a.b.counter, a.m)) return;   // (rows far below their tile's scale: the per-row-scale path takes the call)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wq = wv * 32;
@@ -85,14 +87,26 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     const int64_t e_end = min(a.m, e_begin + a.ent_per_block);
     const int64_t ntile = (e_end - e_begin + SCR_ET - 1) / SCR_ET;
 
-    if (tid < 128) {   // per query row: the bound's constants and the four decision thresholds (see rank_screen_kernel_v1)
-        const bool okq = q0 + tid < a.n;
-        const float4 m4 = a.b.qm[okq ? q0 + tid : a.n - 1];
+    // ---- this THREAD's query row (tid & 127) and pair of thresholds (waves 0, 1: greater / smaller; waves 2, 3: the two ends of
+    // "equal"), for the whole block: per tile it turns them into integer thresholds in the accumulators' units (below).
+    // {c gamma |q|_2,  c A,  c (|q|_1 / 2 + drop A)} inflated by c = 1 + 2^-10 as in rank_screen_kernel_v1; 1 / (2^24 A): a power of two.
+    float rq_y, rq_z, rq_w, rq_iA, thrA, thrB;
+    {
+        const int row = tid & 127;
+        const bool okq = q0 + row < a.n;
+        const float4 m4 = a.b.qm[okq ? q0 + row : a.n - 1];
         const float c = 1.f + 0x1p-10f;
-        qm_s[tid] = make_float4(m4.x * 65536.f, m4.y * c, m4.x * c, fmaf(a.drop, m4.x, m4.z) * c);
-        const float2 t2 = a.b.qt[okq ? q0 + tid : a.n - 1];
+        rq_y = m4.y * c; rq_z = m4.x * c; rq_w = fmaf(a.drop, m4.x, m4.z) * c;
+        rq_iA = 0x1p-24f / m4.x;
+        // the relative part of the epilogue's roundings sits in the thresholds (2^-20 |T|, see rank_screen_kernel_v1); non-finite
+        // thresholds (nothing can be greater / smaller) stay
+        const float2 t2 = a.b.qt[okq ? q0 + row : a.n - 1];
         const float s1 = isfinite(t2.x) ? 0x1p-20f * fabsf(t2.x) : 0.f, s2 = isfinite(t2.y) ? 0x1p-20f * fabsf(t2.y) : 0.f;
-        qt_s[tid] = make_float4(t2.y + s2, t2.x - s1, t2.x + s1, t2.y - s2);
+        thrA = (tid < 128) ? t2.y + s2 : t2.x + s1;   // G  (greater: S - E >= G)      | EL (equal: S - E >= EL ...
+        thrB = (tid < 128) ? t2.x - s1 : t2.y - s2;   // L  (smaller: S + E <  L)      | EH  ... and S + E < EH)
+        // (both parities start as "nothing decided": iteration 0 runs the slices on an empty tile)
+        thr_s[row] = make_int4(1 << 30, -1073741760, 1 << 30, -1073741760);
+        thr_s[128 + row] = make_int4(1 << 30, -1073741760, 1 << 30, -1073741760);
     }
     uint32_t rowmask = 0u;
 #pragma unroll
@@ -116,44 +130,43 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     }
     __syncthreads();   // (the last ordinary loads of the kernel are behind this barrier: from here on every VM operation is a DMA piece)
 
-    // ---- the DMA schedule.  Piece p of a stage image: entity block p / 3, limb p % 3.  Wave w issues piece w and a second one: waves
-    // 0, 1 the pieces 4, 5, waves 2, 3 the tile's 64 candidate metas (1 KB; both write the same bytes) -- two DMA instructions per
-    // wave and stage, all unconditional, so the counted wait is exact.
-    auto piece_off = [&](int p) -> uint32_t { return (uint32_t)(p / 3) * blk_stride + (uint32_t)(p % 3) * 1024u; };
-    const bool low = wv_s < 2;
-    const uint32_t vo0 = piece_off(wv_s) + lane16;
-    const uint32_t vo1 = (low ? piece_off(4 + wv_s) : 0u) + lane16;
-    const char* ebase = nullptr;   // slab ld_s of the loading tile's first block
-    const char* embase = nullptr;  // the loading tile's candidate metas
-    int ld_s = 0, ld_buf = 0;
-    int64_t ld_tile = 0;
-    auto set_src = [&](int64_t tile) {
-        const int64_t et = e_begin + tile * SCR_ET;
-        ebase = reinterpret_cast<const char*>(a.b.elimbs) + (et >> 5) * (int64_t)blk_stride;
-        embase = reinterpret_cast<const char*>(a.b.em + et);
-    };
+    // ---- the DMA schedule.  rank_limbs_tile_kernel lays the candidates' limbs out POSITION-major: [tile of 64][slab][block 0 / 1][limb]
+    // [half][row % 32][16 bytes], i.e. the 6 KB image of a (tile, slab) position is contiguous and consecutive positions of a block follow
+    // each other -- the loader's address is one scalar add per stage.  Piece p of a position: entity block p / 3, limb p % 3.  Wave w
+    // issues piece w of EVERY position and, with every EVEN position p (block-relative), a second one: waves 0, 1 the pieces 4, 5 of p,
+    // waves 2, 3 the pieces 4, 5 of p + 1 (one stage early: that buffer was consumed two stages ago) -- three DMA instructions per wave
+    // and two stages, the same pattern for every wave, so the counted waits are exact (newer than position g + 1: the 4 positions behind
+    // it, two of them even = 6 instructions).  Positions past the block's end re-read its last one.
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_scr;
-    const uint32_t lds_em = lds0 + (uint32_t)(SCRR_NB * SCRR_STAGE + 2 * 128 * 16);
-    auto issue = [&]() {   // this wave's two pieces of the next position into ring buffer ld_buf
-        const uint32_t dst = lds0 + (uint32_t)ld_buf * SCRR_STAGE;
-        scrr_dma16(ebase, vo0, dst + (uint32_t)wv_s * SCRR_PIECE);
-        scrr_dma16(low ? ebase : embase, vo1, low ? dst + (uint32_t)(4 + wv_s) * SCRR_PIECE : lds_em + (uint32_t)(ld_tile & (SCRR_EMB - 1)) * (SCR_ET * 16));
-        ld_buf = (ld_buf + 1) & (SCRR_NB - 1);
-        ebase += SCR_BLK_SLAB;
-        if (++ld_s == S) {
-            ld_s = 0;
-            ld_tile = ld_tile + 1 < ntile ? ld_tile + 1 : ntile - 1;   // (past the end: harmless re-reads of the last tile)
-            set_src(ld_tile);
+    const int G = (int)ntile * S;   // positions of this block
+    const char* const pos_base = reinterpret_cast<const char*>(a.b.elimbs) + (e_begin >> 6) * (int64_t)(S * SCRR_STAGE);
+    const uint32_t max_off = (uint32_t)(G - 1) * SCRR_STAGE;
+    const uint32_t vo0 = (uint32_t)wv_s * SCRR_PIECE + lane16;             // piece w
+    const uint32_t vo1 = (uint32_t)(4 + (wv_s & 1)) * SCRR_PIECE + lane16;   // piece 4 / 5
+    const int late = wv_s >> 1;   // (waves 2, 3: their second piece belongs to the NEXT position)
+    uint32_t ld_off = 0u;
+    int ld_pos = 0, ld_buf = 0;
+    auto issue = [&]() {   // this wave's piece(s) of the next position into ring buffer ld_buf
+        scrr_dma16(pos_base + ld_off, vo0, lds0 + (uint32_t)ld_buf * SCRR_STAGE + (uint32_t)wv_s * SCRR_PIECE);
+        if ((ld_pos & 1) == 0) {
+            const uint32_t off1 = late ? min(ld_off + (uint32_t)SCRR_STAGE, max_off) : ld_off;
+            scrr_dma16(pos_base + off1, vo1, lds0 + (uint32_t)((ld_buf + late) & (SCRR_NB - 1)) * SCRR_STAGE + (uint32_t)(4 + (wv_s & 1)) * SCRR_PIECE);
         }
+        ++ld_pos;
+        ld_buf = (ld_buf + 1) & (SCRR_NB - 1);
+        ld_off = min(ld_off + (uint32_t)SCRR_STAGE, max_off);
     };
 
-    int cnt[16];   // per accumulator register (= query row of this lane): greater | equal << 16
+    // per accumulator register (= query row of this lane): greater, equal; gmask / emask gather one "not greater" / "equal" bit per
+    // output (32 = 16 tiles of two columns) before they are counted
+    int cntg[16], cnte[16];
+    uint32_t gmask[16], emask[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cnt[r] = 0;
+    for (int r = 0; r < 16; ++r) { cntg[r] = 0; cnte[r] = 0; gmask[r] = 0u; emask[r] = 0u; }
     v16i32 acc[3][2];   // [level][entity block]: level 0 = l0 l0', 1 = l0 l1' + l1 l0', 2 = l0 l2' + l1 l1' + l2 l0'
 
     int npend = 0;   // pairs parked in this wave's LDS buffer (wave-uniform)
-    int2* const pend = reinterpret_cast<int2*>(em_s + SCRR_EMB * SCR_ET) + wv * SCRR_PEND;
+    int2* const pend = reinterpret_cast<int2*>(thr_s + 2 * 128) + wv * SCRR_PEND;
     auto flush = [&]() {   // (inline assembly with its own vmcnt(0): it also drains this wave's DMA pieces -- rare, and only stricter)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -201,10 +214,11 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         f = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w};
     };
 
-    set_src(0);
 #pragma unroll
-    for (int i = 0; i < SCRR_D; ++i) issue();   // positions 0 .. D - 1
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * (SCRR_D - 1)) : "memory");   // position 0 has landed: this wave's pieces, and everyone's
+    for (int i = 0; i < SCRR_D; ++i) issue();   // positions 0 .. D - 1 (9 instructions; newer than position 0: 7)
+    static_assert(SCRR_D % 2 == 0 && SCRR_D >= 4 && SCRR_D + 2 <= SCRR_NB, "the counted waits are written for an even number of positions in flight");
+    // (newer than position 0: positions 1 .. D - 1, D / 2 - 1 of them even)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((SCRR_D - 1) + (SCRR_D / 2 - 1)) : "memory");   // position 0 has landed: this wave's pieces, and everyone's
 #pragma unroll
     for (int p = 0; p < 6; ++p) read_frag(frag_ptr, p, eb[0][p / 3][p % 3]);
     rbuf = 1;
@@ -224,20 +238,26 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     // iteration ntile runs the matrix instructions on a re-read tile (results unused).
     // Every matrix instruction is its own inline-assembly statement (operand classes pinned: A in the accumulation file, B / C / D
     // in the vector file -- no copies between the files), separated from the slice behind it by scheduling barriers.
-    // (scalar fp32 on purpose: a packed v_pk_*_f32 next to matrix instructions costs ~22 cycles more than the two scalar operations it
-    // replaces -- /opt/skills/guides/MI355X_MICROARCH.md, per-instruction constants; nine of them per row were ~3 000 cycles a tile)
-    float F0[16], F1[16];
+    // The decision arithmetic, per OUTPUT, is integer: g = (L0 << 8) + L1 + (L2 >> 8) (the three levels folded in units of 2^24 A B_t; the
+    // floor of L2 / 2^8 is below one unit, inside the 2^27 A B the bound carries for the fold) against four integer thresholds of its
+    // (query row, tile) -- ceil((G + E) / sigma), ceil((L - E) / sigma), ceil((EL + E) / sigma), ceil((EH - E) / sigma), sigma = 2^24 A_i
+    // B_t, E = E'(row, the tile's maxima) >= E'(row, candidate) -- computed once per row and tile by the thread that owns the row
+    // (10 operations) instead of ~21 fp32 operations per output: with one wave per SIMD the epilogue's instruction count, not the
+    // matrix pipe, set this kernel's time (profiles/r06e_screen_r_ablations.txt).  An output the tile-wide bound cannot decide is
+    // marked and rechecked exactly like one the per-candidate bound could not decide (a few more of them).
+    int G0[16], G1[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { F0[r] = __builtin_nanf(""); F1[r] = __builtin_nanf(""); }
-    float B20 = 0.f, B21 = 0.f, Y20 = 0.f, Y21 = 0.f, Z20 = 0.f, Z21 = 0.f;   // the previous tile's candidate constants
+    for (int r = 0; r < 16; ++r) { G0[r] = SCRR_NONE; G1[r] = SCRR_NONE; }   // (the sentinel of "no output": smaller than everything, counted nowhere)
+    int nearv = 0;
     int64_t et_prev = e_begin;
     const int row0 = wq + 4 * lh;
-    float4 qm = qm_s[row0], qt = qt_s[row0], qm_n = qm, qt_n = qt;
-    const float k65536 = 65536.f, k256 = 256.f;
-    float s00 = 0.f, s01 = 0.f, e0 = 0.f, e1 = 0.f, lo0 = 0.f, lo1 = 0.f, hi0 = 0.f, hi1 = 0.f;
+    int4 th = thr_s[row0], th_n = th;
     uint32_t undm = 0u;
+    const float4* const tmeta = a.b.tm + (e_begin >> 6);
+    float eb_t = 0.f, isig = 0.f;   // (the threshold slices' temporaries)
 
     for (int t = 0; t <= (int)ntile; ++t) {
+        const float4 tm4 = tmeta[t < (int)ntile ? t : (int)ntile - 1];   // {B_t, max |W e|_2, max |e|_1 / 2, 1 / B_t}: wave-uniform
         scrr_static_for<S>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             constexpr int P = s & 1;
@@ -264,8 +284,9 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 if constexpr (m == 1) {
                     // this wave's pieces of position g + 1 have landed (the D - 2 positions behind it stay in flight) and so have the
                     // other waves'; everyone is past the matrix instructions that consumed position g - 2, whose buffer the DMA reuses
-                    if constexpr (SCRR_ABLATE & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (SCRR_D - 2)) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * (SCRR_D - 2)) : "memory");
+                    // (newer than position g + 1: the D - 2 positions behind it, half of them even)
+                    if constexpr (SCRR_ABLATE & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SCRR_D - 2) + (SCRR_D - 2) / 2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((SCRR_D - 2) + (SCRR_D - 2) / 2) : "memory");
                 } else if constexpr (m == 2) {
                     if constexpr (!(SCRR_ABLATE & 16)) issue();   // position g + D
                     sb = frag_ptr + (size_t)rbuf * SCRR_STAGE;   // position g + 1
@@ -274,35 +295,56 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                     if constexpr (!(SCRR_ABLATE & 32)) read_frag(sb, m - 3, eb[P ^ 1][(m - 3) / 3][(m - 3) % 3]);
                 }
                 // ---- slice k of the previous tile's epilogue: row k / 8 (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4
-                // (lane >> 5)), step k % 8; the arithmetic is rank_screen_kernel_v1's
+                // (lane >> 5)), step k % 8
                 if constexpr (k < 128 && !(SCRR_ABLATE & 1)) {
                     constexpr int r = k >> 3, j = k & 7;
                     if constexpr (j == 0) {
-                        if constexpr (r < 15) { constexpr int rn = ((r + 1) & 3) + 8 * ((r + 1) >> 2); qm_n = qm_s[row0 + rn]; qt_n = qt_s[row0 + rn]; }
-                    } else if constexpr (j == 1) {
-                        s00 = scrr_mul(F0[r], scrr_mul(qm.x, B20)); s01 = scrr_mul(F1[r], scrr_mul(qm.x, B21));   // S~ = f 2^16 A B
-                    } else if constexpr (j == 2) {
-                        // E' = c (gamma |W q|_2 |W e|_2 + A |e|_1 / 2 + B (|q|_1 / 2 + drop A)); the term relative to |S~| sits in the thresholds
-                        e0 = scrr_fma(qm.y, Y20, scrr_fma(qm.z, Z20, scrr_mul(qm.w, B20)));
-                        e1 = scrr_fma(qm.y, Y21, scrr_fma(qm.z, Z21, scrr_mul(qm.w, B21)));
-                    } else if constexpr (j == 3) {
-                        lo0 = scrr_sub(s00, e0); hi0 = scrr_add(s00, e0); lo1 = scrr_sub(s01, e1); hi1 = scrr_add(s01, e1);
-                    } else if constexpr (j == 4 || j == 6) {
-                        // greater: lo >= G; equal after quantisation: lo >= EL and hi < EH
-                        const float lo_ = j == 4 ? lo0 : lo1, hi_ = j == 4 ? hi0 : hi1;
-                        const bool gt = lo_ >= qt.x, eq = (lo_ >= qt.z) && (hi_ < qt.w);
-                        cnt[r] += gt ? 1 : 0;
-                        cnt[r] += eq ? 0x10000 : 0;
-                        asm volatile("" : "+v"(cnt[r]));
-                    } else if constexpr (j == 5 || j == 7) {
-                        // smaller: hi < L; neither of the three: undecided (NaN / infinite bounds compare false everywhere)
-                        constexpr int ni = (j - 5) >> 1;
-                        const float lo_ = j == 5 ? lo0 : lo1, hi_ = j == 5 ? hi0 : hi1;
-                        const bool gt = lo_ >= qt.x, lt = hi_ < qt.y, eq = (lo_ >= qt.z) && (hi_ < qt.w);
-                        undm |= !(gt || lt || eq) ? (1u << (2 * r + ni)) : 0u;
-                        asm volatile("" : "+v"(undm));
-                        if constexpr (j == 7) { qm = qm_n; qt = qt_n; }
+                        if constexpr (r < 15) { constexpr int rn = ((r + 1) & 3) + 8 * ((r + 1) >> 2); th_n = thr_s[((t + 1) & 1) * 128 + row0 + rn]; }
+                    } else if constexpr (j == 2 || j == 3) {
+                        // One output of the row, no scalar register in the chain (a VALU -> SGPR -> VALU round trip costs ~18 cycles next to
+                        // matrix instructions, profiles/r06_mfma_filler_probe.txt): d4 = g - Gi, d1 = g - Li, d2 = g - ELi, d3 = g - EHi
+                        // (thresholds and g inside +-2^30: no overflow).  sign(d4) = "not greater" and sign(~d2 & d3) = "equal" are shifted
+                        // into the row's bit masks (counted every 16 tiles); sign(~d1 & d4 & ~equal) = neither smaller, greater nor
+                        // equal: undecided, marked by the slow path below.
+                        constexpr int ni = j - 2;
+                        const int g = ni ? G1[r] : G0[r];
+                        const int d4 = g - th.x, d1 = g - th.y, d2 = g - th.z, d3 = g - th.w;
+                        const int eqs = ~d2 & d3;
+                        gmask[r] = __builtin_amdgcn_alignbit(gmask[r], (uint32_t)d4, 31);
+                        emask[r] = __builtin_amdgcn_alignbit(emask[r], (uint32_t)eqs, 31);
+                        const int und = ~d1 & d4 & ~eqs;
+                        nearv = ni ? (nearv | und) : und;
+                        asm volatile("" : "+v"(gmask[r]), "+v"(emask[r]), "+v"(nearv));
+                    } else if constexpr (j == 4) {
+                        if (__ballot(nearv < 0) != 0ull) {   // rare (a fraction of a per cent of the outputs): wave-uniform
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                const int g = ni ? G1[r] : G0[r];
+                                const bool near = (g >= th.y) && (g < th.x), eq = (g >= th.z) && (g < th.w);
+                                undm |= (near && !eq) ? (1u << (2 * r + ni)) : 0u;
+                            }
+                        }
+                    } else if constexpr (j == 7) {
+                        th = th_n;
                     }
+                }
+                // ---- this tile's thresholds, by the thread that owns the query row (free slots behind the slices)
+                if constexpr (k == 130) {
+                    // E = c (gamma |W q|_2 max |W e|_2 + A max |e|_1 / 2 + B_t (|q|_1 / 2 + drop A)); 1 / sigma = 1 / (2^24 A) * 1 / B_t
+                    eb_t = __builtin_fmaf(rq_y, tm4.y, __builtin_fmaf(rq_z, tm4.z, rq_w * tm4.x));
+                    isig = rq_iA * tm4.w;
+                } else if constexpr (k == 133) {
+                    // ceil((T +- E) / sigma) as an int32 (|g| < 2^29.1 for S <= 13: thresholds beyond (-2^30 + 64, 2^30] clamp without changing a
+                    // decision); NaN (inf - inf) and scales outside [2^-20, 2^100] (a product could leave fp32's range): nothing decided
+                    const bool okscale = (isig >= 0x1p-20f) && (isig <= 0x1p100f);
+                    const float xa = __builtin_ceilf((thrA + eb_t) * isig), xb = __builtin_ceilf((thrB - eb_t) * isig);
+                    const bool oka = okscale && (xa == xa), okb = okscale && (xb == xb);
+                    const int ia = oka ? (int)fminf(fmaxf(xa, -1073741760.f), 1073741824.f) : (1 << 30);      // (never >=)
+                    const int ib = okb ? (int)fminf(fmaxf(xb, -1073741760.f), 1073741824.f) : -1073741760;    // (never <, but for the sentinel)
+                    int2* const dst = reinterpret_cast<int2*>(thr_s + (t & 1) * 128 + (tid & 127)) + (tid >> 7);
+                    *dst = make_int2(ia, ib);
+                } else if constexpr (k == 140) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the thresholds are in LDS before this wave's next barrier (stage S - 1's)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -329,30 +371,34 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
             else for (int ps = 0; ps < 8; ++ps) append(undm & (0xFu << (4 * ps)), et_prev);   // (<= 4 per lane: 256 per wave)
         }
         undm = 0u;
-        // ---- this tile's accumulators -> F = L0 2^16 + L1 2^8 + L2 (fp32), its candidates' constants -> B2, Y2, Z2
+        if ((t & 15) == 15) {   // 32 "not greater" bits per row gathered: count the others
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { cntg[r] += 32 - __popc(gmask[r]); gmask[r] = 0u; cnte[r] += __popc(emask[r]); emask[r] = 0u; }
+        }
+        // ---- this tile's accumulators -> g = (L0 << 8) + L1 + (L2 >> 8); candidates beyond the range: the sentinel
         {
             const int64_t et = e_begin + (int64_t)t * SCR_ET;
-            // the tile's candidate metas arrived with its first position (a DMA piece of waves 2, 3, behind that stage's barrier);
-            // candidates beyond the range get an infinite bound here: never decided, never counted
-            float4 E0 = em_s[(t & (SCRR_EMB - 1)) * SCR_ET + l31], E1 = em_s[(t & (SCRR_EMB - 1)) * SCR_ET + 32 + l31];
-            if (et + l31 >= e_end) E0.y = INFINITY;
-            if (et + 32 + l31 >= e_end) E1.y = INFINITY;
-            B20 = E0.x; B21 = E1.x; Y20 = E0.y; Y21 = E1.y; Z20 = E0.z; Z21 = E1.z;
 #pragma unroll
             for (int r = 0; r < ((SCRR_ABLATE & 8) ? 1 : 16); ++r) {
-                F0[r] = scrr_fma((float)acc[0][0][r], k65536, scrr_fma((float)acc[1][0][r], k256, (float)acc[2][0][r]));
-                F1[r] = scrr_fma((float)acc[0][1][r], k65536, scrr_fma((float)acc[1][1][r], k256, (float)acc[2][1][r]));
+                G0[r] = (int)(((uint32_t)acc[0][0][r] << 8) + (uint32_t)acc[1][0][r] + (uint32_t)(acc[2][0][r] >> 8));
+                G1[r] = (int)(((uint32_t)acc[0][1][r] << 8) + (uint32_t)acc[1][1][r] + (uint32_t)(acc[2][1][r] >> 8));
+            }
+            if (et + SCR_ET > e_end) {   // (the range's last tile)
+                const bool v0 = et + l31 < e_end, v1 = et + 32 + l31 < e_end;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { G0[r] = v0 ? G0[r] : SCRR_NONE; G1[r] = v1 ? G1[r] : SCRR_NONE; }
             }
             et_prev = et;
-            qm = qm_s[row0]; qt = qt_s[row0];
+            th = thr_s[(t & 1) * 128 + row0];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the positions requested past the end: their DMA must not outlive the workgroup's LDS
     if (npend) flush();
     // ---- per query row: sum over the 32 lanes that share it ----
+    const int nbits = 2 * (((int)ntile + 1) & 15);   // bits gathered since the last count (the masks start at zero: the upper bits are clear)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        int g = cnt[r] & 0xFFFF, e = cnt[r] >> 16;
+        int g = cntg[r] + nbits - __popc(gmask[r]), e = cnte[r] + __popc(emask[r]);
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); e += __shfl_xor(e, o, 64); }
         const int64_t qi = q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh;

@@ -5,6 +5,7 @@
 their dense gradient buffers and optimizer slots, and the scratch used by evaluation.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -583,6 +584,8 @@ class KgeEngine:
         if len(jobs) == 1:
             side, flt, out, stride = jobs[0]
             return [self.rank_side(triples, side, strategy, flt, ent_ids, subset_pos, out=out, out_stride=stride)]
+        if os.environ.get("AMDKGE_EVAL_LANES") == "1":   # (A/B measurements: the sides one after the other)
+            return [self.rank_side(triples, side, strategy, flt, ent_ids, subset_pos, out=out, out_stride=stride) for side, flt, out, stride in jobs]
         # Every lane keeps workspaces of its own (query vectors, the screening pass's fixed-point rows and recheck list -- up to
         # SCREEN_MAX_BYTES --, the filter pass's copy), so two sides in flight about double evaluate()'s peak memory.
         # Beside resident training state on a large table that can be what runs the device out of memory: the sides then run one

@@ -5,8 +5,8 @@ O=gpurun_out/${1:-r06e_ablate}; mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp
-for n in base ${ABL:-1 2 4 9 48 63}; do
-  if [ $n = base ]; then unset AMDKGE_LIB; else export AMDKGE_LIB=$R/build_variants/scrr_ab$n/libamdkge.so; fi
+for n in base ${ABL:-scrr_ab1 scrr_ab2}; do
+  if [ $n = base ]; then unset AMDKGE_LIB; else export AMDKGE_LIB=$R/build_variants/$n/libamdkge.so; fi
   P=/tmp/trace_$n; rm -rf $P; mkdir -p $P
   AMDKGE_SCREEN_KERNEL=4 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o r -- python $R/scripts/screen_time.py > $P/out.log 2> $P/err.log || tail -3 $P/err.log
   python - "$n" <<PY
