@@ -18,7 +18,7 @@ import csv, glob, collections, json, sys
 acc = collections.defaultdict(list)
 for g in glob.glob("$R/$O/pmc_v"+sys.argv[1]+"/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(g)):
-        if "rank_screen_kernel" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "rank_screen_kernel_r" in r["Kernel_Name"] or ("rank_screen_kernel_v1(" in r["Kernel_Name"] and sys.argv[1] == "1"): acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v)/len(v) for k, v in acc.items()}
 if m:
     m["mfma_util"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (m["GRBM_GUI_ACTIVE"] / 8 * 1024) if m.get("GRBM_GUI_ACTIVE") else None
