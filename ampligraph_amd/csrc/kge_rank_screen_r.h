@@ -235,7 +235,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     // measured: MfmaUtil 0.39 with the stages written out but the epilogue behind them).  At the end of a tile its three integer
     // accumulator levels are folded into ONE fp32 value per output (F: 32 registers), which frees the accumulators for the next tile;
     // everything else of the epilogue works on F.  Iteration 0 runs the slices on NaNs (nothing counted, the undecided marks dropped),
-    // iteration ntile runs the matrix instructions on a re-read tile (results unused).
+    // iteration ntile runs the slices alone.
     // Every matrix instruction is its own inline-assembly statement (operand classes pinned: A in the accumulation file, B / C / D
     // in the vector file -- no copies between the files), separated from the slice behind it by scheduling barriers.
     // The decision arithmetic, per OUTPUT, is integer: g = (L0 << 8) + L1 + (L2 >> 8) (the three levels folded in units of 2^24 A B_t; the
@@ -258,6 +258,9 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
 
     for (int t = 0; t <= (int)ntile; ++t) {
         const float4 tm4 = tmeta[t < (int)ntile ? t : (int)ntile - 1];   // {B_t, max |W e|_2, max |e|_1 / 2, 1 / B_t}: wave-uniform
+        // MM = true: the matrix work of tile t between the slices of tile t - 1; false (iteration ntile): the slices alone
+        auto tile_body = [&](auto mm_c) __attribute__((always_inline)) {
+        constexpr bool MM = decltype(mm_c)::value;
         scrr_static_for<S>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             constexpr int P = s & 1;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 constexpr int NI[12] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1};
                 constexpr int QL[12] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2};
                 constexpr int EL[12] = {0, 0, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0};
-                {
+                if constexpr (MM) {
                     v16i32& C = acc[LV[m]][NI[m]];
                     const v4i32& A = qf[s][QL[m]];
                     const v4i32& Bm = eb[P][NI[m]][EL[m]];
@@ -281,7 +284,8 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- the stage's own work, spread over its first slots
-                if constexpr (m == 1) {
+                if constexpr (!MM) {
+                } else if constexpr (m == 1) {
                     // this wave's pieces of position g + 1 have landed (the D - 2 positions behind it stay in flight) and so have the
                     // other waves'; everyone is past the matrix instructions that consumed position g - 2, whose buffer the DMA reuses
                     // (newer than position g + 1: the D - 2 positions behind it, half of them even)
@@ -329,7 +333,8 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                     }
                 }
                 // ---- this tile's thresholds, by the thread that owns the query row (free slots behind the slices)
-                if constexpr (k == 130) {
+                if constexpr (!MM) {
+                } else if constexpr (k == 130) {
                     // E = c (gamma |W q|_2 max |W e|_2 + A max |e|_1 / 2 + B_t (|q|_1 / 2 + drop A)); 1 / sigma = 1 / (2^24 A) * 1 / B_t
                     eb_t = __builtin_fmaf(rq_y, tm4.y, __builtin_fmaf(rq_z, tm4.z, rq_w * tm4.x));
                     isig = rq_iA * tm4.w;
@@ -349,6 +354,8 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+        };
+        if (t < (int)ntile) tile_body(std::true_type{}); else tile_body(std::false_type{});
         // A VALU read of a matrix instruction's result wants up to 19 wait states behind it (8 / 16 passes), and the compiler cannot see
         // into the statements above.  The accumulators and the fragment set the copies below overwrite are operands of the pad: nothing
         // that reads or rewrites them moves in front of it.
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
             for (int r = 0; r < 16; ++r) { cntg[r] += 32 - __popc(gmask[r]); gmask[r] = 0u; cnte[r] += __popc(emask[r]); emask[r] = 0u; }
         }
         // ---- this tile's accumulators -> g = (L0 << 8) + L1 + (L2 >> 8); candidates beyond the range: the sentinel
-        {
+        if (t < (int)ntile) {
             const int64_t et = e_begin + (int64_t)t * SCR_ET;
 #pragma unroll
             for (int r = 0; r < ((SCRR_ABLATE & 8) ? 1 : 16); ++r) {
