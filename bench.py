@@ -101,8 +101,8 @@ def parse():
     if args.optimizer_mode is None:
         args.optimizer_mode = "dense"
     args.preset = args.config or ("C2" if all(getattr(args, k_) == v_ for k_, v_ in PRESETS["C2"].items()) else None)
-    if args.also is None:   # the driver's single command also reports C3, C4 and one GPU's C5 shard
-        args.also = "C3,C4,C5" if (args.preset == "C2" and args.gpus == 1 and args.popularity == "uniform" and not args.deterministic
+    if args.also is None:   # the driver's single command also reports C1, C3, C4 and one GPU's C5 shard (VERDICT r3 #8, r5 #3 / missing #3)
+        args.also = "C1,C3,C4,C5" if (args.preset == "C2" and args.gpus == 1 and args.popularity == "uniform" and not args.deterministic
                                    and args.optimizer_mode == "dense") else "none"
     return args
 
@@ -117,7 +117,7 @@ def preset_args(base, name):
     a.config = a.preset = name
     a.optimizer_mode = PRESETS[name].get("optimizer_mode", "dense")
     a.also = "none"
-    if name == "C4" and base.preset != "C4":   # riding along in another config's line: its CPU legs (a 123 k-row dense Adam on the host) are left out
+    if name in ("C1", "C4") and base.preset != name:   # riding along in another config's line: the CPU legs (C4: a 123 k-row dense Adam on the host) are left out
         a.no_cpu_baseline = True
     if name == "C5" and base.preset != "C5":
         # one GPU's shard of configs[4] riding along (RotatE k = 1000, eta = 64, 6.25 M rows = 50 GB table, 200 GB resident, B = 65 536;

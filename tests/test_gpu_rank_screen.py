@@ -56,14 +56,17 @@ def test_screened_counts_equal_exact_counts(gpu_lib, model, k, N, n, tables):
     print("rechecked pairs", model, k, tables, st, "of", n * N)
 
 
-def test_screened_counts_subsets_ranges_and_bad_rows(gpu_lib):
+# (k = 64: 4-slab rows, rank_screen_kernel_v1; ComplEx k = 200 / DistMult k = 400 / HolE k = 196: 13-slab rows, round 6's rank_screen_kernel_r with
+# its tile-wide candidate scales -- partial last tiles, ranges that do not start on a tile, id lists, non-finite / denormal / zero rows)
+@pytest.mark.parametrize("model,k", [("ComplEx", 64), ("ComplEx", 200), ("DistMult", 400), ("HolE", 196)])
+def test_screened_counts_subsets_ranges_and_bad_rows(gpu_lib, model, k):
     """entities_subset (candidate id list), a candidate range (row-sharded evaluation) and rows holding inf / NaN / denormals."""
     from ampligraph_amd import _ffi
     from ampligraph_amd.engine import KgeEngine
 
-    N, R, k, n = 6000, 5, 64, 600
+    N, R, n = 6000, 5, 600
     rng = np.random.default_rng(3)
-    eng = KgeEngine("ComplEx", k, N, R, max_rel_size=R)
+    eng = KgeEngine(model, k, N, R, max_rel_size=R)
     ent = (rng.normal(size=(N, eng.K)) * 0.3).astype(np.float32)
     rel = (rng.normal(size=(R, eng.K)) * 0.3).astype(np.float32)
     ent[17, 5] = np.inf
@@ -75,11 +78,37 @@ def test_screened_counts_subsets_ranges_and_bad_rows(gpu_lib):
     X[:4, 0] = [17, 99, 200, 201]
     Xd = torch.as_tensor(X).cuda()
     ids = torch.as_tensor(rng.permutation(N)[:3000].astype(np.int32)).cuda()
-    for kw in (dict(), dict(ent_ids=ids), dict(ent_lo=1000, ent_hi=5200), dict(ent_ids=ids, ent_lo=128, ent_hi=2900)):
+    for kw in (dict(), dict(ent_ids=ids), dict(ent_lo=1000, ent_hi=5200), dict(ent_ids=ids, ent_lo=128, ent_hi=2900), dict(ent_lo=17, ent_hi=18),
+               dict(ent_lo=5937, ent_hi=6000)):
         for side in (_ffi.SIDE_S, _ffi.SIDE_O):
             exact, _ = _counts(eng, gpu_lib, Xd, side, 3, **kw)
             scr, st = _counts(eng, gpu_lib, Xd, side, 0, **kw)
             assert np.array_equal(scr, exact), (kw.keys(), side, int((scr != exact).sum()), st)
+
+
+def test_screened_counts_few_far_rows_stay_on_the_tile_scale_path(gpu_lib):
+    """Fewer than 1 / 64 of the rows lie orders of magnitude below their tile's scale: rank_screen_kernel_r keeps the call (no fall-back
+    to per-row scales), their outputs go to the exact recheck -- counts equal, list not overflowed."""
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+
+    N, R, k, n = 9000, 5, 200, 700
+    rng = np.random.default_rng(11)
+    eng = KgeEngine("ComplEx", k, N, R, max_rel_size=R)
+    ent = (rng.normal(size=(N, eng.K)) * 0.25).astype(np.float32)
+    rel = (rng.normal(size=(R, eng.K)) * 0.25).astype(np.float32)
+    far = rng.permutation(N)[:100]                       # 100 of 9 000 rows < 1 / 64
+    ent[far] *= np.exp(rng.uniform(-20, -6, size=(100, 1))).astype(np.float32)
+    ent[far[:5]] *= np.float32(1e6)                      # ... and a few far ABOVE their neighbours (they set their tile's scale)
+    eng.set_tables(ent, rel)
+    X = np.stack([rng.integers(0, N, n), rng.integers(0, R, n), rng.integers(0, N, n)], 1).astype(np.int32)
+    X[:100, 2] = far                                      # positives among them too
+    Xd = torch.as_tensor(X).cuda()
+    for side in (_ffi.SIDE_S, _ffi.SIDE_O):
+        exact, _ = _counts(eng, gpu_lib, Xd, side, 3)
+        scr, st = _counts(eng, gpu_lib, Xd, side, 0)
+        assert np.array_equal(scr, exact), (side, int((scr != exact).sum()), st)
+        assert st is not None and not st[1], st
 
 
 def test_screened_overflowing_recheck_list_falls_back(gpu_lib):
