@@ -1211,7 +1211,6 @@ __global__ void rank_compose_kernel(const int32_t* counts, const int32_t* sub, i
 
 }  // namespace kge
 #include "kge_rank_screen.h"
-#include "kge_rank_screen_g.h"
 #include "kge_rank_screen_r.h"
 constexpr int SCREEN_KERNEL_DEFAULT = 4;   // (see run_screen: rank_screen_kernel_r where it applies -- 13-slab rows --, rank_screen_kernel_v1 elsewhere)
 #define KGE_RANK_EARLY_PART2
@@ -1277,8 +1276,13 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     hipLaunchKernelGGL(rank_limbs_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.Q, (int64_t)g.QW, (const int32_t*)nullptr, (int64_t)0, n, g.U, b.S,
                        (float)(gam * (1.0 + 1e-6)), b.qlimbs, b.qm, (const int*)nullptr);
     if (int rc = check_launch("rank_limbs(Q)")) return rc;
-    // (which screening kernel: see below; kernel r wants the candidates on one scale per tile of 64)
-    static const int screen_kernel_env = [] { const char* ev = getenv("AMDKGE_SCREEN_KERNEL"); const int v = ev ? atoi(ev) : 0; return (v == 1 || v == 3 || v == 4) ? v : SCREEN_KERNEL_DEFAULT; }();
+    // Which screening kernel: rank_screen_kernel_r (round 6, kge_rank_screen_r.h: one wave per SIMD, the query limbs resident in registers,
+    // candidates on one scale per tile of 64) for rows of 13 slabs -- 385 .. 416 int8 units: ComplEx k = 200, DistMult k = 400 --,
+    // rank_screen_kernel_v1 (rounds 3 - 5: query fragments L2 -> registers, entity slab register-staged through LDS) for every other width
+    // and behind kernel r for wild tables.  The same counts either way; AMDKGE_SCREEN_KERNEL=1 pins v1 for A/B runs (read once).  The
+    // variants that measured slower or no faster live in scripts/experiments/: round 5's register-staged LDS form, round 6's LDS-DMA
+    // ring for both operands (g) and the paired-wave split of the limb products (p).
+    static const int screen_kernel_env = [] { const char* ev = getenv("AMDKGE_SCREEN_KERNEL"); const int v = ev ? atoi(ev) : 0; return (v == 1 || v == 4) ? v : SCREEN_KERNEL_DEFAULT; }();
     int screen_kernel = screen_kernel_env;
     if (screen_kernel == 4 && (b.S != 13 || b.cap * 8 < mcand * 16)) screen_kernel = 1;   // (13-slab rows; room for the row records)
     if (screen_kernel == 4) {
@@ -1308,12 +1312,6 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     // U <= 2048; the outer fma's rounding is relative to |f| and sits in the thresholds)
     sa.drop = (float)(((double)g.U * (8388608.0 + 16384.0 + 0.25) + 134217728.0) * (1.0 + 1e-6));
     const int64_t qtiles = (n + SCR_Q - 1) / SCR_Q, etiles = (mcand + SCR_ET - 1) / SCR_ET;
-    // Which screening kernel: rank_screen_kernel_v1 (rounds 3 - 5: query fragments L2 -> registers, entity slab register-staged through
-    // LDS), rank_screen_kernel_g (round 6, kge_rank_screen_g.h: both operands by LDS-DMA into a ring of stage buffers) or
-    // rank_screen_kernel_r (round 6, kge_rank_screen_r.h: one wave per SIMD, the query limbs resident in registers -- rows of 13 slabs,
-    // i.e. 385 .. 416 int8 units: ComplEx k = 200, DistMult k = 400).  The same counts every way; AMDKGE_SCREEN_KERNEL=1 / 3 / 4 pins
-    // one for A/B runs (read once).  Round 5's register-staged "both operands through LDS" form measured slower and lives in
-    // scripts/experiments/rank_screen_kernel_qlds_r05.h.
     // Each block takes a run of entity tiles of one 128-query block.  The run length is the one with the shortest schedule: rounds of
     // `slots` co-resident blocks x (tiles + a block's start-up in tile-times) -- v1 / g: two workgroups per CU, ~0.35 (at C2, 160 x 227
     // tiles, runs of 4 give 18 rounds of 4: 78 tile-times instead of 84 with runs of 9); r: one per CU, and its 39 KB of query limbs come
@@ -1344,8 +1342,6 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_v1)");
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_v1_wild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_v1_wild)");
-        if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCG_LDS_BYTES))
-            return set_error_hip(e, "hipFuncSetAttribute(rank_screen_g)");
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_r<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCRR_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_r)");
         attr_done.done();
@@ -1362,7 +1358,6 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     sa.nblk = (int)nblk;
     if (screen_kernel == 4)   // (the per-row-scale kernel behind rank_screen_kernel_r: a wild table only)
         hipLaunchKernelGGL(rank_screen_kernel_v1_wild, dim3((unsigned)std::min<int64_t>(nblk, 512)), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
-    else if (screen_kernel == 3) hipLaunchKernelGGL(rank_screen_kernel_g, dim3((unsigned)nblk), dim3(SCR_THREADS), SCG_LDS_BYTES, st, sa);
     else hipLaunchKernelGGL(rank_screen_kernel_v1, dim3((unsigned)nblk), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);
     if (int rc = check_launch("rank_screen")) return rc;
     RecheckArgs ra{};

@@ -1,17 +1,22 @@
 // Round 6: the screening kernel restructured around ONE wave per SIMD with the QUERY operand resident in registers.
 // Included by kge_rank.hip behind kge_rank_screen.h, whose limbs / thresholds / recheck / merge kernels, ScreenArgs and error bound it
-// shares: the matrix work (six limb products in three exact int32 accumulator levels per output) and the decision arithmetic of the
-// epilogue are those of rank_screen_kernel_v1 -- the counts are the same integers.
+// shares: the matrix work is rank_screen_kernel_v1's (six limb products in three exact int32 accumulator levels per output), the
+// decisions are the same ones taken in integer arithmetic against a tile-wide bound -- the counts are the same integers.
 //
 // Why.  rank_screen_kernel_v1 (two 256-thread workgroups per CU, 233 registers) re-reads a wave's query fragments from L2 for every
 // entity tile -- 12 KB of the 18 KB a workgroup-stage moves -- and a wave-stage lasts ~1 900 cycles for 384 cycles of matrix work
 // (MfmaUtil 0.38-0.39 for three rounds; every ablation of one instruction class, the register-staged LDS form of round 5 and the LDS-DMA
-// ring of this round left it there: profiles/r06b_pmc_screen_v1.json / _g.json).  At the BASELINE widths (ComplEx k = 200, DistMult k =
-// 400: U = 400 int8 units = S = 13 slabs of 32) the three limbs of a wave's 32 query rows are 13 x 3 x 4 = 156 registers: with ONE wave
-// per SIMD gfx950's unified file gives a wave 512, so they are loaded ONCE per workgroup and stay.  What a stage then needs is the
-// entity slab only (6 KB per workgroup-stage instead of 18, L2 traffic a third), which arrives by LDS-DMA into a ring of eight 6 KB
-// buffers, SIX positions ahead (counted vmcnt; one raw s_barrier per stage), and whose fragments are read from LDS one stage ahead of
-// the matrix instructions that consume them.  Between two matrix instructions the wave issues ~2 other instructions instead of ~9.
+// ring of this round left it there).  At the BASELINE widths (ComplEx k = 200, DistMult k = 400: U = 400 int8 units = S = 13 slabs of
+// 32) the three limbs of a wave's 32 query rows are 13 x 3 x 4 = 156 registers: with ONE wave per SIMD gfx950's unified file gives a
+// wave 512, so they are loaded ONCE per workgroup into the accumulation half of the file and stay.  What a stage then needs is the
+// entity slab only (6 KB per workgroup-stage instead of 18), which arrives by LDS-DMA into a ring of eight 6 KB buffers, six positions
+// ahead (counted vmcnt; one raw s_barrier per stage; 1.5 DMA instructions per wave and stage), and whose fragments are read from LDS
+// one stage ahead of the matrix instructions that consume them.  One wave has nobody to fill its gaps, so the kernel is a software
+// pipeline written out: tile t's 156 matrix instructions (one inline-assembly statement each, operand classes pinned) with tile t - 1's
+// epilogue sliced between them, and an epilogue cut down to what one wave can hide (the step table of round 6):
+// candidates on ONE scale per tile of 64 (rank_limbs_tile_kernel), integer thresholds per (query row, tile) computed once by the
+// thread that owns the row, three integer operations to fold an output's accumulator levels, and four subtractions whose SIGN BITS are
+// gathered into per-row bit masks (no VALU -> SGPR -> VALU round trip) -- the rare undecided outputs go to the exact recheck as before.
 // The tile loop is unrolled over the S slabs (the query registers are indexed statically): one instantiation per S.
 #pragma once
 
@@ -38,12 +43,6 @@ constexpr size_t SCRR_LDS_BYTES = (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + 
 __device__ __forceinline__ void scrr_dma16(const char* sbase, uint32_t voff, uint32_t lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
-
-// Scalar fp32 arithmetic the SLP vectoriser cannot pair into v_pk_*_f32 (see the epilogue slices): same IEEE operations, one result each.
-__device__ __forceinline__ float scrr_mul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float scrr_add(float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float scrr_sub(float a, float b) { float d; asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float scrr_fma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
 template <int N, typename F>
 __device__ __forceinline__ void scrr_static_for(F&& f) {

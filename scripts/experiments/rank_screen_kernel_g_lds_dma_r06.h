@@ -1,3 +1,5 @@
+// NOT PART OF THE PRODUCT (round 6): measured no faster than rank_screen_kernel_v1 (2.119 vs 2.123 ms, MfmaUtil 0.3945 vs 0.3883,
+// profiles/r06b_pmc_screen_g.json); was selectable as AMDKGE_SCREEN_KERNEL=3 in commits eba6079 .. a7dff44 (include it behind kge_rank_screen.h).
 // Round 6: the screening kernel with its operand feed rebuilt around gfx950's LDS-DMA loads.
 // Included by kge_rank.hip behind kge_rank_screen.h, whose limbs / thresholds / recheck / merge kernels, ScreenArgs and bound it shares:
 // the matrix work (six limb products in three exact int32 accumulator levels per output) and the epilogue are those of

@@ -8,7 +8,7 @@ cd /tmp
 for n in base ${ABL:-scrr_ab1 scrr_ab2}; do
   if [ $n = base ]; then unset AMDKGE_LIB; else export AMDKGE_LIB=$R/build_variants/$n/libamdkge.so; fi
   P=/tmp/trace_$n; rm -rf $P; mkdir -p $P
-  AMDKGE_SCREEN_KERNEL=4 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o r -- python $R/scripts/screen_time.py > $P/out.log 2> $P/err.log || tail -3 $P/err.log
+  AMDKGE_SCREEN_KERNEL=${SK:-4} timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o r -- python $R/scripts/screen_time.py > $P/out.log 2> $P/err.log || tail -3 $P/err.log
   python - "$n" <<PY
 import csv, glob, sys
 for g in glob.glob("/tmp/trace_"+sys.argv[1]+"/**/*kernel_stats.csv", recursive=True):

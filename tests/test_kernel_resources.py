@@ -39,7 +39,6 @@ HOT = [
     ("_ZN3kge18tile_direct_kernelILi4ELi4EEEvNS_8TileArgsE", 3),
     ("_ZN3kge27rank_count_mfma_pipe_kernelENS_9CountArgsE", 2),
     ("_ZN3kge21rank_screen_kernel_v1ENS_10ScreenArgsE", 2),
-    ("_ZN3kge20rank_screen_kernel_gENS_10ScreenArgsE", 2),   # round 6: the LDS-DMA form (two 256-thread workgroups per CU)
     # round 6: one wave per SIMD BY DESIGN -- the query limbs (156 registers) stay resident in the accumulation half of the file
     ("_ZN3kge20rank_screen_kernel_rILi13EEEvNS_10ScreenArgsE", 1),
 ]
