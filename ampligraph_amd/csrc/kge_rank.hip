@@ -1317,9 +1317,9 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     // tiles, runs of 4 give 18 rounds of 4: 78 tile-times instead of 84 with runs of 9); r: one per CU, and its 39 KB of query limbs come
     // first (~1 tile-time).
     static const int64_t run_cap = [] { const char* ev = getenv("AMDKGE_SCREEN_RUN"); const int v = ev ? atoi(ev) : 0; return (int64_t)(v > 0 ? v : 64); }();   // (A/B runs: longest run of tiles per block)
-    auto schedule = [&](ScreenArgs& x, int64_t slots, double startup, int64_t& nblk) -> bool {
+    auto schedule = [&](ScreenArgs& x, int64_t slots, double startup, int64_t max_run, int64_t& nblk) -> bool {
         int64_t tiles_per = 1;
-        const int64_t qt8 = 8 * ((qtiles + 7) / 8), lim = etiles < run_cap ? etiles : run_cap;
+        const int64_t qt8 = 8 * ((qtiles + 7) / 8), lim = std::min(etiles < run_cap ? etiles : run_cap, max_run);
         double best = 1e300;
         for (int64_t tp = 1; tp <= lim; ++tp) {
             const int64_t blocks = qt8 * ((etiles + tp - 1) / tp);
@@ -1327,8 +1327,8 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
             if (cost <= best) { best = cost; tiles_per = tp; }   // (ties: the longer run)
         }
         // very large problems: keep the launch below 2^31 blocks and a lane's 16-bit counters (2 candidates per tile) in range
-        while (tiles_per < etiles && tiles_per < 16384 && qt8 * ((etiles + tiles_per - 1) / tiles_per) > (1ll << 24)) tiles_per *= 2;
-        if (tiles_per > 16384) tiles_per = 16384;
+        while (tiles_per < etiles && tiles_per < max_run && qt8 * ((etiles + tiles_per - 1) / tiles_per) > (1ll << 24)) tiles_per *= 2;
+        if (tiles_per > max_run) tiles_per = max_run;
         if (tiles_per > etiles) tiles_per = etiles;
         if (tiles_per < 1) tiles_per = 1;
         const int64_t splits = (etiles + tiles_per - 1) / tiles_per;
@@ -1350,11 +1350,11 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
     if (screen_kernel == 4) {
         ScreenArgs sr = sa;
         sr.wild_mode = 2;
-        if (!schedule(sr, 256, 1.0, nblk)) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
+        if (!schedule(sr, 256, 1.0, SCRR_TMCAP, nblk)) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
         hipLaunchKernelGGL(rank_screen_kernel_r<13>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sr);
         if (int rc = check_launch("rank_screen_r")) return rc;
     }
-    if (!schedule(sa, 512, 0.35, nblk)) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
+    if (!schedule(sa, 512, 0.35, 16384, nblk)) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
     sa.nblk = (int)nblk;
     if (screen_kernel == 4)   // (the per-row-scale kernel behind rank_screen_kernel_r: a wild table only)
         hipLaunchKernelGGL(rank_screen_kernel_v1_wild, dim3((unsigned)std::min<int64_t>(nblk, 512)), dim3(SCR_THREADS), SCR_LDS_BYTES, st, sa);

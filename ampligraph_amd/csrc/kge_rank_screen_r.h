@@ -35,7 +35,8 @@ constexpr int SCRR_PIECE = 1024;                   // bytes per DMA instruction:
 constexpr int SCRR_STAGE = 6 * SCRR_PIECE;         // entity blocks 0, 1 x 3 limbs, as they lie in memory
 constexpr int SCRR_NONE = -(1 << 30);               // "no output here" in the folded accumulators' units (|g| < 2^29.1 for S <= 13; thresholds live in (-2^30, 2^30])
 constexpr int SCRR_PEND = 256;                     // undecided pairs a wave parks in LDS before they go to the list
-constexpr size_t SCRR_LDS_BYTES = (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + 4 * (size_t)SCRR_PEND * 8;   // 61 440: ring, thresholds, parked pairs
+constexpr int SCRR_TMCAP = 1024;                   // tiles per block at most (their metas are staged in LDS; run_screen's schedule holds the run below it)
+constexpr size_t SCRR_LDS_BYTES = (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + 4 * (size_t)SCRR_PEND * 8 + (size_t)SCRR_TMCAP * 16;   // 77 824: ring, thresholds, parked pairs, tile metas
 
 // One LDS-DMA instruction, scalar base + per-lane 32-bit offset: 64 lanes x 16 bytes to LDS bytes [lds, lds + 1 024) (M0 = the
 // wave-uniform LDS byte address; the hardware adds lane x 16).  Inline assembly on purpose (see kge_rank_screen_g.h): the compiler must
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     }
     uint32_t rowmask = 0u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rowmask |= (q0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.n) ? (3u << (2 * r)) : 0u;
+    for (int r = 0; r < 16; ++r) rowmask |= (q0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.n) ? (3u << (30 - 2 * r)) : 0u;   // (bit 31 - (2 r + ni): the order the slices shift the marks in)
 
     // ---- this wave's query fragments, all S slabs x 3 limbs: 39 coalesced 1 KB reads, once (rows beyond n: the stale tail of the last
     // block -- finite integers; their outputs are masked)
@@ -126,6 +127,11 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 const uint4 u = *reinterpret_cast<const uint4*>(qsrc + ((size_t)s * SCR_BLK_SLAB + 1024u * lb + lane16));
                 qf[s][lb] = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w};
             }
+    }
+    float4* const tm_s = reinterpret_cast<float4*>(smem_scr + (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + 4 * (size_t)SCRR_PEND * 8);
+    {   // {B_t, max |W e|_2, max |e|_1 / 2, 1 / B_t} of this block's tiles, staged once (ntile <= SCRR_TMCAP: run_screen's schedule)
+        const float4* const src = a.b.tm + (e_begin >> 6);
+        for (int i = tid; i < (int)ntile; i += SCR_THREADS) tm_s[i] = src[i];
     }
     __syncthreads();   // (the last ordinary loads of the kernel are behind this barrier: from here on every VM operation is a DMA piece)
 
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         while (msk) {
             const int bit = __builtin_ctz(msk);
             msk &= msk - 1;
-            const int r = bit >> 1, ni = bit & 1;
+            const int idx = 31 - bit, r = idx >> 1, ni = idx & 1;
             pend[at++] = make_int2((int)(q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh), (int)(et + ni * 32 + l31));
         }
         npend += total;
@@ -247,16 +253,16 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     int G0[16], G1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { G0[r] = SCRR_NONE; G1[r] = SCRR_NONE; }   // (the sentinel of "no output": smaller than everything, counted nowhere)
-    int nearv = 0;
     int64_t et_prev = e_begin;
     const int row0 = wq + 4 * lh;
     int4 th = thr_s[row0], th_n = th;
     uint32_t undm = 0u;
-    const float4* const tmeta = a.b.tm + (e_begin >> 6);
     float eb_t = 0.f, isig = 0.f;   // (the threshold slices' temporaries)
 
     for (int t = 0; t <= (int)ntile; ++t) {
-        const float4 tm4 = tmeta[t < (int)ntile ? t : (int)ntile - 1];   // {B_t, max |W e|_2, max |e|_1 / 2, 1 / B_t}: wave-uniform
+        // {B_t, max |W e|_2, max |e|_1 / 2, 1 / B_t}: wave-uniform.  From LDS: a vector-memory load here would share vmcnt with the DMA
+        // pieces, and the compiler's wait for it (vmcnt(0)) drained the ring once per tile
+        const float4 tm4 = tm_s[t < (int)ntile ? t : (int)ntile - 1];
         // MM = true: the matrix work of tile t between the slices of tile t - 1; false (iteration ntile): the slices alone
         auto tile_body = [&](auto mm_c) __attribute__((always_inline)) {
         constexpr bool MM = decltype(mm_c)::value;
@@ -304,29 +310,20 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                     if constexpr (j == 0) {
                         if constexpr (r < 15) { constexpr int rn = ((r + 1) & 3) + 8 * ((r + 1) >> 2); th_n = thr_s[((t + 1) & 1) * 128 + row0 + rn]; }
                     } else if constexpr (j == 2 || j == 3) {
-                        // One output of the row, no scalar register in the chain (a VALU -> SGPR -> VALU round trip costs ~18 cycles next to
-                        // matrix instructions, profiles/r06_mfma_filler_probe.txt): d4 = g - Gi, d1 = g - Li, d2 = g - ELi, d3 = g - EHi
-                        // (thresholds and g inside +-2^30: no overflow).  sign(d4) = "not greater" and sign(~d2 & d3) = "equal" are shifted
-                        // into the row's bit masks (counted every 16 tiles); sign(~d1 & d4 & ~equal) = neither smaller, greater nor
-                        // equal: undecided, marked by the slow path below.
+                        // One output of the row, no scalar register and no branch in the chain (a VALU -> SGPR -> VALU round trip costs ~18 cycles
+                        // next to matrix instructions, profiles/r06_mfma_filler_probe.txt; a compare + branch per row ~75, profiles/r06x3_*):
+                        // d4 = g - Gi, d1 = g - Li, d2 = g - ELi, d3 = g - EHi (thresholds and g inside +-2^30: no overflow).  sign(d4) = "not
+                        // greater", sign(~d2 & d3) = "equal" and sign(~d1 & d4 & ~equal) = neither smaller, greater nor equal -- UNDECIDED --
+                        // are shifted into bit masks: two per row, counted every 16 tiles, and one per tile (32 outputs of a lane: bit
+                        // 31 - (2 r + ni)), whose set bits go to the recheck list at the tile's end.
                         constexpr int ni = j - 2;
                         const int g = ni ? G1[r] : G0[r];
                         const int d4 = g - th.x, d1 = g - th.y, d2 = g - th.z, d3 = g - th.w;
                         const int eqs = ~d2 & d3;
                         gmask[r] = __builtin_amdgcn_alignbit(gmask[r], (uint32_t)d4, 31);
                         emask[r] = __builtin_amdgcn_alignbit(emask[r], (uint32_t)eqs, 31);
-                        const int und = ~d1 & d4 & ~eqs;
-                        nearv = ni ? (nearv | und) : und;
-                        asm volatile("" : "+v"(gmask[r]), "+v"(emask[r]), "+v"(nearv));
-                    } else if constexpr (j == 4) {
-                        if (__ballot(nearv < 0) != 0ull) {   // rare (a fraction of a per cent of the outputs): wave-uniform
-#pragma unroll
-                            for (int ni = 0; ni < 2; ++ni) {
-                                const int g = ni ? G1[r] : G0[r];
-                                const bool near = (g >= th.y) && (g < th.x), eq = (g >= th.z) && (g < th.w);
-                                undm |= (near && !eq) ? (1u << (2 * r + ni)) : 0u;
-                            }
-                        }
+                        undm = __builtin_amdgcn_alignbit(undm, (uint32_t)(~d1 & d4 & ~eqs), 31);
+                        asm volatile("" : "+v"(gmask[r]), "+v"(emask[r]), "+v"(undm));
                     } else if constexpr (j == 7) {
                         th = th_n;
                     }
@@ -371,8 +368,8 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         // ---- the previous tile's undecided outputs go to the list
         if (t >= 1) {
             undm &= rowmask;
-            if (et_prev + l31 >= e_end) undm &= 0xAAAAAAAAu;        // candidate of block 0 beyond the range
-            if (et_prev + 32 + l31 >= e_end) undm &= 0x55555555u;   // candidate of block 1 beyond the range
+            if (et_prev + l31 >= e_end) undm &= 0x55555555u;        // candidate of block 0 (the odd bits) beyond the range
+            if (et_prev + 32 + l31 >= e_end) undm &= 0xAAAAAAAAu;   // candidate of block 1 beyond the range
             if (__popcll(__ballot(undm != 0u)) <= SCRR_PEND / 32) append(undm, et_prev);   // (<= 32 outputs per lane)
             else for (int ps = 0; ps < 8; ++ps) append(undm & (0xFu << (4 * ps)), et_prev);   // (<= 4 per lane: 256 per wave)
         }
