@@ -16,8 +16,23 @@
 // epilogue sliced between them, and an epilogue cut down to what one wave can hide (the step table of round 6):
 // candidates on ONE scale per tile of 64 (rank_limbs_tile_kernel), integer thresholds per (query row, tile) computed once by the
 // thread that owns the row, three integer operations to fold an output's accumulator levels, and four subtractions whose SIGN BITS are
-// gathered into per-row bit masks (no VALU -> SGPR -> VALU round trip) -- the rare undecided outputs go to the exact recheck as before.
-// The tile loop is unrolled over the S slabs (the query registers are indexed statically): one instantiation per S.
+// gathered into bit masks -- "not greater" and "equal" per row, "undecided" per tile; no VALU -> SGPR -> VALU round trip and no
+// compare + branch anywhere in the chain -- the rare undecided outputs go to the exact recheck as before.
+// The tile loop is unrolled over the S slabs (the query registers are indexed statically): one instantiation per S, and written out
+// for two consecutive tiles (with an odd S everything that alternates from position to position is a constant of the copy).
+//
+// What the second half of round 6 measured about ONE wave per SIMD (profiles/r06x*, r06y*):
+//   * SQ_VALU_MFMA_COEXEC_CYCLES says how much of the vector work runs in a matrix instruction's shadow: 0.11 of the pipe's busy
+//     cycles with the slices in blocks of ten operations (only the first three or four behind a matrix instruction overlap it: the
+//     next matrix instruction waits behind the rest), 0.19 with <= 3 per slot;
+//   * a v_cmp + s_cbranch per row cost ~75 cycles each (16 per tile): gone, 814 -> 779 us; a vector-memory load in the loop (the tile
+//     metas) made the compiler drain the DMA ring with vmcnt(0) once per tile: staged in LDS;
+//   * 250 scalar instructions and 40 s_waitcnt fewer per tile (a ring addressed by immediates) bought nothing: scalar work is free;
+//   * THE TRAP: gfx90a+ wants two wait states between a VALU write of a register and a matrix instruction that reads it.  The
+//     compiler pads its own matrix instructions; it cannot see into these statements.  When a rearrangement made it park a tile's
+//     first fragments in the accumulation file and copy them back (v_accvgpr_read) right in front of their first use, that matrix
+//     instruction read stale registers -- wrong, run-to-run different ranks in two otherwise correct variants.  The stage-0
+//     statements carry their own s_nop 1, and scripts/check_mfma_hazards.py (tests/test_build_hazards.py) scans the generated code.
 #pragma once
 
 #ifndef SCRR_ABLATE
@@ -150,14 +165,13 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     const uint32_t vo1 = (uint32_t)(4 + (wv_s & 1)) * SCRR_PIECE + lane16;   // piece 4 / 5
     const int late = wv_s >> 1;   // (waves 2, 3: their second piece belongs to the NEXT position)
     uint32_t ld_off = 0u;
-    int ld_pos = 0, ld_buf = 0;
-    auto issue = [&]() {   // this wave's piece(s) of the next position into ring buffer ld_buf
+    int ld_buf = 0;
+    auto issue = [&](auto even_c) __attribute__((always_inline)) {   // this wave's piece(s) of the next position (EVEN: is it an even one?) into ring buffer ld_buf
         scrr_dma16(pos_base + ld_off, vo0, lds0 + (uint32_t)ld_buf * SCRR_STAGE + (uint32_t)wv_s * SCRR_PIECE);
-        if ((ld_pos & 1) == 0) {
+        if constexpr (decltype(even_c)::value) {
             const uint32_t off1 = late ? min(ld_off + (uint32_t)SCRR_STAGE, max_off) : ld_off;
             scrr_dma16(pos_base + off1, vo1, lds0 + (uint32_t)((ld_buf + late) & (SCRR_NB - 1)) * SCRR_STAGE + (uint32_t)(4 + (wv_s & 1)) * SCRR_PIECE);
         }
-        ++ld_pos;
         ld_buf = (ld_buf + 1) & (SCRR_NB - 1);
         ld_off = min(ld_off + (uint32_t)SCRR_STAGE, max_off);
     };
@@ -219,8 +233,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         f = v4i32{(int)u.x, (int)u.y, (int)u.z, (int)u.w};
     };
 
-#pragma unroll
-    for (int i = 0; i < SCRR_D; ++i) issue();   // positions 0 .. D - 1 (9 instructions; newer than position 0: 7)
+    scrr_static_for<SCRR_D>([&](auto ic) __attribute__((always_inline)) { issue(std::bool_constant<(decltype(ic)::value & 1) == 0>{}); });   // positions 0 .. D - 1 (9 instructions; newer than position 0: 7)
     static_assert(SCRR_D % 2 == 0 && SCRR_D >= 4 && SCRR_D + 2 <= SCRR_NB, "the counted waits are written for an even number of positions in flight");
     // (newer than position 0: positions 1 .. D - 1, D / 2 - 1 of them even)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((SCRR_D - 1) + (SCRR_D / 2 - 1)) : "memory");   // position 0 has landed: this wave's pieces, and everyone's
@@ -258,8 +271,14 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     int4 th = thr_s[row0], th_n = th;
     uint32_t undm = 0u;
     float eb_t = 0.f, isig = 0.f;   // (the threshold slices' temporaries)
+    int sd4 = 0, sd1 = 0, sd2 = 0, seq = 0;   // (a row's differences in flight between its slots)
 
-    for (int t = 0; t <= (int)ntile; ++t) {
+    // The tile loop is written out for two consecutive tiles: with an odd number of slabs the parity of a position, of the fragment
+    // registers a stage multiplies from and of the threshold buffer alternate from tile to tile -- compile-time constants of the copy
+    // (TP), not run-time selects and a branch per stage.
+    auto one_tile = [&](auto tp_c, const int t) __attribute__((always_inline)) {
+        constexpr int TP = decltype(tp_c)::value;          // t & 1
+        constexpr int TPS = (S & 1) ? TP : 0;              // parity of the tile's first position
         // {B_t, max |W e|_2, max |e|_1 / 2, 1 / B_t}: wave-uniform.  From LDS: a vector-memory load here would share vmcnt with the DMA
         // pieces, and the compiler's wait for it (vmcnt(0)) drained the ring once per tile
         const float4 tm4 = tm_s[t < (int)ntile ? t : (int)ntile - 1];
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         constexpr bool MM = decltype(mm_c)::value;
         scrr_static_for<S>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
-            constexpr int P = s & 1;
+            constexpr int P = (s + TPS) & 1;
             const char* sb = nullptr;
             scrr_static_for<12>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value;
@@ -284,7 +303,11 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                     const v4i32& A = qf[s][QL[m]];
                     const v4i32& Bm = eb[P][NI[m]][EL[m]];
                     if constexpr (SCRR_ABLATE & 2) asm volatile("" : "+v"(C) : "a"(A), "v"(Bm));
-                    else if constexpr (s == 0 && m < 6) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(C) : "a"(A), "v"(Bm));
+                    // (s_nop 1: a tile's first fragments are parked across the tile's end -- in the accumulation file when the vector
+                    // file is full -- and copied back right in front of their first use; gfx90a+ wants TWO wait states between a VALU
+                    // write of a register and a matrix instruction that reads it, and the compiler, which inserts them for its own matrix
+                    // instructions, cannot see into this statement: scripts/check_mfma_hazards.py scans the generated code for the pattern)
+                    else if constexpr (s == 0 && m < 6) asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(C) : "a"(A), "v"(Bm));
                     else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(C) : "a"(A), "v"(Bm));
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                     if constexpr (SCRR_ABLATE & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SCRR_D - 2) + (SCRR_D - 2) / 2) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((SCRR_D - 2) + (SCRR_D - 2) / 2) : "memory");
                 } else if constexpr (m == 2) {
-                    if constexpr (!(SCRR_ABLATE & 16)) issue();   // position g + D
+                    if constexpr (!(SCRR_ABLATE & 16)) issue(std::bool_constant<((TPS + s + SCRR_D) & 1) == 0>{});   // position g + D
                     sb = frag_ptr + (size_t)rbuf * SCRR_STAGE;   // position g + 1
                     rbuf = (rbuf + 1) & (SCRR_NB - 1);
                 } else if constexpr (m >= 3 && m <= 8) {
@@ -307,23 +330,40 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 // (lane >> 5)), step k % 8
                 if constexpr (k < 128 && !(SCRR_ABLATE & 1)) {
                     constexpr int r = k >> 3, j = k & 7;
+                    // A row = two outputs (entity blocks 0 / 1), no scalar register and no branch in the chain (a VALU -> SGPR -> VALU round
+                    // trip costs ~18 cycles next to matrix instructions, profiles/r06_mfma_filler_probe.txt; a compare + branch per row
+                    // ~75, profiles/r06x3_*): d4 = g - Gi, d1 = g - Li, d2 = g - ELi, d3 = g - EHi (thresholds and g inside +-2^30: no
+                    // overflow).  sign(d4) = "not greater", sign(~d2 & d3) = "equal" and sign(~d1 & d4 & ~equal) = neither smaller, greater
+                    // nor equal -- UNDECIDED -- are shifted into bit masks: two per row, counted every 16 tiles, and one per tile (the 32
+                    // outputs of a lane: bit 31 - (2 r + ni)), whose set bits go to the recheck list at the tile's end.  The row's ~20
+                    // operations are spread over its slots at <= 3 per slot: what a lone wave issues behind a matrix instruction runs
+                    // in its shadow only as long as the next one is not waiting behind it (SQ_VALU_MFMA_COEXEC_CYCLES 0.11 -> 0.19 of
+                    // the matrix pipe's busy cycles, profiles/r06x9_*).
                     if constexpr (j == 0) {
-                        if constexpr (r < 15) { constexpr int rn = ((r + 1) & 3) + 8 * ((r + 1) >> 2); th_n = thr_s[((t + 1) & 1) * 128 + row0 + rn]; }
-                    } else if constexpr (j == 2 || j == 3) {
-                        // One output of the row, no scalar register and no branch in the chain (a VALU -> SGPR -> VALU round trip costs ~18 cycles
-                        // next to matrix instructions, profiles/r06_mfma_filler_probe.txt; a compare + branch per row ~75, profiles/r06x3_*):
-                        // d4 = g - Gi, d1 = g - Li, d2 = g - ELi, d3 = g - EHi (thresholds and g inside +-2^30: no overflow).  sign(d4) = "not
-                        // greater", sign(~d2 & d3) = "equal" and sign(~d1 & d4 & ~equal) = neither smaller, greater nor equal -- UNDECIDED --
-                        // are shifted into bit masks: two per row, counted every 16 tiles, and one per tile (32 outputs of a lane: bit
-                        // 31 - (2 r + ni)), whose set bits go to the recheck list at the tile's end.
-                        constexpr int ni = j - 2;
-                        const int g = ni ? G1[r] : G0[r];
-                        const int d4 = g - th.x, d1 = g - th.y, d2 = g - th.z, d3 = g - th.w;
-                        const int eqs = ~d2 & d3;
-                        gmask[r] = __builtin_amdgcn_alignbit(gmask[r], (uint32_t)d4, 31);
-                        emask[r] = __builtin_amdgcn_alignbit(emask[r], (uint32_t)eqs, 31);
-                        undm = __builtin_amdgcn_alignbit(undm, (uint32_t)(~d1 & d4 & ~eqs), 31);
+                        if constexpr (r < 15) { constexpr int rn = ((r + 1) & 3) + 8 * ((r + 1) >> 2); th_n = thr_s[(TP ^ 1) * 128 + row0 + rn]; }
+                        sd4 = G0[r] - th.x; sd1 = G0[r] - th.y;
+                        asm volatile("" : "+v"(sd4), "+v"(sd1));
+                    } else if constexpr (j == 1) {
+                        const int d2 = G0[r] - th.z, d3 = G0[r] - th.w;
+                        seq = ~d2 & d3;
+                        asm volatile("" : "+v"(seq));
+                    } else if constexpr (j == 2) {
+                        gmask[r] = __builtin_amdgcn_alignbit(gmask[r], (uint32_t)sd4, 31);
+                        emask[r] = __builtin_amdgcn_alignbit(emask[r], (uint32_t)seq, 31);
+                        undm = __builtin_amdgcn_alignbit(undm, (uint32_t)(~sd1 & sd4 & ~seq), 31);
                         asm volatile("" : "+v"(gmask[r]), "+v"(emask[r]), "+v"(undm));
+                    } else if constexpr (j == 3) {
+                        sd4 = G1[r] - th.x; sd1 = G1[r] - th.y; sd2 = G1[r] - th.z;
+                        asm volatile("" : "+v"(sd4), "+v"(sd1), "+v"(sd2));
+                    } else if constexpr (j == 4) {
+                        const int d3 = G1[r] - th.w;
+                        seq = ~sd2 & d3;
+                        gmask[r] = __builtin_amdgcn_alignbit(gmask[r], (uint32_t)sd4, 31);
+                        asm volatile("" : "+v"(seq), "+v"(gmask[r]));
+                    } else if constexpr (j == 5) {
+                        emask[r] = __builtin_amdgcn_alignbit(emask[r], (uint32_t)seq, 31);
+                        undm = __builtin_amdgcn_alignbit(undm, (uint32_t)(~sd1 & sd4 & ~seq), 31);
+                        asm volatile("" : "+v"(emask[r]), "+v"(undm));
                     } else if constexpr (j == 7) {
                         th = th_n;
                     }
@@ -342,7 +382,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                     const bool oka = okscale && (xa == xa), okb = okscale && (xb == xb);
                     const int ia = oka ? (int)fminf(fmaxf(xa, -1073741760.f), 1073741824.f) : (1 << 30);      // (never >=)
                     const int ib = okb ? (int)fminf(fmaxf(xb, -1073741760.f), 1073741824.f) : -1073741760;    // (never <, but for the sentinel)
-                    int2* const dst = reinterpret_cast<int2*>(thr_s + (t & 1) * 128 + (tid & 127)) + (tid >> 7);
+                    int2* const dst = reinterpret_cast<int2*>(thr_s + TP * 128 + (tid & 127)) + (tid >> 7);
                     *dst = make_int2(ia, ib);
                 } else if constexpr (k == 140) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the thresholds are in LDS before this wave's next barrier (stage S - 1's)
@@ -353,18 +393,9 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         };
         if (t < (int)ntile) tile_body(std::true_type{}); else tile_body(std::false_type{});
         // A VALU read of a matrix instruction's result wants up to 19 wait states behind it (8 / 16 passes), and the compiler cannot see
-        // into the statements above.  The accumulators and the fragment set the copies below overwrite are operands of the pad: nothing
-        // that reads or rewrites them moves in front of it.
+        // into the statements above.  The accumulators are operands of the pad: nothing that reads them moves in front of it.
         asm volatile("s_nop 15\n\ts_nop 7"
-                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
-                       "+v"(eb[0][0][0]), "+v"(eb[0][0][1]), "+v"(eb[0][0][2]), "+v"(eb[0][1][0]), "+v"(eb[0][1][1]), "+v"(eb[0][1][2])
-                     :: "memory");
-        if constexpr (S & 1) {   // (an odd number of stages: the next tile's first fragments sit in the other parity)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int lb = 0; lb < 3; ++lb) eb[0][ni][lb] = eb[1][ni][lb];
-        }
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]) :: "memory");
         // ---- the previous tile's undecided outputs go to the list
         if (t >= 1) {
             undm &= rowmask;
@@ -392,8 +423,13 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 for (int r = 0; r < 16; ++r) { G0[r] = v0 ? G0[r] : SCRR_NONE; G1[r] = v1 ? G1[r] : SCRR_NONE; }
             }
             et_prev = et;
-            th = thr_s[(t & 1) * 128 + row0];
+            th = thr_s[TP * 128 + row0];
         }
+    };
+    for (int t = 0; t <= (int)ntile; t += 2) {
+        one_tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 > (int)ntile) break;
+        one_tile(std::integral_constant<int, 1>{}, t + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the positions requested past the end: their DMA must not outlive the workgroup's LDS
     if (npend) flush();
