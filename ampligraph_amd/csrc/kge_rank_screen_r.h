@@ -36,7 +36,7 @@
 #pragma once
 
 #ifndef SCRR_ABLATE
-#define SCRR_ABLATE 0   // development (scripts/build_variant.sh with EXTRA=-DSCRR_ABLATE=n): 1 no epilogue slices, 2 no matrix instructions, 4 no stage barrier, 8 no fold of the accumulators, 16 no DMA, 32 no fragment reads -- wrong counts, timing only
+#define SCRR_ABLATE 0   // development (scripts/build_variant.sh with EXTRA=-DSCRR_ABLATE=n): 1 no epilogue slices, 2 no matrix instructions, 4 no stage barrier, 8 no fold of the accumulators, 16 no DMA, 32 no fragment reads, 64 no hand-over of the undecided outputs -- wrong counts, timing only
 #endif
 
 namespace kge {
@@ -51,7 +51,9 @@ constexpr int SCRR_STAGE = 6 * SCRR_PIECE;         // entity blocks 0, 1 x 3 lim
 constexpr int SCRR_NONE = -(1 << 30);               // "no output here" in the folded accumulators' units (|g| < 2^29.1 for S <= 13; thresholds live in (-2^30, 2^30])
 constexpr int SCRR_PEND = 256;                     // undecided pairs a wave parks in LDS before they go to the list
 constexpr int SCRR_TMCAP = 1024;                   // tiles per block at most (their metas are staged in LDS; run_screen's schedule holds the run below it)
-constexpr size_t SCRR_LDS_BYTES = (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + 4 * (size_t)SCRR_PEND * 8 + (size_t)SCRR_TMCAP * 16;   // 77 824: ring, thresholds, parked pairs, tile metas
+constexpr int SCRR_UB = 16;                        // tiles whose undecided marks are handed over together
+constexpr size_t SCRR_LDS_UND = (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + 4 * (size_t)SCRR_PEND * 8 + (size_t)SCRR_TMCAP * 16;   // [SCRR_UB][256] uint32: a thread's marks of the last tiles
+constexpr size_t SCRR_LDS_BYTES = SCRR_LDS_UND + (size_t)SCRR_UB * 256 * 4;   // 94 208: ring, thresholds, parked pairs, tile metas, marks
 
 // One LDS-DMA instruction, scalar base + per-lane 32-bit offset: 64 lanes x 16 bytes to LDS bytes [lds, lds + 1 024) (M0 = the
 // wave-uniform LDS byte address; the hardware adds lane x 16).  Inline assembly on purpose (see kge_rank_screen_g.h): the compiler must
@@ -166,8 +168,19 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     const int late = wv_s >> 1;   // (waves 2, 3: their second piece belongs to the NEXT position)
     uint32_t ld_off = 0u;
     int ld_buf = 0;
-    auto issue = [&](auto even_c) __attribute__((always_inline)) {   // this wave's piece(s) of the next position (EVEN: is it an even one?) into ring buffer ld_buf
+#ifndef SCRR_FIRST_SLOT
+#define SCRR_FIRST_SLOT 6    // development: the stage's slot that issues the wave's first piece (>= 2: behind the stage barrier of slot 1)
+#endif
+#ifndef SCRR_SECOND_SLOT
+#define SCRR_SECOND_SLOT 10  // development: the stage's slot that issues the wave's SECOND piece of an even position (2: with the first)
+#endif
+    // this wave's piece(s) of the next position (EVEN: is it an even one?) into ring buffer ld_buf: the first piece, then -- for an even
+    // position -- the second (issue_second; it may sit in a later slot of the stage: the counted waits only need both in front of the next
+    // stage's), then the advance
+    auto issue_first = [&]() __attribute__((always_inline)) {
         scrr_dma16(pos_base + ld_off, vo0, lds0 + (uint32_t)ld_buf * SCRR_STAGE + (uint32_t)wv_s * SCRR_PIECE);
+    };
+    auto issue_second = [&](auto even_c) __attribute__((always_inline)) {
         if constexpr (decltype(even_c)::value) {
             const uint32_t off1 = late ? min(ld_off + (uint32_t)SCRR_STAGE, max_off) : ld_off;
             scrr_dma16(pos_base + off1, vo1, lds0 + (uint32_t)((ld_buf + late) & (SCRR_NB - 1)) * SCRR_STAGE + (uint32_t)(4 + (wv_s & 1)) * SCRR_PIECE);
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         ld_buf = (ld_buf + 1) & (SCRR_NB - 1);
         ld_off = min(ld_off + (uint32_t)SCRR_STAGE, max_off);
     };
+    auto issue = [&](auto even_c) __attribute__((always_inline)) { issue_first(); issue_second(even_c); };
 
     // per accumulator register (= query row of this lane): greater, equal; gmask / emask gather one "not greater" / "equal" bit per
     // output (32 = 16 tiles of two columns) before they are counted
@@ -224,6 +238,55 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         npend += total;
     };
 
+    // The usual tile marks one or two outputs per WAVE (0.09 % of them at C2), and handing them over tile by tile -- a prefix sum over the
+    // lanes (six dependent cross-lane steps) and a divergent loop, or a scalar walk over the marked lanes: either way a handful of VALU ->
+    // SGPR round trips -- cost ~650 cycles per tile with the matrix pipe idle (profiles/r06y12_*: 51 us of the kernel's 712).  So a thread
+    // parks its tile mask in LDS (one ds_write) and the wave hands over SCRR_UB tiles at a time: one prefix sum over the lanes' totals,
+    // then every lane walks ITS marks (a handful of iterations for the wave).  A batch with more marks than the wave's parking buffer holds
+    // (wild rows, non-finite values) goes tile by tile through the compacting path above.
+    uint32_t* const und_s = reinterpret_cast<uint32_t*>(smem_scr + SCRR_LDS_UND) + tid;   // [slot][thread]
+    auto hand_over = [&](const int t0, const int cnt) {   // the marks of tiles t0 .. t0 + cnt - 1 of this block (slots 0 .. cnt - 1)
+        int mine = 0;
+        uint32_t nz = 0u;   // which of the slots hold marks of this lane
+#pragma unroll
+        for (int i = 0; i < SCRR_UB; ++i) {
+            const uint32_t v = (i < cnt) ? und_s[i * 256] : 0u;
+            mine += __popc(v);
+            nz |= v ? (1u << i) : 0u;
+        }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
+        const int total = __shfl(incl, 63, 64);
+        if (!total) return;
+        if (total > SCRR_PEND) {
+            for (int i = 0; i < cnt; ++i) {
+                const uint32_t msk = und_s[i * 256];
+                const int64_t et = e_begin + (int64_t)(t0 + i) * SCR_ET;
+                if (__popcll(__ballot(msk != 0u)) <= SCRR_PEND / 32) append(msk, et);   // (<= 32 outputs per lane)
+                else for (int ps = 0; ps < 8; ++ps) append(msk & (0xFu << (4 * ps)), et);   // (<= 4 per lane: 256 per wave)
+            }
+            return;
+        }
+        if (npend + total > SCRR_PEND) flush();
+        int at = npend + incl - mine;
+        uint32_t msk = 0u;
+        int ti = 0;
+        for (int left = mine; left > 0; --left) {   // (divergent: one mark of the lane per iteration, the next marked slot fetched when a mask runs out)
+            const bool fresh = msk == 0u;
+            const int tn = __builtin_ctz(nz | 0x10000u);
+            ti = fresh ? tn : ti;
+            nz = fresh ? (nz & (nz - 1u)) : nz;
+            const uint32_t ld = und_s[ti * 256];
+            msk = fresh ? ld : msk;
+            const int bit = __builtin_ctz(msk);
+            msk &= msk - 1u;
+            const int idx = 31 - bit, r = idx >> 1, ni = idx & 1;
+            pend[at++] = make_int2((int)(q0 + wq + (r & 3) + 8 * (r >> 2) + 4 * lh), (int)(e_begin + (int64_t)(t0 + ti) * SCR_ET + ni * 32 + l31));
+        }
+        npend += total;
+    };
+
     // this lane's 16 bytes inside a 1 KB piece: [half][row]
     const char* const frag_ptr = smem_scr + (lh * 512 + l31 * 16);
     v4i32 eb[2][2][3];   // [stage parity][entity block][limb]: the fragments of the NEXT stage are read while this one multiplies
@@ -234,7 +297,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     };
 
     scrr_static_for<SCRR_D>([&](auto ic) __attribute__((always_inline)) { issue(std::bool_constant<(decltype(ic)::value & 1) == 0>{}); });   // positions 0 .. D - 1 (9 instructions; newer than position 0: 7)
-    static_assert(SCRR_D % 2 == 0 && SCRR_D >= 4 && SCRR_D + 2 <= SCRR_NB, "the counted waits are written for an even number of positions in flight");
+    static_assert(SCRR_D % 2 == 0 && SCRR_D >= 2 && SCRR_D + 2 <= SCRR_NB, "the counted waits are written for an even number of positions in flight");
     // (newer than position 0: positions 1 .. D - 1, D / 2 - 1 of them even)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((SCRR_D - 1) + (SCRR_D / 2 - 1)) : "memory");   // position 0 has landed: this wave's pieces, and everyone's
 #pragma unroll
@@ -320,12 +383,13 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                     if constexpr (SCRR_ABLATE & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SCRR_D - 2) + (SCRR_D - 2) / 2) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((SCRR_D - 2) + (SCRR_D - 2) / 2) : "memory");
                 } else if constexpr (m == 2) {
-                    if constexpr (!(SCRR_ABLATE & 16)) issue(std::bool_constant<((TPS + s + SCRR_D) & 1) == 0>{});   // position g + D
                     sb = frag_ptr + (size_t)rbuf * SCRR_STAGE;   // position g + 1
                     rbuf = (rbuf + 1) & (SCRR_NB - 1);
                 } else if constexpr (m >= 3 && m <= 8) {
                     if constexpr (!(SCRR_ABLATE & 32)) read_frag(sb, m - 3, eb[P ^ 1][(m - 3) / 3][(m - 3) % 3]);
                 }
+                if constexpr (MM && m == SCRR_FIRST_SLOT && !(SCRR_ABLATE & 16)) issue_first();   // position g + D
+                if constexpr (MM && m == SCRR_SECOND_SLOT && !(SCRR_ABLATE & 16)) issue_second(std::bool_constant<((TPS + s + SCRR_D) & 1) == 0>{});
                 // ---- slice k of the previous tile's epilogue: row k / 8 (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4
                 // (lane >> 5)), step k % 8
                 if constexpr (k < 128 && !(SCRR_ABLATE & 1)) {
@@ -397,12 +461,15 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
         asm volatile("s_nop 15\n\ts_nop 7"
                      : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]) :: "memory");
         // ---- the previous tile's undecided outputs go to the list
-        if (t >= 1) {
+        if (t >= 1 && !(SCRR_ABLATE & 64)) {
             undm &= rowmask;
-            if (et_prev + l31 >= e_end) undm &= 0x55555555u;        // candidate of block 0 (the odd bits) beyond the range
-            if (et_prev + 32 + l31 >= e_end) undm &= 0xAAAAAAAAu;   // candidate of block 1 beyond the range
-            if (__popcll(__ballot(undm != 0u)) <= SCRR_PEND / 32) append(undm, et_prev);   // (<= 32 outputs per lane)
-            else for (int ps = 0; ps < 8; ++ps) append(undm & (0xFu << (4 * ps)), et_prev);   // (<= 4 per lane: 256 per wave)
+            if (et_prev + SCR_ET > e_end) {   // (the range's last tile)
+                if (et_prev + l31 >= e_end) undm &= 0x55555555u;        // candidate of block 0 (the odd bits) beyond the range
+                if (et_prev + 32 + l31 >= e_end) undm &= 0xAAAAAAAAu;   // candidate of block 1 beyond the range
+            }
+            const int slot = (t - 1) & (SCRR_UB - 1);
+            und_s[slot * 256] = undm;
+            if (slot == SCRR_UB - 1 || t == (int)ntile) hand_over(t - 1 - slot, slot + 1);
         }
         undm = 0u;
         if ((t & 15) == 15) {   // 32 "not greater" bits per row gathered: count the others
