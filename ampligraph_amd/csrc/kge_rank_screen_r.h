@@ -392,8 +392,14 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 if constexpr (MM && m == SCRR_SECOND_SLOT && !(SCRR_ABLATE & 16)) issue_second(std::bool_constant<((TPS + s + SCRR_D) & 1) == 0>{});
                 // ---- slice k of the previous tile's epilogue: row k / 8 (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4
                 // (lane >> 5)), step k % 8
-                if constexpr (k < 128 && !(SCRR_ABLATE & 1)) {
-                    constexpr int r = k >> 3, j = k & 7;
+                // (a tile of S slabs has 12 S slots; the 128 steps -- 16 rows x 8 -- go to its first SLICE_SLOTS of them in order, one per slot
+                // at S = 13, several per slot for narrower rows)
+                constexpr int SLICE_SLOTS = 12 * S - 28 < 128 ? 12 * S - 28 : 128;
+                constexpr int Q_LO = k < SLICE_SLOTS ? (k * 128 + SLICE_SLOTS - 1) / SLICE_SLOTS : 128;
+                constexpr int Q_HI = k < SLICE_SLOTS ? ((k + 1) * 128 + SLICE_SLOTS - 1) / SLICE_SLOTS : 128;
+                if constexpr (!(SCRR_ABLATE & 1)) scrr_static_for<Q_HI - Q_LO>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = Q_LO + decltype(qc)::value;
+                    constexpr int r = q >> 3, j = q & 7;
                     // A row = two outputs (entity blocks 0 / 1), no scalar register and no branch in the chain (a VALU -> SGPR -> VALU round
                     // trip costs ~18 cycles next to matrix instructions, profiles/r06_mfma_filler_probe.txt; a compare + branch per row
                     // ~75, profiles/r06x3_*): d4 = g - Gi, d1 = g - Li, d2 = g - ELi, d3 = g - EHi (thresholds and g inside +-2^30: no
@@ -431,14 +437,14 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                     } else if constexpr (j == 7) {
                         th = th_n;
                     }
-                }
+                });
                 // ---- this tile's thresholds, by the thread that owns the query row (free slots behind the slices)
                 if constexpr (!MM) {
-                } else if constexpr (k == 130) {
+                } else if constexpr (k == 12 * S - 26) {
                     // E = c (gamma |W q|_2 max |W e|_2 + A max |e|_1 / 2 + B_t (|q|_1 / 2 + drop A)); 1 / sigma = 1 / (2^24 A) * 1 / B_t
                     eb_t = __builtin_fmaf(rq_y, tm4.y, __builtin_fmaf(rq_z, tm4.z, rq_w * tm4.x));
                     isig = rq_iA * tm4.w;
-                } else if constexpr (k == 133) {
+                } else if constexpr (k == 12 * S - 23) {
                     // ceil((T +- E) / sigma) as an int32 (|g| < 2^29.1 for S <= 13: thresholds beyond (-2^30 + 64, 2^30] clamp without changing a
                     // decision); NaN (inf - inf) and scales outside [2^-20, 2^100] (a product could leave fp32's range): nothing decided
                     const bool okscale = (isig >= 0x1p-20f) && (isig <= 0x1p100f);
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                     const int ib = okb ? (int)fminf(fmaxf(xb, -1073741760.f), 1073741824.f) : -1073741760;    // (never <, but for the sentinel)
                     int2* const dst = reinterpret_cast<int2*>(thr_s + TP * 128 + (tid & 127)) + (tid >> 7);
                     *dst = make_int2(ia, ib);
-                } else if constexpr (k == 140) {
+                } else if constexpr (k == 12 * S - 16) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the thresholds are in LDS before this wave's next barrier (stage S - 1's)
                 }
                 __builtin_amdgcn_sched_barrier(0);
