@@ -1,3 +1,11 @@
+// NOT IN THE PRODUCT LIBRARY (round 6, measured and dropped): 844 us against r's 818 - 838 on the same box -- 280 instructions fewer per
+// tile (26 scalar instead of 275, 41 s_waitcnt instead of 68) bought nothing: scalar work and waits are free beside matrix instructions.
+// Its recheck list also differed from r's (252 524 against 257 556 pairs): never debugged; probably the unpadded VALU-write ->
+// matrix-instruction-read pattern that later explained two other variants (kge_rank_screen_r.h, scripts/check_mfma_hazards.py) -- the copies
+// behind its two PAIR bodies are where the allocator would have put them.  Kept for the record of the idea (ring buffer = slab index:
+// every LDS address of the loop an immediate); profiles/r06x2_screen_variants.txt.  To build it again: include behind kge_rank_screen_r.h
+// and launch rank_screen_kernel_s<13> with ScrsLds<13>::bytes of dynamic LDS (git show 214863e^ has the wiring).
+//
 // Round 6, second step: rank_screen_kernel_r with its instruction stream cut down to what ONE wave can issue.
 // Included by kge_rank.hip behind kge_rank_screen_r.h (whose static_for and constants it uses).  Same matrix work, same decisions, same
 // counts as kernels v1 / r.

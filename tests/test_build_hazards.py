@@ -39,3 +39,20 @@ def test_rank_kernels_have_no_unpadded_valu_write_in_front_of_a_matrix_instructi
     assert "v_mfma_i32_32x32x32_i8" in text
     hits = chk.scan(text)
     assert hits == [], "\n".join("%s: %s -> %s" % (k, w, m) for k, _, w, m in hits[:10])
+    # rank_screen_kernel_r<13> fills the register file and parks a few dwords that are live across its tile loop
+    # (tests/test_kernel_resources.py): stored before the loop, loaded behind it -- never between two matrix instructions
+    kernel, lines = None, {}
+    for raw in text.split("\n"):
+        l = raw.split(";")[0].strip()
+        if l.endswith(":") and l.startswith("_ZN3kge20rank_screen_kernel_r"):
+            kernel = l[:-1]
+            lines[kernel] = []
+        elif l.startswith(".Lfunc_end"):
+            kernel = None
+        elif kernel and l and not l.startswith("."):
+            lines[kernel].append(l)
+    assert len(lines) >= 3
+    for k, ls in lines.items():
+        mf = [i for i, l in enumerate(ls) if l.startswith("v_mfma")]
+        inside = [l for l in ls[mf[0]:mf[-1] + 1] if l.startswith("scratch_")]
+        assert inside == [], (k, inside[:4])

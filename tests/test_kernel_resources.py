@@ -41,6 +41,8 @@ HOT = [
     ("_ZN3kge21rank_screen_kernel_v1ENS_10ScreenArgsE", 2),
     # round 6: one wave per SIMD BY DESIGN -- the query limbs (156 registers) stay resident in the accumulation half of the file
     ("_ZN3kge20rank_screen_kernel_rILi13EEEvNS_10ScreenArgsE", 1),
+    ("_ZN3kge20rank_screen_kernel_rILi10EEEvNS_10ScreenArgsE", 1),
+    ("_ZN3kge20rank_screen_kernel_rILi7EEEvNS_10ScreenArgsE", 1),
 ]
 
 
@@ -49,13 +51,18 @@ HOT = [
 # loaded once after them: no scratch access inside a loop) instead of dropping to two waves.  The default-mode ComplEx / RotatE
 # kernels must NOT need that: with parked dwords C4 measured 0.408 ms against 0.384 (profiles/r05l_*).
 FORCED_THREE_WAVES = {_f(2, 1, 1, det=True)}
+# rank_screen_kernel_r<13> fills the whole unified file (256 + 256 registers, one wave per SIMD); since the tile loop is written out
+# for two tile parities the allocator parks a dozen dwords that are live ACROSS the loop (stored before it, loaded behind it: the
+# final reduction's operands) -- tests/test_build_hazards.py holds the generated code to "no scratch access between the kernel's
+# first and last matrix instruction".
+PARKED_ACROSS_THE_LOOP = {"_ZN3kge20rank_screen_kernel_rILi13EEEvNS_10ScreenArgsE": 64}
 
 
 @pytest.mark.parametrize("name,waves", HOT, ids=[h[0][7:60] for h in HOT])
 def test_hot_kernel_occupancy(res, name, waves):
     assert name in res, "kernel not in the library (renamed? update the guard)"
     k = res[name]
-    assert k["scratch"] == 0 or (name in FORCED_THREE_WAVES and k["scratch"] <= 24), k
+    assert k["scratch"] == 0 or (name in FORCED_THREE_WAVES and k["scratch"] <= 24) or k["scratch"] <= PARKED_ACROSS_THE_LOOP.get(name, 0), k
     assert k["waves_per_simd"] >= waves, k
 
 
@@ -70,7 +77,7 @@ def test_no_kernel_spills_except_the_known_wide_row_fallbacks(res):
                # round 6: the per-row-scale fall-back behind rank_screen_kernel_r (a persistent loop around rank_screen_kernel_v1's body,
                # taken only for tables whose rows lie orders of magnitude apart): the loop state costs it a few parked dwords
                "_ZN3kge26rank_screen_kernel_v1_wildENS_10ScreenArgsE",
-               } | FORCED_THREE_WAVES
+               } | FORCED_THREE_WAVES | set(PARKED_ACROSS_THE_LOOP)
     assert set(spilling) <= allowed, spilling
 
 
