@@ -141,3 +141,30 @@ def test_screened_overflowing_recheck_list_falls_back(gpu_lib):
     flag = buf[:8].view(torch.int32).cpu().numpy()
     assert flag[1] != 0 and flag[0] > 8200
     assert np.array_equal(counts.cpu().numpy(), exact)
+
+
+@pytest.mark.parametrize("model,k,undecided", [("ComplEx", 200, 52503), ("DistMult", 200, 29446), ("ComplEx", 150, 39257)])
+def test_screened_pass_is_repeatable_down_to_its_recheck_list(gpu_lib, model, k, undecided):
+    """The screening kernels issue their matrix instructions as inline assembly; round 6 met two rearrangements of rank_screen_kernel_r in
+    which a matrix instruction read a register a VALU copy had written fewer than two wait states before (tests/test_build_hazards.py):
+    one of them produced the RIGHT ranks on this very input and a recheck list that differed from run to run (~1 % of one entity block's
+    marks) -- the equality of the counts with the exact kernel does not see that.  Same call five times: the same number of undecided
+    pairs, the same counts; and the count of undecided pairs is the shipped kernel's (a hazard moves it, a legitimate change of the
+    bound would too: then update the figures)."""
+    from ampligraph_amd import _ffi
+    from ampligraph_amd.engine import KgeEngine
+
+    N, R, n = 14505, 237, 4096
+    rng = np.random.default_rng(0)
+    eng = KgeEngine(model, k, N, R, max_rel_size=R)
+    eng.set_tables((rng.normal(size=(N, eng.K)) * 0.25).astype(np.float32), (rng.normal(size=(R, eng.K)) * 0.25).astype(np.float32))
+    X = np.stack([rng.integers(0, N, n), rng.integers(0, R, n), rng.integers(0, N, n)], 1).astype(np.int32)
+    Xd = torch.as_tensor(X).cuda()
+    exact, _ = _counts(eng, gpu_lib, Xd, _ffi.SIDE_S, 3)
+    seen = []
+    for _ in range(5):
+        scr, st = _counts(eng, gpu_lib, Xd, _ffi.SIDE_S, 0)
+        assert np.array_equal(scr, exact) and st is not None and not st[1], st
+        seen.append(st[0])
+    assert len(set(seen)) == 1, seen
+    assert seen[0] == undecided, (seen[0], undecided)   # (profiles/r06y*: the shipped rank_screen_kernel_r<13 / 7 / 10> on this input)
