@@ -56,7 +56,7 @@ constexpr size_t SCRR_LDS_UND = (size_t)SCRR_NB * SCRR_STAGE + 2 * 128 * 16 + 4 
 constexpr size_t SCRR_LDS_BYTES = SCRR_LDS_UND + (size_t)SCRR_UB * 256 * 4;   // 94 208: ring, thresholds, parked pairs, tile metas, marks
 
 // One LDS-DMA instruction, scalar base + per-lane 32-bit offset: 64 lanes x 16 bytes to LDS bytes [lds, lds + 1 024) (M0 = the
-// wave-uniform LDS byte address; the hardware adds lane x 16).  Inline assembly on purpose (see kge_rank_screen_g.h): the compiler must
+// wave-uniform LDS byte address; the hardware adds lane x 16).  Inline assembly on purpose (as in scripts/experiments/rank_screen_kernel_g_lds_dma_r06.h): the compiler must
 // not know an LDS write is pending, the pieces are counted by hand.
 __device__ __forceinline__ void scrr_dma16(const char* sbase, uint32_t voff, uint32_t lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
@@ -169,10 +169,10 @@ __global__ __launch_bounds__(SCR_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     uint32_t ld_off = 0u;
     int ld_buf = 0;
 #ifndef SCRR_FIRST_SLOT
-#define SCRR_FIRST_SLOT 6    // development: the stage's slot that issues the wave's first piece (>= 2: behind the stage barrier of slot 1)
+#define SCRR_FIRST_SLOT 6    // the stage's slot that issues the wave's first piece (>= 2: behind the stage barrier of slot 1)
 #endif
 #ifndef SCRR_SECOND_SLOT
-#define SCRR_SECOND_SLOT 10  // development: the stage's slot that issues the wave's SECOND piece of an even position (2: with the first)
+#define SCRR_SECOND_SLOT 10  // ... and its SECOND piece of an even position: two ~60 - 90-cycle DMA issues in ONE slot starve the matrix pipe (both in slot 2: 726 us; 6 / 10: 691 - 714, other splits within noise of it: profiles/r06y7 - r06y9)
 #endif
     // this wave's piece(s) of the next position (EVEN: is it an even one?) into ring buffer ld_buf: the first piece, then -- for an even
     // position -- the second (issue_second; it may sit in a later slot of the stage: the counted waits only need both in front of the next
