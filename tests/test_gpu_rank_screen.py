@@ -24,7 +24,8 @@ def _counts(eng, gpu_lib, Xd, side, which, **kw):
 @pytest.mark.parametrize("model,k,N,n", [("ComplEx", 200, 14505, 2000), ("DistMult", 400, 9000, 1500), ("HolE", 350, 3000, 700),
                                           ("DistMult", 50, 5000, 300), ("ComplEx", 1000, 2000, 256), ("ComplEx", 16, 700, 130),
                                           # (7- and 10-slab rows: the narrower instantiations of rank_screen_kernel_r, several slice steps per slot)
-                                          ("DistMult", 200, 14505, 2000), ("ComplEx", 100, 6000, 1500), ("ComplEx", 150, 9000, 1100), ("DistMult", 300, 4100, 600)])
+                                          ("DistMult", 200, 14505, 2000), ("ComplEx", 100, 6000, 1500), ("ComplEx", 150, 9000, 1100), ("DistMult", 300, 4100, 600),
+                                          ("DistMult", 100, 8000, 900), ("ComplEx", 50, 5000, 700), ("DistMult", 128, 3000, 500)])
 @pytest.mark.parametrize("tables", ["gaussian", "wild", "ties"])
 def test_screened_counts_equal_exact_counts(gpu_lib, model, k, N, n, tables):
     from ampligraph_amd import _ffi
@@ -58,7 +59,7 @@ def test_screened_counts_equal_exact_counts(gpu_lib, model, k, N, n, tables):
     print("rechecked pairs", model, k, tables, st, "of", n * N)
 
 
-# (k = 64: 4-slab rows, rank_screen_kernel_v1; ComplEx k = 200 / DistMult k = 400 / HolE k = 196: 13-slab rows, DistMult k = 200: 7, ComplEx k = 150: 10 -- round 6's rank_screen_kernel_r with
+# (k = 64: 4-slab rows; ComplEx k = 200 / DistMult k = 400 / HolE k = 196: 13-slab rows, DistMult k = 200: 7, ComplEx k = 150: 10 -- round 6's rank_screen_kernel_r with
 # its tile-wide candidate scales -- partial last tiles, ranges that do not start on a tile, id lists, non-finite / denormal / zero rows)
 @pytest.mark.parametrize("model,k", [("ComplEx", 64), ("ComplEx", 200), ("DistMult", 400), ("HolE", 196), ("DistMult", 200), ("ComplEx", 150)])
 def test_screened_counts_subsets_ranges_and_bad_rows(gpu_lib, model, k):

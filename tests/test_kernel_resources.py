@@ -43,6 +43,7 @@ HOT = [
     ("_ZN3kge20rank_screen_kernel_rILi13EEEvNS_10ScreenArgsE", 1),
     ("_ZN3kge20rank_screen_kernel_rILi10EEEvNS_10ScreenArgsE", 1),
     ("_ZN3kge20rank_screen_kernel_rILi7EEEvNS_10ScreenArgsE", 1),
+    ("_ZN3kge20rank_screen_kernel_rILi4EEEvNS_10ScreenArgsE", 1),
 ]
 
 
