@@ -25,7 +25,8 @@ def _counts(eng, gpu_lib, Xd, side, which, **kw):
                                           ("DistMult", 50, 5000, 300), ("ComplEx", 1000, 2000, 256), ("ComplEx", 16, 700, 130),
                                           # (7- and 10-slab rows: the narrower instantiations of rank_screen_kernel_r, several slice steps per slot)
                                           ("DistMult", 200, 14505, 2000), ("ComplEx", 100, 6000, 1500), ("ComplEx", 150, 9000, 1100), ("DistMult", 300, 4100, 600),
-                                          ("DistMult", 100, 8000, 900), ("ComplEx", 50, 5000, 700), ("DistMult", 128, 3000, 500)])
+                                          ("DistMult", 100, 8000, 900), ("ComplEx", 50, 5000, 700), ("DistMult", 128, 3000, 500),
+                                          ("ComplEx", 128, 7000, 1200), ("DistMult", 256, 5000, 800)])
 @pytest.mark.parametrize("tables", ["gaussian", "wild", "ties"])
 def test_screened_counts_equal_exact_counts(gpu_lib, model, k, N, n, tables):
     from ampligraph_amd import _ffi
