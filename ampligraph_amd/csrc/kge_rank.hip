@@ -1277,15 +1277,15 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
                        (float)(gam * (1.0 + 1e-6)), b.qlimbs, b.qm, (const int*)nullptr);
     if (int rc = check_launch("rank_limbs(Q)")) return rc;
     // Which screening kernel: rank_screen_kernel_r (round 6, kge_rank_screen_r.h: one wave per SIMD, the query limbs resident in registers,
-    // candidates on one scale per tile of 64) for rows of 13, 10, 8, 7 or 4 slabs -- 385 .. 416 int8 units: ComplEx k = 200, DistMult k = 400;
-    // 289 .. 320: ComplEx k = 150, DistMult k = 300; 225 .. 256: ComplEx k = 128, DistMult k = 256; 193 .. 224: ComplEx k = 100, DistMult k = 200; 97 .. 128: ComplEx k = 50 / 64, DistMult k = 100 --,
+    // candidates on one scale per tile of 64) for rows of 4 .. 13 slabs -- 97 .. 416 int8 units: ComplEx k = 50 .. 208, DistMult k = 97 .. 416 (BASELINE's ComplEx k = 200 and
+    // DistMult k = 400 are 13-slab rows; the reference's published DistMult k = 350 is 11) --,
     // rank_screen_kernel_v1 (rounds 3 - 5: query fragments L2 -> registers, entity slab register-staged through LDS) for every other width
     // and behind kernel r for wild tables.  The same counts either way; AMDKGE_SCREEN_KERNEL=1 pins v1 for A/B runs (read once).  The
     // variants that measured slower or no faster live in scripts/experiments/: round 5's register-staged LDS form, round 6's LDS-DMA
     // ring for both operands (g) and the paired-wave split of the limb products (p).
     static const int screen_kernel_env = [] { const char* ev = getenv("AMDKGE_SCREEN_KERNEL"); const int v = ev ? atoi(ev) : 0; return (v == 1 || v == 4) ? v : SCREEN_KERNEL_DEFAULT; }();
     int screen_kernel = screen_kernel_env;
-    if (screen_kernel == 4 && (!(b.S == 13 || b.S == 10 || b.S == 8 || b.S == 7 || b.S == 4) || b.cap * 8 < mcand * 16)) screen_kernel = 1;   // (the instantiated widths; room for the row records)
+    if (screen_kernel == 4 && (b.S < 4 || b.S > 13 || b.cap * 8 < mcand * 16)) screen_kernel = 1;   // (the instantiated widths; room for the row records)
     if (screen_kernel == 4) {
         // (the row records of the first pass live in the head of the pair list, unused until the screening kernel)
         float4* const stats = reinterpret_cast<float4*>(b.pairs);
@@ -1343,7 +1343,9 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_v1)");
         if (hipError_t e = hipFuncSetAttribute((const void*)rank_screen_kernel_v1_wild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_BYTES))
             return set_error_hip(e, "hipFuncSetAttribute(rank_screen_v1_wild)");
-        for (const void* f : {(const void*)rank_screen_kernel_r<13>, (const void*)rank_screen_kernel_r<10>, (const void*)rank_screen_kernel_r<8>, (const void*)rank_screen_kernel_r<7>, (const void*)rank_screen_kernel_r<4>})
+        for (const void* f : {(const void*)rank_screen_kernel_r<13>, (const void*)rank_screen_kernel_r<12>, (const void*)rank_screen_kernel_r<11>, (const void*)rank_screen_kernel_r<10>,
+                              (const void*)rank_screen_kernel_r<9>, (const void*)rank_screen_kernel_r<8>, (const void*)rank_screen_kernel_r<7>, (const void*)rank_screen_kernel_r<6>,
+                              (const void*)rank_screen_kernel_r<5>, (const void*)rank_screen_kernel_r<4>})
             if (hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCRR_LDS_BYTES))
                 return set_error_hip(e, "hipFuncSetAttribute(rank_screen_r)");
         attr_done.done();
@@ -1353,11 +1355,12 @@ static int run_screen(const amdkge_model* m, const float* d_ent, const int32_t* 
         ScreenArgs sr = sa;
         sr.wild_mode = 2;
         if (!schedule(sr, 256, 1.0, SCRR_TMCAP, nblk)) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");
-        if (b.S == 13) hipLaunchKernelGGL(rank_screen_kernel_r<13>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sr);
-        else if (b.S == 10) hipLaunchKernelGGL(rank_screen_kernel_r<10>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sr);
-        else if (b.S == 8) hipLaunchKernelGGL(rank_screen_kernel_r<8>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sr);
-        else if (b.S == 7) hipLaunchKernelGGL(rank_screen_kernel_r<7>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sr);
-        else hipLaunchKernelGGL(rank_screen_kernel_r<4>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sr);
+        switch (b.S) {
+#define KGE_SCR_R(N) case N: hipLaunchKernelGGL(rank_screen_kernel_r<N>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sr); break
+            KGE_SCR_R(13); KGE_SCR_R(12); KGE_SCR_R(11); KGE_SCR_R(10); KGE_SCR_R(9); KGE_SCR_R(8); KGE_SCR_R(7); KGE_SCR_R(6); KGE_SCR_R(5);
+            default: hipLaunchKernelGGL(rank_screen_kernel_r<4>, dim3((unsigned)nblk), dim3(SCR_THREADS), SCRR_LDS_BYTES, st, sr); break;
+#undef KGE_SCR_R
+        }
         if (int rc = check_launch("rank_screen_r")) return rc;
     }
     if (!schedule(sa, 512, 0.35, 16384, nblk)) return set_error(AMDKGE_EUNSUPPORTED, "rank_counts: too many tiles for one launch");

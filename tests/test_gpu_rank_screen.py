@@ -26,7 +26,9 @@ def _counts(eng, gpu_lib, Xd, side, which, **kw):
                                           # (7- and 10-slab rows: the narrower instantiations of rank_screen_kernel_r, several slice steps per slot)
                                           ("DistMult", 200, 14505, 2000), ("ComplEx", 100, 6000, 1500), ("ComplEx", 150, 9000, 1100), ("DistMult", 300, 4100, 600),
                                           ("DistMult", 100, 8000, 900), ("ComplEx", 50, 5000, 700), ("DistMult", 128, 3000, 500),
-                                          ("ComplEx", 128, 7000, 1200), ("DistMult", 256, 5000, 800)])
+                                          ("ComplEx", 128, 7000, 1200), ("DistMult", 256, 5000, 800),
+                                          # (5, 6, 9, 11, 12 slabs; DistMult k = 350 is the reference's published width)
+                                          ("ComplEx", 80, 4000, 600), ("DistMult", 192, 6000, 700), ("ComplEx", 144, 5000, 500), ("DistMult", 350, 9000, 1000), ("ComplEx", 192, 3000, 600)])
 @pytest.mark.parametrize("tables", ["gaussian", "wild", "ties"])
 def test_screened_counts_equal_exact_counts(gpu_lib, model, k, N, n, tables):
     from ampligraph_amd import _ffi
@@ -62,7 +64,7 @@ def test_screened_counts_equal_exact_counts(gpu_lib, model, k, N, n, tables):
 
 # (k = 64: 4-slab rows; ComplEx k = 200 / DistMult k = 400 / HolE k = 196: 13-slab rows, DistMult k = 200: 7, ComplEx k = 150: 10 -- round 6's rank_screen_kernel_r with
 # its tile-wide candidate scales -- partial last tiles, ranges that do not start on a tile, id lists, non-finite / denormal / zero rows)
-@pytest.mark.parametrize("model,k", [("ComplEx", 64), ("ComplEx", 200), ("DistMult", 400), ("HolE", 196), ("DistMult", 200), ("ComplEx", 150)])
+@pytest.mark.parametrize("model,k", [("ComplEx", 64), ("ComplEx", 200), ("DistMult", 400), ("HolE", 196), ("DistMult", 200), ("ComplEx", 150), ("DistMult", 350), ("ComplEx", 80)])
 def test_screened_counts_subsets_ranges_and_bad_rows(gpu_lib, model, k):
     """entities_subset (candidate id list), a candidate range (row-sharded evaluation) and rows holding inf / NaN / denormals."""
     from ampligraph_amd import _ffi

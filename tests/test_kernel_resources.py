@@ -41,10 +41,7 @@ HOT = [
     ("_ZN3kge21rank_screen_kernel_v1ENS_10ScreenArgsE", 2),
     # round 6: one wave per SIMD BY DESIGN -- the query limbs (156 registers) stay resident in the accumulation half of the file
     ("_ZN3kge20rank_screen_kernel_rILi13EEEvNS_10ScreenArgsE", 1),
-    ("_ZN3kge20rank_screen_kernel_rILi10EEEvNS_10ScreenArgsE", 1),
-    ("_ZN3kge20rank_screen_kernel_rILi8EEEvNS_10ScreenArgsE", 1),
-    ("_ZN3kge20rank_screen_kernel_rILi7EEEvNS_10ScreenArgsE", 1),
-    ("_ZN3kge20rank_screen_kernel_rILi4EEEvNS_10ScreenArgsE", 1),
+] + [(f"_ZN3kge20rank_screen_kernel_rILi{S}EEEvNS_10ScreenArgsE", 1) for S in range(4, 13)   # (the narrower instantiations)
 ]
 
 
