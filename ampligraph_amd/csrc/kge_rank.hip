@@ -1212,7 +1212,7 @@ __global__ void rank_compose_kernel(const int32_t* counts, const int32_t* sub, i
 }  // namespace kge
 #include "kge_rank_screen.h"
 #include "kge_rank_screen_r.h"
-constexpr int SCREEN_KERNEL_DEFAULT = 4;   // (see run_screen: rank_screen_kernel_r where it applies -- 13-slab rows --, rank_screen_kernel_v1 elsewhere)
+constexpr int SCREEN_KERNEL_DEFAULT = 4;   // (see run_screen: rank_screen_kernel_r where it applies -- rows of 4 .. 13 slabs --, rank_screen_kernel_v1 elsewhere)
 #define KGE_RANK_EARLY_PART2
 #include "kge_rank_early.h"   // part 2: workspace, row flags, the exact recheck of the distance models
 namespace kge {
